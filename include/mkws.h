@@ -1,0 +1,182 @@
+/*
+ * mkws.h -- C-ABI of libmkws_hip.so: the MI355X (gfx950) hot path of multilingual_kws
+ * (micro-frontend features -> EfficientNet-B0 embedding -> few-shot head).
+ *
+ * The reference (harvard-edge/multilingual_kws) is pure Python on TensorFlow and has no FFI; its
+ * boundary for this path is a Python function surface.  Each entry point below names the reference
+ * call it replaces (file:line relative to the reference repo).  INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types.  Returns MKWS_OK (0) or a negative mkws_status;
+ *    never throws.  mkws_last_error() returns a thread-local message for the last failure.
+ *  - every `d_*` pointer is caller-owned DEVICE memory (e.g. torch tensor.data_ptr()), contiguous,
+ *    row-major.  `h_*` pointers are host memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All *_forward / *_step
+ *    calls are asynchronous on that stream, allocate nothing and never synchronise the device, so
+ *    they are hipGraph-capturable.  Handles own only tables, weights and a workspace sized at create.
+ *  - a handle belongs to the device that was current at create; not thread-safe; distinct handles are.
+ *  - there is no CPU fallback: with no usable GPU, create fails with MKWS_ERR_NO_DEVICE.
+ */
+#ifndef MKWS_H_
+#define MKWS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKWS_ABI_VERSION 1
+
+typedef enum mkws_status {
+  MKWS_OK = 0,
+  MKWS_ERR_INVALID_ARG = -1,   /* NULL pointer, negative size, batch > max_batch, ... */
+  MKWS_ERR_UNSUPPORTED = -2,   /* configuration outside what the kernels implement */
+  MKWS_ERR_NO_DEVICE = -3,     /* no HIP device / not gfx950 */
+  MKWS_ERR_HIP = -4,           /* a HIP runtime call failed; see mkws_last_error() */
+  MKWS_ERR_ALLOC = -5,
+  MKWS_ERR_BAD_WEIGHTS = -6    /* weight blob does not match the architecture */
+} mkws_status;
+
+int mkws_abi_version(void);
+const char* mkws_last_error(void);
+/* Name of the architecture the device code was compiled for ("gfx950"). */
+const char* mkws_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Micro-frontend.  Replaces the AudioMicrofrontend op call in
+ *   multilingual_kws/embedding/input_data.py:19-35  (to_micro_spectrogram)
+ * including the `audio * 32768 -> int16` cast (:23) and the `* 10/256` scaling (:34), batched.
+ * Field defaults = input_data.py:25-33 plus the TF Python wrapper's own defaults.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mkws_frontend_cfg {
+  int32_t sample_rate;          /* 16000 */
+  int32_t window_size_ms;       /* 30  (model_settings["window_size_samples"]*1000/sample_rate) */
+  int32_t window_step_ms;       /* 20 */
+  int32_t num_channels;         /* 40  (model_settings["fingerprint_width"]) */
+  float upper_band_limit;       /* 7500 */
+  float lower_band_limit;       /* 125 */
+  int32_t smoothing_bits;       /* 10 */
+  float even_smoothing;         /* 0.025 */
+  float odd_smoothing;          /* 0.06 */
+  float min_signal_remaining;   /* 0.05 */
+  int32_t enable_pcan;          /* 1 */
+  float pcan_strength;          /* 0.95 */
+  float pcan_offset;            /* 80 */
+  int32_t gain_bits;            /* 21 */
+  int32_t enable_log;           /* 1 */
+  int32_t scale_shift;          /* 6 */
+} mkws_frontend_cfg;
+
+typedef struct mkws_frontend mkws_frontend;
+
+/* Fills *cfg with the defaults above. */
+void mkws_frontend_default_cfg(mkws_frontend_cfg* cfg);
+
+/* Host-only (no GPU needed): builds the integer tables for `cfg` exactly as the upstream C library
+ * does and copies table `which` into dst (at most cap_bytes).  Returns the table's size in bytes,
+ * or a negative mkws_status.  `which`: */
+enum {
+  MKWS_FT_WINDOW_COEF = 0,     /* int16[window_size] */
+  MKWS_FT_TWIDDLES = 1,        /* int16[2*ncfft]  (r,i) pairs of the ncfft-point complex FFT */
+  MKWS_FT_SUPER_TWIDDLES = 2,  /* int16[2*(ncfft/2)] */
+  MKWS_FT_FB_WEIGHTS = 3,      /* int16[num_weights] */
+  MKWS_FT_FB_UNWEIGHTS = 4,    /* int16[num_weights] */
+  MKWS_FT_FB_FREQ_STARTS = 5,  /* int16[num_channels+1] */
+  MKWS_FT_FB_WEIGHT_STARTS = 6,/* int16[num_channels+1] */
+  MKWS_FT_FB_WIDTHS = 7,       /* int16[num_channels+1] */
+  MKWS_FT_PCAN_LUT = 8,        /* int16[125] */
+  MKWS_FT_LOG_LUT = 9,         /* uint16[130] */
+  MKWS_FT_SCALARS = 10         /* int32[8]: window_size, window_step, fft_size, start_index, end_index,
+                                  num_weights, snr_shift, correction_bits */
+};
+int mkws_frontend_host_table(const mkws_frontend_cfg* cfg, int which, void* dst, size_t cap_bytes);
+
+/* Number of frames the op emits for n_samples of audio (0 if shorter than one window). */
+int mkws_frontend_num_frames(const mkws_frontend_cfg* cfg, int n_samples);
+
+/* Builds the tables on the host, uploads them once.  max_samples bounds n_samples of later calls. */
+int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_frontend** out);
+void mkws_frontend_destroy(mkws_frontend* fe);
+
+/* d_audio float32 [B, n_samples] in [-1,1]  ->  d_spec float32 [B, frames, channels]
+ * (= raw uint16 * 10/256, what to_micro_spectrogram returns).  d_raw (optional, may be NULL) receives
+ * the op's raw uint16 [B, frames, channels] for bit-exact checks. */
+int mkws_frontend_forward_f32(mkws_frontend* fe, const float* d_audio, int B, int n_samples,
+                              float* d_spec, uint16_t* d_raw, void* stream);
+/* Same with int16 PCM input (what decode_wav holds before the /32768, input_data.py:41-45). */
+int mkws_frontend_forward_i16(mkws_frontend* fe, const int16_t* d_audio, int B, int n_samples,
+                              float* d_spec, uint16_t* d_raw, void* stream);
+
+/* Streaming form of batch_streaming_analysis.py:99-117: one long recording d_audio [n_samples]
+ * (float32), windows of `window_samples` every `hop_samples`; window w covers samples
+ * [w*hop, w*hop + window_samples).  Emits d_spec [num_windows, frames, channels] with
+ * num_windows = 1 + (n_samples - window_samples) / hop_samples... (0 if too short).  Requires
+ * hop_samples to be a multiple of the frame step so per-frame FFT/filterbank work is shared
+ * across overlapping windows; the noise-reduction/PCAN recurrence restarts per window exactly as
+ * the reference's per-window op call does.  Returns num_windows or a negative mkws_status. */
+int mkws_frontend_stream_f32(mkws_frontend* fe, const float* d_audio, int n_samples,
+                             int window_samples, int hop_samples, float* d_spec, uint16_t* d_raw,
+                             int max_windows, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding model.  Replaces `embedding.predict(x)` on the Keras model
+ *   EfficientNetB0(include_top=False, weights=None, input_shape=(49,40,1)) -> GAP ->
+ *   Dense 2048 relu -> Dense 2048 relu -> Dense 1024 selu ("dense_2")
+ * defined at multilingual_kws/train_multilingual_embedding.py:58-83 and cut at dense_2 by
+ * multilingual_kws/embedding/transfer_learning.py:36-43 / distance_filtering.py:18-27.
+ * Weights arrive as one host blob of float32 tensors in Keras order/layout (HWIO conv kernels,
+ * [in,out] dense kernels, BN gamma/beta/mean/var); multilingual_kws_amd/weights.py writes it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mkws_embed mkws_embed;
+
+/* Number of float32 values the weight blob must hold (12 967 004 params + BN statistics). */
+size_t mkws_embed_weight_count(void);
+/* Host-only: writes a JSON manifest (tensor name, shape, offset into the blob) into dst; returns
+ * bytes needed (call with cap 0 to size). */
+int mkws_embed_weight_manifest(char* dst, size_t cap_bytes);
+
+int mkws_embed_create(const float* h_weights, size_t n_floats, int max_batch, mkws_embed** out);
+void mkws_embed_destroy(mkws_embed* em);
+/* d_spec float32 [B,49,40,1] (NHWC, i.e. the frontend's output) -> d_emb float32 [B,1024]. */
+int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, void* stream);
+/* Debug/parity tap: copies the activation of a named stage (e.g. "stem", "block2a", "top", "gap",
+ * "dense_0") of the LAST forward into d_dst (float32, NHWC); returns element count or negative. */
+int mkws_embed_tap(mkws_embed* em, const char* stage, int B, float* d_dst, size_t cap_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Few-shot head.  Replaces Dense(18,tanh) -> Dense(3,softmax) + SparseCategoricalCrossentropy +
+ * Adam of multilingual_kws/embedding/transfer_learning.py:47-59 and the per-step work of
+ * xfer.fit (:86-93) on the frozen embedding.
+ * Parameter vector layout (float32, P = in*hid + hid + hid*cls + cls = 18 507 for 1024/18/3):
+ *   W1[in,hid] | b1[hid] | W2[hid,cls] | b2[cls]     (Keras [in,out] kernels)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mkws_head mkws_head;
+
+int mkws_head_create(int in_dim, int hidden, int classes, int max_batch, mkws_head** out);
+void mkws_head_destroy(mkws_head* hd);
+int mkws_head_param_count(const mkws_head* hd);
+/* Device pointers into the handle's own state (valid until destroy): params, grads, Adam m, Adam v.
+ * Exposed so the data-parallel host code can all-reduce the flat gradient with RCCL in place. */
+float* mkws_head_params(mkws_head* hd);
+float* mkws_head_grads(mkws_head* hd);
+int mkws_head_set_params(mkws_head* hd, const float* h_params, int n);   /* also zeroes Adam state */
+int mkws_head_get_params(mkws_head* hd, float* h_params, int n, void* stream);
+/* d_emb [B,in] -> d_probs [B,classes] (softmax probabilities, what model.predict returns). */
+int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, void* stream);
+/* Forward + mean sparse-CE loss + backward into the handle's grad buffer (gradient of the MEAN loss
+ * over these B rows).  d_labels int32 [B].  d_stats float32[2] receives {sum of per-row loss,
+ * number of correct argmax predictions} for these B rows. */
+int mkws_head_loss_grad(mkws_head* hd, const float* d_emb, const int32_t* d_labels, int B,
+                        float* d_stats, void* stream);
+/* Keras Adam update from the grad buffer (grad is multiplied by grad_scale first, e.g. 1/world_size
+ * after a sum all-reduce): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps). */
+int mkws_head_adam_step(mkws_head* hd, float lr, float beta1, float beta2, float eps, int step_t,
+                        float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKWS_H_ */

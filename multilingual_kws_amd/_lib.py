@@ -1,0 +1,92 @@
+"""ctypes loader for lib/libmkws_hip.so (C-ABI: include/mkws.h).  Fails loudly; no fallback."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmkws_hip.so")
+
+MKWS_OK = 0
+
+
+class MkwsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmkws_hip error {code}: {msg}")
+        self.code = code
+
+
+class FrontendCfg(ctypes.Structure):
+    """mkws_frontend_cfg (include/mkws.h)."""
+    _fields_ = [
+        ("sample_rate", ctypes.c_int32), ("window_size_ms", ctypes.c_int32),
+        ("window_step_ms", ctypes.c_int32), ("num_channels", ctypes.c_int32),
+        ("upper_band_limit", ctypes.c_float), ("lower_band_limit", ctypes.c_float),
+        ("smoothing_bits", ctypes.c_int32), ("even_smoothing", ctypes.c_float),
+        ("odd_smoothing", ctypes.c_float), ("min_signal_remaining", ctypes.c_float),
+        ("enable_pcan", ctypes.c_int32), ("pcan_strength", ctypes.c_float),
+        ("pcan_offset", ctypes.c_float), ("gain_bits", ctypes.c_int32),
+        ("enable_log", ctypes.c_int32), ("scale_shift", ctypes.c_int32),
+    ]
+
+
+# every symbol include/mkws.h declares: (name, restype, argtypes)
+_P, _I, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_CFG = ctypes.POINTER(FrontendCfg)
+SYMBOLS = [
+    ("mkws_abi_version", _I, []),
+    ("mkws_last_error", ctypes.c_char_p, []),
+    ("mkws_build_arch", ctypes.c_char_p, []),
+    ("mkws_frontend_default_cfg", None, [_CFG]),
+    ("mkws_frontend_host_table", _I, [_CFG, _I, _P, _SZ]),
+    ("mkws_frontend_num_frames", _I, [_CFG, _I]),
+    ("mkws_frontend_create", _I, [_CFG, _I, ctypes.POINTER(_P)]),
+    ("mkws_frontend_destroy", None, [_P]),
+    ("mkws_frontend_forward_f32", _I, [_P, _P, _I, _I, _P, _P, _P]),
+    ("mkws_frontend_forward_i16", _I, [_P, _P, _I, _I, _P, _P, _P]),
+    ("mkws_frontend_stream_f32", _I, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    ("mkws_embed_weight_count", _SZ, []),
+    ("mkws_embed_weight_manifest", _I, [ctypes.c_char_p, _SZ]),
+    ("mkws_embed_create", _I, [_P, _SZ, _I, ctypes.POINTER(_P)]),
+    ("mkws_embed_destroy", None, [_P]),
+    ("mkws_embed_forward", _I, [_P, _P, _I, _P, _P]),
+    ("mkws_embed_tap", _I, [_P, ctypes.c_char_p, _I, _P, _SZ, _P]),
+    ("mkws_head_create", _I, [_I, _I, _I, _I, ctypes.POINTER(_P)]),
+    ("mkws_head_destroy", None, [_P]),
+    ("mkws_head_param_count", _I, [_P]),
+    ("mkws_head_params", _P, [_P]),
+    ("mkws_head_grads", _P, [_P]),
+    ("mkws_head_set_params", _I, [_P, _P, _I]),
+    ("mkws_head_get_params", _I, [_P, _P, _I, _P]),
+    ("mkws_head_forward", _I, [_P, _P, _I, _P, _P]),
+    ("mkws_head_loss_grad", _I, [_P, _P, _P, _I, _P, _P]),
+    ("mkws_head_adam_step", _I, [_P, _F, _F, _F, _F, _I, _F, _P]),
+]
+
+_lib = None
+
+
+def lib():
+    """Returns the loaded library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C multilingual_kws_amd/csrc`).  multilingual_kws_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)       # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code < 0:
+        raise MkwsError(code, lib().mkws_last_error().decode("utf-8", "replace"))
+    return code
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

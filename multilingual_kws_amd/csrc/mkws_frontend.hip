@@ -1,0 +1,643 @@
+// mkws_frontend.hip -- batched TFLite-Micro "audio_microfrontend" on gfx950, bit-exact.
+//
+// Replaces the per-clip CPU op call of multilingual_kws/embedding/input_data.py:19-35.
+// Arithmetic spec: SURVEY.md Appendix A (validated against upstream TF's known-answer vectors).
+//
+// Mapping (CDNA4, wave = 64 lanes):
+//   * one workgroup per clip, NWAVES waves; wave w takes frames w, w+NWAVES, ...
+//   * per frame, ONE WAVE does window -> block-shift -> 256-point complex radix-4 fixed-point FFT
+//     (4 stages x 64 butterflies = exactly one butterfly per lane per stage) -> real-FFT post-pass
+//     -> |X|^2 -> 40 triangular mel sums (uint64) -> rounded sqrt.  The 1 KB of FFT state lives in
+//     LDS; window coefficients and twiddles are per-lane constants held in registers for the
+//     whole clip.  Samples are read straight from HBM already in base-4 digit-reversed order, so
+//     the first FFT stage runs out of registers.
+//   * the only sequential part -- the noise-estimate recurrence over frames -- is a 49-step scan
+//     by 40 lanes of wave 0 over the LDS-staged [frames x channels] tile; noise subtraction, PCAN
+//     gain and the log LUT are then element-wise over the tile by all lanes.
+//   * HBM traffic = the audio once (+ 160-sample frame overlaps that hit L2) and the [49,40] tile
+//     out: 71 840 B per clip for fp32 input, the algorithmic minimum.
+#include "mkws_common.h"
+#include "mkws_frontend_tables.h"
+
+#include <new>
+#include <vector>
+
+namespace mkws {
+
+// ------------------------------------------------------------------------------------------------
+struct FrontendParams {
+  // device tables
+  const int16_t* window_coef;   // [512], zero padded
+  const uint32_t* tw;           // [256] packed (re | im<<16)
+  const uint32_t* stw;          // [128] packed
+  const int16_t* out_start;     // [C]
+  const int16_t* out_len;       // [C]
+  const int16_t* out_off;       // [C]
+  const int16_t* out_coef;      // [ncoef]
+  const int16_t* pcan_lut;      // [128]
+  const uint16_t* log_lut;      // [132]
+  int ncoef;
+  int window_size, window_step, num_channels;
+  int smoothing_bits, enable_pcan, enable_log, scale_shift, snr_shift, correction_bits;
+  uint32_t even_smoothing, odd_smoothing, min_signal_remaining;
+};
+
+struct cpx { int r, i; };
+
+__device__ __forceinline__ int sext16(int v) { return (int)(short)v; }
+__device__ __forceinline__ int sround(int v) { return sext16((v + 16384) >> 15); }
+__device__ __forceinline__ int fixdiv4(int v) { return sround(v * 8191); }    // kissfft DIVSCALAR(x,4)
+__device__ __forceinline__ int fixdiv2(int v) { return sround(v * 16383); }   // DIVSCALAR(x,2)
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) {
+  cpx m;
+  m.r = sround(a.r * b.r - a.i * b.i);
+  m.i = sround(a.r * b.i + a.i * b.r);
+  return m;
+}
+__device__ __forceinline__ uint32_t pack(int r, int i) { return ((uint32_t)r & 0xFFFFu) | ((uint32_t)i << 16); }
+__device__ __forceinline__ cpx unpack(uint32_t u) { cpx c; c.r = sext16((int)u); c.i = ((int)u) >> 16; return c; }
+
+// LDS traffic between FFT stages is wave-private: DS operations of one wave execute in program
+// order, so only the compiler has to be kept from reordering across the exchange.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// kissfft kf_bfly4 (forward), one butterfly.  Inputs/outputs are sign-extended int16 values; the
+// int16 wrap of the C code is applied when results are packed (adds commute with the wrap).
+__device__ __forceinline__ void bfly4(cpx& F0, cpx& F1, cpx& F2, cpx& F3, cpx t1, cpx t2, cpx t3) {
+  F0.r = fixdiv4(F0.r); F0.i = fixdiv4(F0.i);
+  F1.r = fixdiv4(F1.r); F1.i = fixdiv4(F1.i);
+  F2.r = fixdiv4(F2.r); F2.i = fixdiv4(F2.i);
+  F3.r = fixdiv4(F3.r); F3.i = fixdiv4(F3.i);
+  const cpx s0 = cmul(F1, t1), s1 = cmul(F2, t2), s2 = cmul(F3, t3);
+  const cpx s5 = {F0.r - s1.r, F0.i - s1.i};
+  const cpx a0 = {F0.r + s1.r, F0.i + s1.i};
+  const cpx s3 = {s0.r + s2.r, s0.i + s2.i};
+  const cpx s4 = {s0.r - s2.r, s0.i - s2.i};
+  F2.r = a0.r - s3.r; F2.i = a0.i - s3.i;
+  F0.r = a0.r + s3.r; F0.i = a0.i + s3.i;
+  F1.r = s5.r + s4.i; F1.i = s5.i - s4.r;
+  F3.r = s5.r - s4.i; F3.i = s5.i + s4.r;
+}
+
+// bits.h Sqrt64/Sqrt32: floor sqrt, then +1 when the remainder exceeds the root (round to nearest),
+// except at the saturation points 0xFFFF (32-bit path) / 0xFFFFFFFF.
+__device__ __forceinline__ uint32_t sqrt64_round(uint64_t x) {
+  if (x == 0) return 0;
+  uint64_t r = (uint64_t)__builtin_sqrt((double)x);
+  if (r > 0xFFFFFFFFull) r = 0xFFFFFFFFull;
+  while (r * r > x) --r;
+  while (r < 0xFFFFFFFFull && (r + 1) * (r + 1) <= x) ++r;
+  const uint64_t rem = x - r * r;
+  const uint64_t sat = ((x >> 32) == 0) ? 0xFFFFull : 0xFFFFFFFFull;
+  if (rem > r && r != sat) ++r;
+  return (uint32_t)r;
+}
+
+// pcan_gain_control.c WideDynamicFunction
+__device__ __forceinline__ int wide_dynamic(uint32_t x, const int16_t* lut) {
+  if (x <= 2) return lut[x];
+  const int interval = 32 - __clz((int)x);
+  const int16_t* l = lut + 4 * interval - 6;
+  const int frac = (int)(((interval < 11) ? (x << (11 - interval)) : (x >> (interval - 11))) & 0x3FF);
+  int result = ((int)l[2] * frac) >> 5;
+  result += (int)((uint32_t)(int)l[1] << 5);
+  result *= frac;
+  result = (result + (1 << 14)) >> 15;
+  result += l[0];
+  return sext16(result);
+}
+
+// log_scale.c Log (with Log2FractionPart)
+__device__ __forceinline__ uint32_t log_scale(uint32_t x, int scale_shift, const uint16_t* lut) {
+  const uint32_t integer = 31 - __clz((int)x);
+  int frac = (int)(x - (1u << integer));
+  if (integer < 16) frac <<= (16 - integer); else frac >>= (integer - 16);
+  const uint32_t seg = (uint32_t)frac >> 9;
+  const int c0 = lut[seg], c1 = lut[seg + 1];
+  const int rel = ((c1 - c0) * (frac - (int)(seg << 9))) >> 16;
+  const uint32_t fraction = (uint32_t)(frac + c0 + rel);
+  const uint32_t log2v = (integer << 16) + fraction;
+  const uint32_t loge = (uint32_t)((45426ull * log2v + 32768u) >> 16);
+  return ((loge << scale_shift) + 32768u) >> 16;
+}
+
+// Per-lane constants that do not change across the frames of a clip.
+struct LaneConst {
+  int coef[8];        // window coefficients of this lane's 8 samples
+  cpx twB[3], twC[3], twD[3];
+  cpx st1, st2;       // super twiddles for k = lane+1 and k = lane+65
+  int n0;             // base-4 digit reversal of the lane id (3 digits)
+};
+
+__device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lane, LaneConst& L) {
+  const int d0 = lane & 3, d1 = (lane >> 2) & 3, d2 = (lane >> 4) & 3;
+  L.n0 = d0 * 16 + d1 * 4 + d2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = L.n0 + 64 * j;
+    L.coef[2 * j] = p.window_coef[2 * n];
+    L.coef[2 * j + 1] = p.window_coef[2 * n + 1];
+  }
+  {  // stage B: m = 4, fstride = 16; stage C: m = 16, fstride = 4; stage D: m = 64, fstride = 1
+    const int kB = lane & 3, kC = lane & 15, kD = lane;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      L.twB[q] = unpack(p.tw[kB * 16 * (q + 1)]);
+      L.twC[q] = unpack(p.tw[kC * 4 * (q + 1)]);
+      L.twD[q] = unpack(p.tw[kD * (q + 1)]);
+    }
+  }
+  L.st1 = unpack(p.stw[lane]);
+  L.st2 = unpack(p.stw[lane + 64]);
+}
+
+// window.c + fft.c + kiss_fftr + filterbank.c for ONE frame by ONE wave.
+//   x[8]   : this lane's 8 int16 samples (as ints), samples 2n,2n+1 for n = n0 + 64 j
+//   fftbuf : wave-private LDS uint32[256];  ebuf: wave-private LDS uint32[256]
+//   sig_out: where lane c < C writes channel c of this frame (LDS or global)
+__device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const LaneConst& L, int lane,
+                                             const int (&x)[8], uint32_t* fftbuf, uint32_t* ebuf,
+                                             const int16_t* s_coef, uint32_t* sig_out) {
+  // ---- window (A.1) and block exponent (A.2) ----
+  int w[8];
+  int mx = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    w[q] = sext16((x[q] * L.coef[q]) >> 12);
+    const int a = (w[q] < 0) ? sext16(-w[q]) : w[q];   // int16 negate: -(-32768) stays negative
+    mx = (a > mx) ? a : mx;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int o = __shfl_xor(mx, off, 64);
+    mx = (o > mx) ? o : mx;
+  }
+  const int shift = (mx == 0) ? 15 : (15 - (32 - __clz(mx)));
+  // ---- stage A (m = 1): butterflies on z[n0 + 64 j], twiddle (32767, 0) ----
+  // fft.c FftCompute: (int16)((uint16)w << shift)
+  auto shl = [shift](int v) { return sext16((int)((uint32_t)v << shift)); };
+  cpx F0 = {shl(w[0]), shl(w[1])};
+  cpx F1 = {shl(w[2]), shl(w[3])};
+  cpx F2 = {shl(w[4]), shl(w[5])};
+  cpx F3 = {shl(w[6]), shl(w[7])};
+  const cpx one = {32767, 0};
+  bfly4(F0, F1, F2, F3, one, one, one);
+  fftbuf[4 * lane + 0] = pack(F0.r, F0.i);
+  fftbuf[4 * lane + 1] = pack(F1.r, F1.i);
+  fftbuf[4 * lane + 2] = pack(F2.r, F2.i);
+  fftbuf[4 * lane + 3] = pack(F3.r, F3.i);
+  wave_lds_sync();
+  // ---- stage B (m = 4) ----
+  {
+    const int base = (lane >> 2) * 16 + (lane & 3);
+    F0 = unpack(fftbuf[base]); F1 = unpack(fftbuf[base + 4]); F2 = unpack(fftbuf[base + 8]); F3 = unpack(fftbuf[base + 12]);
+    bfly4(F0, F1, F2, F3, L.twB[0], L.twB[1], L.twB[2]);
+    fftbuf[base] = pack(F0.r, F0.i); fftbuf[base + 4] = pack(F1.r, F1.i);
+    fftbuf[base + 8] = pack(F2.r, F2.i); fftbuf[base + 12] = pack(F3.r, F3.i);
+    wave_lds_sync();
+  }
+  // ---- stage C (m = 16) ----
+  {
+    const int base = (lane >> 4) * 64 + (lane & 15);
+    F0 = unpack(fftbuf[base]); F1 = unpack(fftbuf[base + 16]); F2 = unpack(fftbuf[base + 32]); F3 = unpack(fftbuf[base + 48]);
+    bfly4(F0, F1, F2, F3, L.twC[0], L.twC[1], L.twC[2]);
+    fftbuf[base] = pack(F0.r, F0.i); fftbuf[base + 16] = pack(F1.r, F1.i);
+    fftbuf[base + 32] = pack(F2.r, F2.i); fftbuf[base + 48] = pack(F3.r, F3.i);
+    wave_lds_sync();
+  }
+  // ---- stage D (m = 64) ----
+  {
+    F0 = unpack(fftbuf[lane]); F1 = unpack(fftbuf[lane + 64]); F2 = unpack(fftbuf[lane + 128]); F3 = unpack(fftbuf[lane + 192]);
+    bfly4(F0, F1, F2, F3, L.twD[0], L.twD[1], L.twD[2]);
+    fftbuf[lane] = pack(F0.r, F0.i); fftbuf[lane + 64] = pack(F1.r, F1.i);
+    fftbuf[lane + 128] = pack(F2.r, F2.i); fftbuf[lane + 192] = pack(F3.r, F3.i);
+    wave_lds_sync();
+  }
+  // ---- real-FFT post-pass (kiss_fftr) + energy, bins k and 256-k for k = lane+1, lane+65 ----
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = lane + 1 + 64 * h;
+    const cpx st = h ? L.st2 : L.st1;
+    cpx fpk = unpack(fftbuf[k]);
+    cpx t = unpack(fftbuf[256 - k]);
+    cpx fpnk = {t.r, sext16(-t.i)};
+    fpk.r = fixdiv2(fpk.r); fpk.i = fixdiv2(fpk.i);
+    fpnk.r = fixdiv2(fpnk.r); fpnk.i = fixdiv2(fpnk.i);
+    const cpx f1 = {sext16(fpk.r + fpnk.r), sext16(fpk.i + fpnk.i)};
+    const cpx f2 = {sext16(fpk.r - fpnk.r), sext16(fpk.i - fpnk.i)};
+    const cpx tw = cmul(f2, st);
+    const int ar = sext16((f1.r + tw.r) >> 1), ai = sext16((f1.i + tw.i) >> 1);
+    const int br = sext16((f1.r - tw.r) >> 1), bi = sext16((tw.i - f1.i) >> 1);
+    // FilterbankConvertFftComplexToEnergy: uint32 r*r + i*i (can reach exactly 2^31)
+    if (k != 128) ebuf[k] = (uint32_t)(ar * ar) + (uint32_t)(ai * ai);
+    ebuf[256 - k] = (uint32_t)(br * br) + (uint32_t)(bi * bi);   // k == 128: the second write wins upstream
+  }
+  wave_lds_sync();
+  // ---- mel filterbank (uint64 sums) + rounded sqrt, one channel per lane ----
+  if (lane < p.num_channels) {
+    const int start = p.out_start[lane], len = p.out_len[lane], off = p.out_off[lane];
+    uint64_t acc = 0;
+    for (int j = 0; j < len; ++j) {
+      // upstream multiplies (uint64_t)(int32 energy): sign-extends the one value 2^31
+      const uint64_t e = (uint64_t)(int64_t)(int32_t)ebuf[start + j];
+      acc += (uint64_t)(int64_t)s_coef[off + j] * e;
+    }
+    sig_out[lane] = sqrt64_round(acc) >> shift;
+  }
+}
+
+template <typename T> struct AudioLoad;
+template <> struct AudioLoad<float> {
+  // input_data.py:23: audio * 32768 -> int16 (truncation toward zero; saturating)
+  static __device__ __forceinline__ int cvt(float a) {
+    const float v = fminf(fmaxf(a * 32768.0f, -32768.0f), 32767.0f);
+    return (int)v;
+  }
+  static __device__ __forceinline__ void pair(const float* p, bool aligned, int& a, int& b) {
+    if (aligned) { const float2 v = *reinterpret_cast<const float2*>(p); a = cvt(v.x); b = cvt(v.y); }
+    else { a = cvt(p[0]); b = cvt(p[1]); }
+  }
+  static __device__ __forceinline__ int one(const float* p) { return cvt(*p); }
+};
+template <> struct AudioLoad<int16_t> {
+  static __device__ __forceinline__ void pair(const int16_t* p, bool aligned, int& a, int& b) {
+    if (aligned) { const uint32_t v = *reinterpret_cast<const uint32_t*>(p); a = sext16((int)v); b = ((int)v) >> 16; }
+    else { a = p[0]; b = p[1]; }
+  }
+  static __device__ __forceinline__ int one(const int16_t* p) { return *p; }
+};
+
+// Loads this lane's 8 samples of the frame starting at `frame` (window_size valid samples).
+template <typename T>
+__device__ __forceinline__ void load_frame(const T* frame, int window_size, bool aligned, const LaneConst& L, int (&x)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = 2 * (L.n0 + 64 * j);
+    if (t + 1 < window_size) AudioLoad<T>::pair(frame + t, aligned, x[2 * j], x[2 * j + 1]);
+    else if (t < window_size) { x[2 * j] = AudioLoad<T>::one(frame + t); x[2 * j + 1] = 0; }
+    else { x[2 * j] = 0; x[2 * j + 1] = 0; }
+  }
+}
+
+// noise_reduction.c (given the already-scanned estimate) + pcan_gain_control.c + log_scale.c for one
+// (frame, channel) element.
+__device__ __forceinline__ uint32_t finish_element(const FrontendParams& p, uint32_t s, uint32_t est,
+                                                   const int16_t* s_pcan, const uint16_t* s_log) {
+  const uint32_t su = s << p.smoothing_bits;
+  const uint32_t e = est < su ? est : su;
+  const uint32_t floor_ = (uint32_t)(((uint64_t)s * p.min_signal_remaining) >> 14);
+  const uint32_t sub = (su - e) >> p.smoothing_bits;
+  uint32_t v = sub > floor_ ? sub : floor_;
+  if (p.enable_pcan) {
+    const uint32_t gain = (uint32_t)wide_dynamic(est, s_pcan);
+    const uint32_t snr = (uint32_t)(((uint64_t)v * gain) >> p.snr_shift);
+    v = (snr < 8192u) ? ((snr * snr) >> 20) : ((snr >> 6) - 64u);
+  }
+  if (p.enable_log) {
+    v = (p.correction_bits < 0) ? (v >> (-p.correction_bits)) : (v << p.correction_bits);
+    v = (v > 1) ? log_scale(v, p.scale_shift, s_log) : 0;
+  }
+  return v < 0xFFFFu ? v : 0xFFFFu;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused kernel: one workgroup per clip.
+// dynamic LDS: [NWAVES][512] u32 (fft+energy) | sig [F*C] u32 | est [F*C] u32 | coef i16 | pcan i16[128] | log u16[132]
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void frontend_clip_kernel(FrontendParams p, const T* __restrict__ audio,
+                                                                      int n_samples, int num_frames, int aligned,
+                                                                      float* __restrict__ spec, uint16_t* __restrict__ raw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int C = p.num_channels;
+  const int FC = num_frames * C;
+  uint32_t* s_fft = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* s_sig = s_fft + NWAVES * 512;
+  uint32_t* s_est = s_sig + FC;
+  int16_t* s_coef = reinterpret_cast<int16_t*>(s_est + FC);
+  int16_t* s_pcan = s_coef + ((p.ncoef + 7) & ~7);
+  uint16_t* s_log = reinterpret_cast<uint16_t*>(s_pcan + 128);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t clip = blockIdx.x;
+
+  for (int i = tid; i < p.ncoef; i += NWAVES * 64) s_coef[i] = p.out_coef[i];
+  for (int i = tid; i < 128; i += NWAVES * 64) s_pcan[i] = p.pcan_lut[i];
+  for (int i = tid; i < 132; i += NWAVES * 64) s_log[i] = p.log_lut[i];
+  LaneConst L;
+  init_lane_const(p, lane, L);
+  __syncthreads();
+
+  const T* clip_audio = audio + clip * (size_t)n_samples;
+  uint32_t* fftbuf = s_fft + wave * 512;
+  uint32_t* ebuf = fftbuf + 256;
+  int x[8];
+  int f = wave;
+  if (f < num_frames) load_frame<T>(clip_audio + (size_t)f * p.window_step, p.window_size, aligned != 0, L, x);
+  for (; f < num_frames; f += NWAVES) {
+    int xn[8];
+    const int fn = f + NWAVES;
+    if (fn < num_frames) load_frame<T>(clip_audio + (size_t)fn * p.window_step, p.window_size, aligned != 0, L, xn);
+    frame_to_sig(p, L, lane, x, fftbuf, ebuf, s_coef, s_sig + f * C);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = xn[q];
+  }
+  __syncthreads();
+  // noise-estimate recurrence over frames (noise_reduction.c), 40 lanes of wave 0
+  if (wave == 0 && lane < C) {
+    const uint32_t sm = (lane & 1) ? p.odd_smoothing : p.even_smoothing;
+    const uint32_t om = (1u << 14) - sm;
+    uint32_t est = 0;
+    for (int t = 0; t < num_frames; ++t) {
+      const uint32_t su = s_sig[t * C + lane] << p.smoothing_bits;
+      est = (uint32_t)((((uint64_t)su * sm) + ((uint64_t)est * om)) >> 14);
+      s_est[t * C + lane] = est;
+    }
+  }
+  __syncthreads();
+  const float scale = 10.0f / 256.0f;
+  for (int i = tid; i < FC; i += NWAVES * 64) {
+    const uint32_t v = finish_element(p, s_sig[i], s_est[i], s_pcan, s_log);
+    if (spec) spec[clip * FC + i] = (float)v * scale;
+    if (raw) raw[clip * FC + i] = (uint16_t)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming split (batch_streaming_analysis.py:99-117): frame-level work once per hop, then one
+// scan per window.
+template <typename T>
+__global__ __launch_bounds__(256) void frontend_frames_kernel(FrontendParams p, const T* __restrict__ audio, int total_frames,
+                                                              int aligned, uint32_t* __restrict__ sig /*[total_frames, C]*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* s_fft = reinterpret_cast<uint32_t*>(smem);
+  int16_t* s_coef = reinterpret_cast<int16_t*>(s_fft + 4 * 512);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < p.ncoef; i += 256) s_coef[i] = p.out_coef[i];
+  LaneConst L;
+  init_lane_const(p, lane, L);
+  __syncthreads();
+  uint32_t* fftbuf = s_fft + wave * 512;
+  for (int f = blockIdx.x * 4 + wave; f < total_frames; f += gridDim.x * 4) {
+    int x[8];
+    load_frame<T>(audio + (size_t)f * p.window_step, p.window_size, aligned != 0, L, x);
+    frame_to_sig(p, L, lane, x, fftbuf, fftbuf + 256, s_coef, sig + (size_t)f * p.num_channels);
+  }
+}
+
+// one workgroup (256 threads) per window: scan + finish over frames [w*hop_frames, +frames_per_window)
+__global__ __launch_bounds__(256) void frontend_windows_kernel(FrontendParams p, const uint32_t* __restrict__ sig, int hop_frames,
+                                                               int frames_per_window, float* __restrict__ spec,
+                                                               uint16_t* __restrict__ raw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int C = p.num_channels, FC = frames_per_window * C;
+  uint32_t* s_sig = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* s_est = s_sig + FC;
+  int16_t* s_pcan = reinterpret_cast<int16_t*>(s_est + FC);
+  uint16_t* s_log = reinterpret_cast<uint16_t*>(s_pcan + 128);
+  const int tid = threadIdx.x;
+  const size_t win = blockIdx.x;
+  const uint32_t* src = sig + win * (size_t)hop_frames * C;
+  for (int i = tid; i < FC; i += 256) s_sig[i] = src[i];
+  for (int i = tid; i < 128; i += 256) s_pcan[i] = p.pcan_lut[i];
+  for (int i = tid; i < 132; i += 256) s_log[i] = p.log_lut[i];
+  __syncthreads();
+  if (tid < C) {
+    const uint32_t sm = (tid & 1) ? p.odd_smoothing : p.even_smoothing;
+    const uint32_t om = (1u << 14) - sm;
+    uint32_t est = 0;
+    for (int t = 0; t < frames_per_window; ++t) {
+      const uint32_t su = s_sig[t * C + tid] << p.smoothing_bits;
+      est = (uint32_t)((((uint64_t)su * sm) + ((uint64_t)est * om)) >> 14);
+      s_est[t * C + tid] = est;
+    }
+  }
+  __syncthreads();
+  const float scale = 10.0f / 256.0f;
+  for (int i = tid; i < FC; i += 256) {
+    const uint32_t v = finish_element(p, s_sig[i], s_est[i], s_pcan, s_log);
+    if (spec) spec[win * FC + i] = (float)v * scale;
+    if (raw) raw[win * FC + i] = (uint16_t)v;
+  }
+}
+
+}  // namespace mkws
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+using namespace mkws;
+
+struct mkws_frontend {
+  mkws_frontend_cfg cfg;
+  FrontendTables tab;
+  FrontendParams prm;
+  void* d_blob = nullptr;
+  uint32_t* d_stream_sig = nullptr;   // [max_frames, C] workspace for the streaming split
+  int max_samples = 0;
+  int max_frames = 0;
+  int device = 0;
+};
+
+extern "C" {
+
+int mkws_abi_version(void) { return MKWS_ABI_VERSION; }
+const char* mkws_last_error(void) { return mkws::err_buf(); }
+const char* mkws_build_arch(void) { return "gfx950"; }
+
+void mkws_frontend_default_cfg(mkws_frontend_cfg* c) {
+  if (!c) return;
+  c->sample_rate = 16000; c->window_size_ms = 30; c->window_step_ms = 20; c->num_channels = 40;
+  c->upper_band_limit = 7500.0f; c->lower_band_limit = 125.0f; c->smoothing_bits = 10;
+  c->even_smoothing = 0.025f; c->odd_smoothing = 0.06f; c->min_signal_remaining = 0.05f;
+  c->enable_pcan = 1; c->pcan_strength = 0.95f; c->pcan_offset = 80.0f; c->gain_bits = 21;
+  c->enable_log = 1; c->scale_shift = 6;
+}
+
+int mkws_frontend_host_table(const mkws_frontend_cfg* cfg, int which, void* dst, size_t cap) {
+  if (!cfg) return fail(MKWS_ERR_INVALID_ARG, "cfg is NULL");
+  FrontendTables t;
+  int rc = build_frontend_tables(*cfg, &t);
+  if (rc != MKWS_OK) return rc;
+  const void* src = nullptr;
+  size_t n = 0;
+  int32_t scalars[8] = {t.window_size, t.window_step, t.fft_size, t.start_index, t.end_index, t.num_weights, t.snr_shift, t.correction_bits};
+  switch (which) {
+    case MKWS_FT_WINDOW_COEF: src = t.window_coef.data(); n = t.window_coef.size() * 2; break;
+    case MKWS_FT_TWIDDLES: src = t.twiddles.data(); n = t.twiddles.size() * 2; break;
+    case MKWS_FT_SUPER_TWIDDLES: src = t.super_twiddles.data(); n = t.super_twiddles.size() * 2; break;
+    case MKWS_FT_FB_WEIGHTS: src = t.fb_weights.data(); n = t.fb_weights.size() * 2; break;
+    case MKWS_FT_FB_UNWEIGHTS: src = t.fb_unweights.data(); n = t.fb_unweights.size() * 2; break;
+    case MKWS_FT_FB_FREQ_STARTS: src = t.fb_freq_starts.data(); n = t.fb_freq_starts.size() * 2; break;
+    case MKWS_FT_FB_WEIGHT_STARTS: src = t.fb_weight_starts.data(); n = t.fb_weight_starts.size() * 2; break;
+    case MKWS_FT_FB_WIDTHS: src = t.fb_widths.data(); n = t.fb_widths.size() * 2; break;
+    case MKWS_FT_PCAN_LUT: src = t.pcan_lut.data(); n = t.pcan_lut.size() * 2; break;
+    case MKWS_FT_LOG_LUT: src = t.log_lut.data(); n = t.log_lut.size() * 2; break;
+    case MKWS_FT_SCALARS: src = scalars; n = sizeof(scalars); break;
+    default: return fail(MKWS_ERR_INVALID_ARG, "unknown table id %d", which);
+  }
+  if (dst && cap > 0) memcpy(dst, src, n < cap ? n : cap);
+  return (int)n;
+}
+
+int mkws_frontend_num_frames(const mkws_frontend_cfg* cfg, int n_samples) {
+  if (!cfg || cfg->sample_rate <= 0) return fail(MKWS_ERR_INVALID_ARG, "cfg is NULL or invalid");
+  const int size = cfg->window_size_ms * cfg->sample_rate / 1000;
+  const int step = cfg->window_step_ms * cfg->sample_rate / 1000;
+  if (size <= 0 || step <= 0) return fail(MKWS_ERR_INVALID_ARG, "window/step of zero samples");
+  if (n_samples < size) return 0;
+  return (n_samples - size) / step + 1;
+}
+
+int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_frontend** out) {
+  if (!cfg || !out) return fail(MKWS_ERR_INVALID_ARG, "cfg/out is NULL");
+  *out = nullptr;
+  if (max_samples <= 0) return fail(MKWS_ERR_INVALID_ARG, "max_samples must be positive");
+  mkws_frontend* fe = new (std::nothrow) mkws_frontend();
+  if (!fe) return fail(MKWS_ERR_ALLOC, "out of host memory");
+  fe->cfg = *cfg;
+  int rc = build_frontend_tables(*cfg, &fe->tab);
+  if (rc != MKWS_OK) { delete fe; return rc; }
+  const FrontendTables& t = fe->tab;
+  if (t.fft_size != 512) {
+    delete fe;
+    return fail(MKWS_ERR_UNSUPPORTED, "HIP frontend implements the 512-point FFT (window of 257..512 samples); got window %d -> fft %d",
+                t.window_size, t.fft_size);
+  }
+  if (cfg->num_channels > 64) { delete fe; return fail(MKWS_ERR_UNSUPPORTED, "num_channels %d > 64", cfg->num_channels); }
+  rc = require_device();
+  if (rc != MKWS_OK) { delete fe; return rc; }
+  (void)hipGetDevice(&fe->device);
+  // pack one device blob
+  const int C = cfg->num_channels;
+  const size_t ncoef = t.out_coef.size();
+  auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+  size_t o_win = 0, o_tw = al(o_win + 512 * 2), o_stw = al(o_tw + 256 * 4), o_os = al(o_stw + 128 * 4), o_ol = al(o_os + C * 2),
+         o_oo = al(o_ol + C * 2), o_oc = al(o_oo + C * 2), o_pc = al(o_oc + (ncoef + 8) * 2), o_lg = al(o_pc + 128 * 2), total = al(o_lg + 132 * 2);
+  std::vector<unsigned char> h(total, 0);
+  memcpy(h.data() + o_win, t.window_coef.data(), t.window_coef.size() * 2);
+  uint32_t* tw = reinterpret_cast<uint32_t*>(h.data() + o_tw);
+  for (int i = 0; i < 256; ++i) tw[i] = ((uint32_t)(uint16_t)t.twiddles[2 * i]) | ((uint32_t)(uint16_t)t.twiddles[2 * i + 1] << 16);
+  uint32_t* stw = reinterpret_cast<uint32_t*>(h.data() + o_stw);
+  for (int i = 0; i < 128; ++i) stw[i] = ((uint32_t)(uint16_t)t.super_twiddles[2 * i]) | ((uint32_t)(uint16_t)t.super_twiddles[2 * i + 1] << 16);
+  memcpy(h.data() + o_os, t.out_start.data(), C * 2);
+  memcpy(h.data() + o_ol, t.out_len.data(), C * 2);
+  memcpy(h.data() + o_oo, t.out_off.data(), C * 2);
+  memcpy(h.data() + o_oc, t.out_coef.data(), ncoef * 2);
+  memcpy(h.data() + o_pc, t.pcan_lut.data(), t.pcan_lut.size() * 2);
+  memcpy(h.data() + o_lg, t.log_lut.data(), t.log_lut.size() * 2);
+  if (hipMalloc(&fe->d_blob, total) != hipSuccess) { delete fe; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) failed", total); }
+  if (hipMemcpy(fe->d_blob, h.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(fe->d_blob); delete fe; return fail(MKWS_ERR_HIP, "table upload failed");
+  }
+  unsigned char* d = static_cast<unsigned char*>(fe->d_blob);
+  FrontendParams& p = fe->prm;
+  p.window_coef = reinterpret_cast<int16_t*>(d + o_win);
+  p.tw = reinterpret_cast<uint32_t*>(d + o_tw);
+  p.stw = reinterpret_cast<uint32_t*>(d + o_stw);
+  p.out_start = reinterpret_cast<int16_t*>(d + o_os);
+  p.out_len = reinterpret_cast<int16_t*>(d + o_ol);
+  p.out_off = reinterpret_cast<int16_t*>(d + o_oo);
+  p.out_coef = reinterpret_cast<int16_t*>(d + o_oc);
+  p.pcan_lut = reinterpret_cast<int16_t*>(d + o_pc);
+  p.log_lut = reinterpret_cast<uint16_t*>(d + o_lg);
+  p.ncoef = (int)ncoef;
+  p.window_size = t.window_size; p.window_step = t.window_step; p.num_channels = C;
+  p.smoothing_bits = cfg->smoothing_bits; p.enable_pcan = cfg->enable_pcan ? 1 : 0; p.enable_log = cfg->enable_log ? 1 : 0;
+  p.scale_shift = cfg->scale_shift; p.snr_shift = t.snr_shift; p.correction_bits = t.correction_bits;
+  p.even_smoothing = t.even_smoothing; p.odd_smoothing = t.odd_smoothing; p.min_signal_remaining = t.min_signal_remaining;
+  fe->max_samples = max_samples;
+  fe->max_frames = mkws_frontend_num_frames(cfg, max_samples);
+  *out = fe;
+  return MKWS_OK;
+}
+
+void mkws_frontend_destroy(mkws_frontend* fe) {
+  if (!fe) return;
+  if (fe->d_blob) (void)hipFree(fe->d_blob);
+  if (fe->d_stream_sig) (void)hipFree(fe->d_stream_sig);
+  delete fe;
+}
+
+}  // extern "C"
+
+namespace {
+
+constexpr int kClipWaves = 4;
+
+size_t clip_lds_bytes(const mkws_frontend* fe, int frames) {
+  const size_t FC = (size_t)frames * fe->prm.num_channels;
+  return kClipWaves * 512 * 4 + 2 * FC * 4 + ((fe->prm.ncoef + 7) & ~7) * 2 + 128 * 2 + 132 * 2 + 16;
+}
+
+template <typename T>
+int frontend_forward_impl(mkws_frontend* fe, const T* d_audio, int B, int n_samples, float* d_spec, uint16_t* d_raw, void* stream) {
+  if (!fe) return fail(MKWS_ERR_INVALID_ARG, "frontend handle is NULL");
+  if (B < 0 || n_samples < 0) return fail(MKWS_ERR_INVALID_ARG, "negative batch or sample count");
+  if (n_samples > fe->max_samples) return fail(MKWS_ERR_INVALID_ARG, "n_samples %d exceeds max_samples %d given at create", n_samples, fe->max_samples);
+  if (!d_spec && !d_raw) return fail(MKWS_ERR_INVALID_ARG, "both outputs are NULL");
+  const int frames = mkws_frontend_num_frames(&fe->cfg, n_samples);
+  if (B == 0 || frames == 0) return MKWS_OK;   // empty input -> empty output, like the op
+  if (!d_audio) return fail(MKWS_ERR_INVALID_ARG, "d_audio is NULL");
+  const size_t lds = clip_lds_bytes(fe, frames);
+  if (lds > 64 * 1024)
+    return fail(MKWS_ERR_UNSUPPORTED, "%d frames per clip need %zu B of LDS; use mkws_frontend_stream_f32 for long audio", frames, lds);
+  const int aligned = ((n_samples % 2) == 0 && (fe->prm.window_step % 2) == 0 && (reinterpret_cast<uintptr_t>(d_audio) % (2 * sizeof(T))) == 0) ? 1 : 0;
+  hipLaunchKernelGGL((frontend_clip_kernel<T, kClipWaves>), dim3(B), dim3(kClipWaves * 64), lds, static_cast<hipStream_t>(stream),
+                     fe->prm, d_audio, n_samples, frames, aligned, d_spec, d_raw);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mkws_frontend_forward_f32(mkws_frontend* fe, const float* d_audio, int B, int n_samples, float* d_spec, uint16_t* d_raw, void* stream) {
+  return frontend_forward_impl<float>(fe, d_audio, B, n_samples, d_spec, d_raw, stream);
+}
+
+int mkws_frontend_forward_i16(mkws_frontend* fe, const int16_t* d_audio, int B, int n_samples, float* d_spec, uint16_t* d_raw, void* stream) {
+  return frontend_forward_impl<int16_t>(fe, d_audio, B, n_samples, d_spec, d_raw, stream);
+}
+
+int mkws_frontend_stream_f32(mkws_frontend* fe, const float* d_audio, int n_samples, int window_samples, int hop_samples,
+                             float* d_spec, uint16_t* d_raw, int max_windows, void* stream) {
+  if (!fe) return fail(MKWS_ERR_INVALID_ARG, "frontend handle is NULL");
+  if (n_samples < 0 || window_samples <= 0 || hop_samples <= 0) return fail(MKWS_ERR_INVALID_ARG, "bad sample counts");
+  if (n_samples > fe->max_samples) return fail(MKWS_ERR_INVALID_ARG, "n_samples %d exceeds max_samples %d", n_samples, fe->max_samples);
+  const FrontendParams& p = fe->prm;
+  if (hop_samples % p.window_step != 0)
+    return fail(MKWS_ERR_UNSUPPORTED, "hop of %d samples is not a multiple of the %d-sample frame step (frame sharing needs that)", hop_samples, p.window_step);
+  const int fpw = mkws_frontend_num_frames(&fe->cfg, window_samples);
+  if (fpw <= 0 || n_samples < window_samples) return 0;
+  const int num_windows = 1 + (n_samples - window_samples) / hop_samples;
+  if (num_windows > max_windows) return fail(MKWS_ERR_INVALID_ARG, "%d windows exceed max_windows %d", num_windows, max_windows);
+  if (!d_audio || (!d_spec && !d_raw)) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
+  const int hop_frames = hop_samples / p.window_step;
+  const int total_frames = (num_windows - 1) * hop_frames + fpw;
+  const size_t lds2 = 2 * (size_t)fpw * p.num_channels * 4 + 128 * 2 + 132 * 2 + 16;
+  if (lds2 > 64 * 1024) return fail(MKWS_ERR_UNSUPPORTED, "window of %d frames needs %zu B LDS", fpw, lds2);
+  if (!fe->d_stream_sig) {
+    const size_t n = (size_t)(fe->max_frames > 0 ? fe->max_frames : 1) * p.num_channels * 4;
+    if (hipMalloc(reinterpret_cast<void**>(&fe->d_stream_sig), n) != hipSuccess) return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) failed", n);
+  }
+  const int aligned = ((p.window_step % 2) == 0 && (reinterpret_cast<uintptr_t>(d_audio) % 8) == 0) ? 1 : 0;
+  const size_t lds1 = 4 * 512 * 4 + ((p.ncoef + 7) & ~7) * 2 + 16;
+  int grid1 = (total_frames + 3) / 4;
+  if (grid1 > 4096) grid1 = 4096;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL((frontend_frames_kernel<float>), dim3(grid1), dim3(256), lds1, s, p, d_audio, total_frames, aligned, fe->d_stream_sig);
+  MKWS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(frontend_windows_kernel, dim3(num_windows), dim3(256), lds2, s, p, fe->d_stream_sig, hop_frames, fpw, d_spec, d_raw);
+  MKWS_HIP(hipGetLastError());
+  return num_windows;
+}
+
+}  // extern "C"
