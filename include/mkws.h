@@ -142,9 +142,11 @@ int mkws_embed_create(const float* h_weights, size_t n_floats, int max_batch, mk
 void mkws_embed_destroy(mkws_embed* em);
 /* d_spec float32 [B,49,40,1] (NHWC, i.e. the frontend's output) -> d_emb float32 [B,1024]. */
 int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, void* stream);
-/* Debug/parity tap: copies the activation of a named stage (e.g. "stem", "block2a", "top", "gap",
- * "dense_0") of the LAST forward into d_dst (float32, NHWC); returns element count or negative. */
-int mkws_embed_tap(mkws_embed* em, const char* stage, int B, float* d_dst, size_t cap_floats, void* stream);
+/* Debug/parity tap: runs the forward pass up to and including `stage` ("stem", "block2a_expand",
+ * "block2a_dw", "block2a_gate", "block2a", ..., "top", "gap", "dense", "dense_1", "dense_2") and copies
+ * that stage's output (float32, NHWC) into d_dst; returns its element count or a negative status. */
+int mkws_embed_forward_tap(mkws_embed* em, const float* d_spec, int B, const char* stage, float* d_dst,
+                           size_t cap_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Few-shot head.  Replaces Dense(18,tanh) -> Dense(3,softmax) + SparseCategoricalCrossentropy +

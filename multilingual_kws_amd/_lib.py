@@ -48,7 +48,7 @@ SYMBOLS = [
     ("mkws_embed_create", _I, [_P, _SZ, _I, ctypes.POINTER(_P)]),
     ("mkws_embed_destroy", None, [_P]),
     ("mkws_embed_forward", _I, [_P, _P, _I, _P, _P]),
-    ("mkws_embed_tap", _I, [_P, ctypes.c_char_p, _I, _P, _SZ, _P]),
+    ("mkws_embed_forward_tap", _I, [_P, _P, _I, ctypes.c_char_p, _P, _SZ, _P]),
     ("mkws_head_create", _I, [_I, _I, _I, _I, ctypes.POINTER(_P)]),
     ("mkws_head_destroy", None, [_P]),
     ("mkws_head_param_count", _I, [_P]),

@@ -1,0 +1,312 @@
+// mkws_head.hip -- the few-shot head on the frozen embedding: Dense(18,tanh) -> Dense(3,softmax),
+// sparse categorical cross-entropy, backward, Keras Adam.
+//
+// Replaces the trainable part of multilingual_kws/embedding/transfer_learning.py:47-59 and the
+// per-step work of xfer.fit (:86-93).  Semantics: SURVEY.md Appendix C.1-C.2.
+//   parameter vector: W1[in,hid] | b1[hid] | W2[hid,cls] | b2[cls]   (Keras [in,out] kernels)
+// The gradient lives in one flat device buffer so the data-parallel host code can all-reduce it with
+// a single RCCL call (74 028 B for 1024/18/3).  All reductions are fixed-order (no atomics), so a
+// step is bit-reproducible.
+#include "mkws_common.h"
+
+#include <cmath>
+#include <new>
+
+namespace mkws {
+
+constexpr int kMaxHidden = 32;
+constexpr int kMaxClasses = 8;
+constexpr int kGradSplits = 8;
+
+struct HeadDims { int in, hid, cls; };
+
+// one wave per row: h = tanh(x W1 + b1); z = h W2 + b2; p = softmax(z).
+// TRAIN: also per-row loss, correctness, dz = (p - onehot)/B and dpre = (dz W2^T) * (1 - h^2).
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float* __restrict__ params, const float* __restrict__ x,
+                                                        const int32_t* __restrict__ labels, int B, float* __restrict__ probs,
+                                                        float* __restrict__ hbuf /*[B,hid]*/, float* __restrict__ dz /*[B,cls]*/,
+                                                        float* __restrict__ dpre /*[B,hid]*/, float* __restrict__ rowstat /*[B,2]*/) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* W1 = params;
+  const float* b1 = W1 + (size_t)d.in * d.hid;
+  const float* W2 = b1 + d.hid;
+  const float* b2 = W2 + (size_t)d.hid * d.cls;
+  float acc[kMaxHidden];
+#pragma unroll
+  for (int j = 0; j < kMaxHidden; ++j) acc[j] = 0.0f;
+  const float* xr = x + (size_t)row * d.in;
+  for (int k = lane; k < d.in; k += 64) {
+    const float xv = xr[k];
+    const float* w = W1 + (size_t)k * d.hid;
+#pragma unroll
+    for (int j = 0; j < kMaxHidden; ++j)
+      if (j < d.hid) acc[j] += xv * w[j];
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxHidden; ++j) {
+    if (j < d.hid) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+    }
+  }
+  // every lane now holds the full sums; lane 0 finishes the row
+  if (lane == 0) {
+    float h[kMaxHidden];
+#pragma unroll
+    for (int j = 0; j < kMaxHidden; ++j) h[j] = (j < d.hid) ? tanhf(acc[j] + b1[j]) : 0.0f;
+    float z[kMaxClasses];
+    float zmax = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) {
+      if (c < d.cls) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kMaxHidden; ++j)
+          if (j < d.hid) s += h[j] * W2[j * d.cls + c];
+        z[c] = s + b2[c];
+        zmax = fmaxf(zmax, z[c]);
+      } else {
+        z[c] = 0.0f;
+      }
+    }
+    float e[kMaxClasses], esum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) {
+      e[c] = (c < d.cls) ? expf(z[c] - zmax) : 0.0f;
+      esum += e[c];
+    }
+    const float inv = 1.0f / esum;
+    if (probs) {
+#pragma unroll
+      for (int c = 0; c < kMaxClasses; ++c)
+        if (c < d.cls) probs[(size_t)row * d.cls + c] = e[c] * inv;
+    }
+    if (TRAIN) {
+      const int y = labels[row];
+      int best = 0;
+      float zy = 0.0f;
+#pragma unroll
+      for (int c = 0; c < kMaxClasses; ++c) {
+        if (c < d.cls) {
+          if (z[c] > z[best]) best = c;
+          if (c == y) zy = z[c];
+        }
+      }
+      // -log softmax(z)[y], computed from the logits (what Keras does for a softmax-activated output)
+      rowstat[2 * row] = (logf(esum) + zmax) - zy;
+      rowstat[2 * row + 1] = (best == y) ? 1.0f : 0.0f;
+      const float invB = 1.0f / (float)B;
+      float dzl[kMaxClasses];
+#pragma unroll
+      for (int c = 0; c < kMaxClasses; ++c) {
+        dzl[c] = (c < d.cls) ? (e[c] * inv - (c == y ? 1.0f : 0.0f)) * invB : 0.0f;
+        if (c < d.cls) dz[(size_t)row * d.cls + c] = dzl[c];
+      }
+#pragma unroll
+      for (int j = 0; j < kMaxHidden; ++j) {
+        if (j < d.hid) {
+          float s = 0.0f;
+#pragma unroll
+          for (int c = 0; c < kMaxClasses; ++c)
+            if (c < d.cls) s += dzl[c] * W2[j * d.cls + c];
+          hbuf[(size_t)row * d.hid + j] = h[j];
+          dpre[(size_t)row * d.hid + j] = s * (1.0f - h[j] * h[j]);
+        }
+      }
+    }
+  }
+}
+
+// partial dW1: block (kx, split) handles 256 input features x rows [split*rows_per, +rows_per)
+__global__ __launch_bounds__(256) void head_dw1_partial_kernel(HeadDims d, const float* __restrict__ x, const float* __restrict__ dpre,
+                                                               int B, int rows_per, float* __restrict__ partial /*[splits][in*hid]*/) {
+  __shared__ float s_dp[64 * kMaxHidden];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = (r0 + rows_per < B) ? r0 + rows_per : B;
+  float acc[kMaxHidden];
+#pragma unroll
+  for (int j = 0; j < kMaxHidden; ++j) acc[j] = 0.0f;
+  for (int rb = r0; rb < r1; rb += 64) {
+    const int nr = (r1 - rb < 64) ? r1 - rb : 64;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * d.hid; i += 256) s_dp[i] = dpre[(size_t)rb * d.hid + i];
+    __syncthreads();
+    if (k < d.in) {
+      for (int r = 0; r < nr; ++r) {
+        const float xv = x[(size_t)(rb + r) * d.in + k];
+#pragma unroll
+        for (int j = 0; j < kMaxHidden; ++j)
+          if (j < d.hid) acc[j] += xv * s_dp[r * d.hid + j];
+      }
+    }
+  }
+  if (k < d.in) {
+    float* dst = partial + (size_t)blockIdx.y * d.in * d.hid + (size_t)k * d.hid;
+#pragma unroll
+    for (int j = 0; j < kMaxHidden; ++j)
+      if (j < d.hid) dst[j] = acc[j];
+  }
+}
+
+// final reduce: grads = [sum of partials | db1 | dW2 | db2], stats = {sum loss, sum correct}
+__global__ __launch_bounds__(256) void head_grad_finish_kernel(HeadDims d, const float* __restrict__ partial, int splits,
+                                                               const float* __restrict__ hbuf, const float* __restrict__ dz,
+                                                               const float* __restrict__ dpre, const float* __restrict__ rowstat, int B,
+                                                               float* __restrict__ grads, float* __restrict__ stats) {
+  const int nW1 = d.in * d.hid;
+  const int nsmall = d.hid + d.hid * d.cls + d.cls;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nW1) {
+    float s = 0.0f;
+    for (int p = 0; p < splits; ++p) s += partial[(size_t)p * nW1 + i];
+    grads[i] = s;
+  } else if (i < nW1 + nsmall) {
+    const int t = i - nW1;
+    float s = 0.0f;
+    if (t < d.hid) {                                  // db1[j] = sum_b dpre[b][j]
+      for (int b = 0; b < B; ++b) s += dpre[(size_t)b * d.hid + t];
+    } else if (t < d.hid + d.hid * d.cls) {            // dW2[j][c] = sum_b h[b][j] dz[b][c]
+      const int j = (t - d.hid) / d.cls, c = (t - d.hid) % d.cls;
+      for (int b = 0; b < B; ++b) s += hbuf[(size_t)b * d.hid + j] * dz[(size_t)b * d.cls + c];
+    } else {                                          // db2[c]
+      const int c = t - d.hid - d.hid * d.cls;
+      for (int b = 0; b < B; ++b) s += dz[(size_t)b * d.cls + c];
+    }
+    grads[i] = s;
+  } else if (i < nW1 + nsmall + 2 && stats) {
+    const int t = i - nW1 - nsmall;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += rowstat[2 * b + t];
+    stats[t] = s;
+  }
+}
+
+// Keras Adam (optimizer_v2/adam.py): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)
+__global__ __launch_bounds__(256) void head_adam_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ m,
+                                                        float* __restrict__ v, int n, float lr_t, float beta1, float beta2, float eps,
+                                                        float grad_scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float g = grads[i] * grad_scale;
+  const float mi = m[i] + (g - m[i]) * (1.0f - beta1);
+  const float vi = v[i] + (g * g - v[i]) * (1.0f - beta2);
+  m[i] = mi;
+  v[i] = vi;
+  params[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
+}
+
+}  // namespace mkws
+
+using namespace mkws;
+
+struct mkws_head {
+  HeadDims d;
+  int max_batch = 0, nparams = 0;
+  float* d_state = nullptr;   // params | grads | m | v
+  float* d_work = nullptr;    // hbuf | dz | dpre | rowstat | partial
+  float *params, *grads, *m, *v;
+  float *hbuf, *dz, *dpre, *rowstat, *partial;
+};
+
+extern "C" {
+
+int mkws_head_create(int in_dim, int hidden, int classes, int max_batch, mkws_head** out) {
+  if (!out) return fail(MKWS_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (in_dim <= 0 || hidden <= 0 || classes <= 1 || max_batch <= 0) return fail(MKWS_ERR_INVALID_ARG, "head dims must be positive (classes >= 2)");
+  if (hidden > kMaxHidden || classes > kMaxClasses)
+    return fail(MKWS_ERR_UNSUPPORTED, "head kernels support hidden <= %d and classes <= %d", kMaxHidden, kMaxClasses);
+  int rc = require_device();
+  if (rc != MKWS_OK) return rc;
+  mkws_head* hd = new (std::nothrow) mkws_head();
+  if (!hd) return fail(MKWS_ERR_ALLOC, "out of host memory");
+  hd->d = {in_dim, hidden, classes};
+  hd->max_batch = max_batch;
+  hd->nparams = in_dim * hidden + hidden + hidden * classes + classes;
+  const size_t P = ((size_t)hd->nparams + 63) & ~size_t(63);
+  if (hipMalloc(reinterpret_cast<void**>(&hd->d_state), 4 * P * sizeof(float)) != hipSuccess) { delete hd; return fail(MKWS_ERR_ALLOC, "hipMalloc failed"); }
+  (void)hipMemset(hd->d_state, 0, 4 * P * sizeof(float));
+  hd->params = hd->d_state; hd->grads = hd->d_state + P; hd->m = hd->d_state + 2 * P; hd->v = hd->d_state + 3 * P;
+  const size_t mb = (size_t)max_batch;
+  const size_t nwork = mb * hidden * 2 + mb * classes + mb * 2 + (size_t)kGradSplits * in_dim * hidden + 64;
+  if (hipMalloc(reinterpret_cast<void**>(&hd->d_work), nwork * sizeof(float)) != hipSuccess) {
+    (void)hipFree(hd->d_state); delete hd; return fail(MKWS_ERR_ALLOC, "hipMalloc failed");
+  }
+  float* w = hd->d_work;
+  hd->hbuf = w; w += mb * hidden; hd->dpre = w; w += mb * hidden; hd->dz = w; w += mb * classes; hd->rowstat = w; w += mb * 2; hd->partial = w;
+  *out = hd;
+  return MKWS_OK;
+}
+
+void mkws_head_destroy(mkws_head* hd) {
+  if (!hd) return;
+  if (hd->d_state) (void)hipFree(hd->d_state);
+  if (hd->d_work) (void)hipFree(hd->d_work);
+  delete hd;
+}
+
+int mkws_head_param_count(const mkws_head* hd) { return hd ? hd->nparams : fail(MKWS_ERR_INVALID_ARG, "head handle is NULL"); }
+float* mkws_head_params(mkws_head* hd) { return hd ? hd->params : nullptr; }
+float* mkws_head_grads(mkws_head* hd) { return hd ? hd->grads : nullptr; }
+
+int mkws_head_set_params(mkws_head* hd, const float* h_params, int n) {
+  if (!hd || !h_params) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
+  if (n != hd->nparams) return fail(MKWS_ERR_INVALID_ARG, "expected %d parameters, got %d", hd->nparams, n);
+  MKWS_HIP(hipMemcpy(hd->params, h_params, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  const size_t P = ((size_t)hd->nparams + 63) & ~size_t(63);
+  MKWS_HIP(hipMemset(hd->grads, 0, 3 * P * sizeof(float)));
+  return MKWS_OK;
+}
+
+int mkws_head_get_params(mkws_head* hd, float* h_params, int n, void* stream) {
+  if (!hd || !h_params) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
+  if (n != hd->nparams) return fail(MKWS_ERR_INVALID_ARG, "expected %d parameters, got %d", hd->nparams, n);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MKWS_HIP(hipMemcpyAsync(h_params, hd->params, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+  MKWS_HIP(hipStreamSynchronize(s));
+  return MKWS_OK;
+}
+
+int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, void* stream) {
+  if (!hd) return fail(MKWS_ERR_INVALID_ARG, "head handle is NULL");
+  if (B < 0) return fail(MKWS_ERR_INVALID_ARG, "negative batch");
+  if (B == 0) return MKWS_OK;
+  if (!d_emb || !d_probs) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
+  hipLaunchKernelGGL((head_rows_kernel<false>), dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb,
+                     nullptr, B, d_probs, nullptr, nullptr, nullptr, nullptr);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_head_loss_grad(mkws_head* hd, const float* d_emb, const int32_t* d_labels, int B, float* d_stats, void* stream) {
+  if (!hd) return fail(MKWS_ERR_INVALID_ARG, "head handle is NULL");
+  if (B <= 0 || B > hd->max_batch) return fail(MKWS_ERR_INVALID_ARG, "batch %d outside [1, max_batch=%d]", B, hd->max_batch);
+  if (!d_emb || !d_labels) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL((head_rows_kernel<true>), dim3((B + 3) / 4), dim3(256), 0, s, hd->d, hd->params, d_emb, d_labels, B, nullptr,
+                     hd->hbuf, hd->dz, hd->dpre, hd->rowstat);
+  const int rows_per = (B + kGradSplits - 1) / kGradSplits;
+  const int splits = (B + rows_per - 1) / rows_per;
+  hipLaunchKernelGGL(head_dw1_partial_kernel, dim3((hd->d.in + 255) / 256, splits), dim3(256), 0, s, hd->d, d_emb, hd->dpre, B, rows_per, hd->partial);
+  const int total = hd->nparams + 2;
+  hipLaunchKernelGGL(head_grad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, hd->d, hd->partial, splits, hd->hbuf, hd->dz, hd->dpre,
+                     hd->rowstat, B, hd->grads, d_stats);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_head_adam_step(mkws_head* hd, float lr, float beta1, float beta2, float eps, int step_t, float grad_scale, void* stream) {
+  if (!hd) return fail(MKWS_ERR_INVALID_ARG, "head handle is NULL");
+  if (step_t < 1) return fail(MKWS_ERR_INVALID_ARG, "Adam step index starts at 1");
+  const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, step_t)) / (1.0 - std::pow((double)beta1, step_t));
+  hipLaunchKernelGGL(head_adam_kernel, dim3((hd->nparams + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), hd->params, hd->grads,
+                     hd->m, hd->v, hd->nparams, (float)lr_t, beta1, beta2, eps, grad_scale);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""Device embedding network handle: host wrapper over mkws_embed_* (include/mkws.h).
+
+Stands in for the Keras sub-model `Model(base.inputs, base.get_layer("dense_2").output)` that
+multilingual_kws/embedding/transfer_learning.py:36-43 builds: `.predict(x[B,49,40,1]) -> [B,1024]`.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+EMBEDDING_DIM = 1024
+SPEC_SHAPE = (49, 40)
+
+
+class EmbeddingModel:
+    def __init__(self, weight_blob, max_batch=1024, device=None):
+        import torch
+        self.L = _lib.lib()
+        blob = np.ascontiguousarray(weight_blob, dtype=np.float32)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mkws_embed_create(blob.ctypes.data, blob.shape[0], int(max_batch), ctypes.byref(h)))
+        self.h = h
+        self.max_batch = int(max_batch)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mkws_embed_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _prep(self, spec):
+        import torch
+        if not torch.is_tensor(spec):
+            spec = torch.as_tensor(np.asarray(spec, dtype=np.float32))
+        spec = spec.to(self.device, dtype=torch.float32)
+        if spec.dim() == 4 and spec.shape[-1] == 1:
+            spec = spec[..., 0]
+        if spec.dim() != 3 or tuple(spec.shape[1:]) != SPEC_SHAPE:
+            raise ValueError(f"expected [B,49,40] or [B,49,40,1], got {tuple(spec.shape)}")
+        return spec.contiguous()
+
+    def forward(self, spec, out=None):
+        """spec CUDA tensor [B,49,40(,1)] -> CUDA tensor [B,1024].  B may exceed max_batch (chunked)."""
+        import torch
+        spec = self._prep(spec)
+        B = spec.shape[0]
+        emb = out if out is not None else torch.empty((B, EMBEDDING_DIM), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for s in range(0, B, self.max_batch):
+                n = min(self.max_batch, B - s)
+                _lib.check(self.L.mkws_embed_forward(self.h, ctypes.c_void_p(spec[s:s + n].data_ptr()), n,
+                                                     ctypes.c_void_p(emb[s:s + n].data_ptr()), _lib.current_stream_ptr()))
+        return emb
+
+    def predict(self, x):
+        """Keras-style: numpy in ([B,49,40,1]), numpy out ([B,1024])."""
+        return self.forward(x).cpu().numpy()
+
+    def tap(self, spec, stage):
+        """Output of a named intermediate stage (flat float32 CUDA tensor) for parity debugging."""
+        import torch
+        spec = self._prep(spec)
+        B = spec.shape[0]
+        if B > self.max_batch:
+            raise ValueError("tap: batch exceeds max_batch")
+        dst = torch.empty(B * 48000, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            n = _lib.check(self.L.mkws_embed_forward_tap(self.h, ctypes.c_void_p(spec.data_ptr()), B, stage.encode(),
+                                                         ctypes.c_void_p(dst.data_ptr()), dst.numel(), _lib.current_stream_ptr()))
+        return dst[:n]
