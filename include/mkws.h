@@ -142,6 +142,17 @@ int mkws_embed_create(const float* h_weights, size_t n_floats, int max_batch, mk
 void mkws_embed_destroy(mkws_embed* em);
 /* d_spec float32 [B,49,40,1] (NHWC, i.e. the frontend's output) -> d_emb float32 [B,1024]. */
 int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, void* stream);
+/* Execution options (A/B switches for measurement; results are equal up to fp32 rounding):
+ *   "fuse_front" (default 1): expand 1x1 conv + depthwise conv in one kernel (expanded tensor stays in LDS);
+ *                 0 = separate GEMM and depthwise kernels. */
+int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
+
+/* Measurement aid (NOT capturable: it records a hipEvent pair around every kernel launch and
+ * synchronises the stream after each of the `reps` passes).  Writes one line per launch,
+ * "<stage>\t<kernel name as rocprofv3 shows it>\t<average ms>\n", into dst; returns the bytes needed. */
+int mkws_embed_profile(mkws_embed* em, const float* d_spec, int B, int reps, float* d_emb, char* dst,
+                       size_t cap_bytes, void* stream);
+
 /* Debug/parity tap: runs the forward pass up to and including `stage` ("stem", "block2a_expand",
  * "block2a_dw", "block2a_gate", "block2a", ..., "top", "gap", "dense", "dense_1", "dense_2") and copies
  * that stage's output (float32, NHWC) into d_dst; returns its element count or a negative status. */
@@ -177,6 +188,34 @@ int mkws_head_loss_grad(mkws_head* hd, const float* d_emb, const int32_t* d_labe
  * after a sum all-reduce): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps). */
 int mkws_head_adam_step(mkws_head* hd, float lr, float beta1, float beta2, float eps, int step_t,
                         float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-batch assembly.  Replaces the per-clip tf.data map of AudioDataset.augment /
+ * random_timeshift / random_background_sample / add_background
+ * (multilingual_kws/embedding/input_data.py:141-157,227-304) and spec_augment (:306-369).
+ * The random draws are made by the host (one item per clip); the sample-level work runs on device.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mkws_augment_item {
+  int32_t mode;     /* 0: out = shift(fg)            (random_timeshift, :245-268)
+                       1: out = bg_slice * bg_vol    (silence branch, :284-287 / :227-243)
+                       2: out = clip(shift(fg) + bg_slice * (rms(fg)/rms(bg) or 0) * bg_vol, -1, 1)
+                          (add_background, :141-157) */
+  int32_t bank;     /* foreground bank: 0 = d_bank0 (target clips), 1 = d_bank1 (unknown-word clips) */
+  int32_t src;      /* row of the foreground clip in that bank */
+  int32_t shift;    /* out[t] = fg[t - shift], zero-filled (positive = delay) */
+  int32_t bg_idx;   /* background track */
+  int32_t bg_off;   /* first sample of the n_samples-long background slice */
+  float bg_vol;
+  int32_t reserved;
+} mkws_augment_item;
+
+/* d_bank0 [n0, n_samples], d_bank1 [n1, n_samples] (may be NULL), d_bg [tracks, bg_stride] float32;
+ * d_items [B]; d_out [B, n_samples]. */
+int mkws_augment_batch(const float* d_bank0, const float* d_bank1, const float* d_bg, int64_t bg_stride,
+                       const mkws_augment_item* d_items, int B, int n_samples, float* d_out, void* stream);
+/* SpecAugment masking in place on d_spec [B, frames, channels]; d_masks int32 [B,8] =
+ * {freq0 start, size, freq1 start, size, time0 start, size, time1 start, size}; size 0 = no mask. */
+int mkws_specaug_apply(float* d_spec, const int32_t* d_masks, int B, int frames, int channels, void* stream);
 
 #ifdef __cplusplus
 }

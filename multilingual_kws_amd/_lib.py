@@ -48,7 +48,11 @@ SYMBOLS = [
     ("mkws_embed_create", _I, [_P, _SZ, _I, ctypes.POINTER(_P)]),
     ("mkws_embed_destroy", None, [_P]),
     ("mkws_embed_forward", _I, [_P, _P, _I, _P, _P]),
+    ("mkws_embed_set_option", _I, [_P, ctypes.c_char_p, _I]),
+    ("mkws_embed_profile", _I, [_P, _P, _I, _I, _P, ctypes.c_char_p, _SZ, _P]),
     ("mkws_embed_forward_tap", _I, [_P, _P, _I, ctypes.c_char_p, _P, _SZ, _P]),
+    ("mkws_augment_batch", _I, [_P, _P, _P, ctypes.c_int64, _P, _I, _I, _P, _P]),
+    ("mkws_specaug_apply", _I, [_P, _P, _I, _I, _I, _P]),
     ("mkws_head_create", _I, [_I, _I, _I, _I, ctypes.POINTER(_P)]),
     ("mkws_head_destroy", None, [_P]),
     ("mkws_head_param_count", _I, [_P]),

@@ -31,7 +31,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SELU = 3, ACT_SIGMOID = 4 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// sigmoid on the hardware transcendentals: v_exp_f32 + v_rcp_f32 (1 ulp each) -- 4 instructions, vs ~20 for
+// expf + IEEE division; swish sits in every epilogue and was the largest VALU cost of the fused kernels.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -83,7 +87,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ spe
 // ------------------------------------------------------------------------------------------------
 // 1x1 conv / dense GEMM.  Y[m, n] = act((sum_k X[m,k] * gate[m/HW, k] * W[k,n]) * scale[n] + shift[n]) + R[m,n]
 // Packed weights: Wp[((nt*KC + j)*4 + g)*64 + c*4 + s] = W[16j + 4g + s][16nt + c]  (zero padded).
-// Block = 4 waves; wave w owns rows [blockIdx.x*128 + 32w, +32) and NT n-tiles starting at blockIdx.y*NT.
+// Block = 4 waves; wave w owns MT row tiles (16 rows each) starting at blockIdx.x*64*MT + 16*MT*w and NT
+// n-tiles starting at blockIdx.y*NT.  (MT, NT) is picked per layer so that small-M layers still put several
+// waves on every SIMD (launch_gemm).
 struct GemmArgs {
   const float* X; int ldx;
   const float* Wp; const float* scale; const float* shift;
@@ -91,22 +97,24 @@ struct GemmArgs {
   const float* R; int ldr;
   float* Y; int ldy;
   int M, K, N, KC, NTtot, act;
+  int splitk;      // > 1: blockIdx.z owns a slice of the K chunks and writes raw sums to part[z][M][ldp]
+  float* part; int ldp;
 };
 
-template <int NT, bool GATE>
+template <int MT, int NT, bool GATE>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int m0 = blockIdx.x * 128 + wave * 32;
+  const int m0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
   const int nt0 = blockIdx.y * NT;
   if (m0 >= a.M) return;
 
-  const float* xrow[2];
-  const float* grow[2];
-  bool rowok[2];
+  const float* xrow[MT];
+  const float* grow[MT];
+  bool rowok[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + mt * 16 + c;
     rowok[mt] = m < a.M;
     const int mm = rowok[mt] ? m : (a.M - 1);
@@ -114,18 +122,28 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
     grow[mt] = GATE ? (a.gate + (size_t)(mm / a.HW) * a.K + 4 * g) : nullptr;
   }
   const float* wbase = a.Wp + ((size_t)nt0 * a.KC * 4 + g) * 64 + c * 4;
+  // K range of this block (split-K over blockIdx.z)
+  int jbeg = 0, jend = a.KC;
+  if (a.splitk > 1) {
+    const int per = (a.KC + a.splitk - 1) / a.splitk;
+    jbeg = blockIdx.z * per;
+    jend = (jbeg + per < a.KC) ? jbeg + per : a.KC;
+  }
 
-  f32x4 acc[2][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  f32x4 xb[2], wb[NT];
-  auto load = [&](int j, f32x4 (&xv)[2], f32x4 (&wv)[NT]) {
+  // D-deep register ring over the K chunks: slot d is refilled with chunk j+D right after chunk j's MFMAs
+  // were issued, so D chunk loads are always in flight (small-tile configs are load-latency bound).
+  constexpr int D = (MT * NT >= 10) ? 3 : 4;
+  f32x4 xq[D][MT], wq[D][NT];
+  auto load = [&](int j, f32x4 (&xv)[MT], f32x4 (&wv)[NT]) {
     const bool kok = (16 * j + 4 * g) < a.K;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (kok && rowok[mt]) {
         v = *reinterpret_cast<const f32x4*>(xrow[mt] + 16 * j);
@@ -140,23 +158,36 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
       wv[nt] = v;
     }
   };
-  load(0, xb, wb);
-  for (int j = 0; j < a.KC; ++j) {
-    f32x4 xn[2], wn[NT];
-    if (j + 1 < a.KC) load(j + 1, xn, wn);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+  for (int d = 0; d < D; ++d)
+    if (jbeg + d < jend) load(jbeg + d, xq[d], wq[d]);
+  for (int j0 = jbeg; j0 < jend; j0 += D) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+    for (int d = 0; d < D; ++d) {
+      const int j = j0 + d;
+      if (j < jend) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[nt][s], xb[mt][s], acc[mt][nt], 0, 0, 0);
-    if (j + 1 < a.KC) {
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) xb[mt] = xn[mt];
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wb[nt] = wn[nt];
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d][nt][s], xq[d][mt][s], acc[mt][nt], 0, 0, 0);
+        if (j + D < jend) load(j + D, xq[d], wq[d]);
+      }
     }
+  }
+  if (a.splitk > 1) {     // raw partial sums; epilogue happens in splitk_reduce_kernel
+    float* P = a.part + (size_t)blockIdx.z * a.M * a.ldp;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (nt0 + nt) * 16 + 4 * g;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        if (rowok[mt]) *reinterpret_cast<f32x4*>(P + (size_t)(m0 + mt * 16 + c) * a.ldp + n) = acc[mt][nt];
+    }
+    return;
   }
   // epilogue: lane (g, c) holds rows m = m0 + mt*16 + c, channels n = 16*(nt0+nt) + 4g .. +3
 #pragma unroll
@@ -166,7 +197,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       if (!rowok[mt]) continue;
       const size_t m = (size_t)(m0 + mt * 16 + c);
       f32x4 y = acc[mt][nt] * sc + sh;
@@ -176,6 +207,24 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
       if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
       *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = y;
     }
+  }
+}
+
+// split-K epilogue: Y = act(sum_z part[z] * scale + shift) + R, one float4 per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splitk, int M, int N, int ldp,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                            const float* __restrict__ R, int ldr, float* __restrict__ Y, int ldy) {
+  const int nq = N / 4;
+  const long total = (long)M * nq;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / nq;
+    const int n = (int)(i % nq) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)m * ldp + n);
+    for (int z = 1; z < splitk; ++z) v += *reinterpret_cast<const f32x4*>(part + ((size_t)z * M + m) * ldp + n);
+    f32x4 y = v * *reinterpret_cast<const f32x4*>(scale + n) + *reinterpret_cast<const f32x4*>(shift + n);
+    if (act != ACT_NONE) { y.x = apply_act(y.x, act); y.y = apply_act(y.y, act); y.z = apply_act(y.z, act); y.w = apply_act(y.w, act); }
+    if (R) y += *reinterpret_cast<const f32x4*>(R + (size_t)m * ldr + n);
+    *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + n) = y;
   }
 }
 
@@ -202,8 +251,9 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X, co
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c0);
     const float* xin = X + (size_t)b * H * W * C + c0;
     float* yout = Y + (size_t)b * Ho * Wo * C + c0;
+    int oh = tp / Wo, ow = tp % Wo;
+    const int dh = P / Wo, dwo = P % Wo;
     for (int p = tp; p < Ho * Wo; p += P) {
-      const int oh = p / Wo, ow = p % Wo;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < KS; ++i) {
@@ -220,6 +270,8 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X, co
       y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
       *reinterpret_cast<f32x4*>(yout + (size_t)p * C) = y;
       ssum += y;
+      oh += dh; ow += dwo;
+      if (ow >= Wo) { ow -= Wo; ++oh; }
     }
   }
   s_red[threadIdx.x] = ssum;
@@ -232,45 +284,383 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// SE: mean = sums/HW; r = swish(mean @ Wr + br); gate = sigmoid(r @ We + be).  4 clips per block.
-__global__ __launch_bounds__(256) void se_kernel(const float* __restrict__ sums, float inv_hw, const float* __restrict__ Wr /*[C][se]*/,
-                                                 const float* __restrict__ br, const float* __restrict__ We /*[se][C]*/,
-                                                 const float* __restrict__ be, float* __restrict__ gate, int B, int C, int se) {
-  extern __shared__ __attribute__((aligned(16))) float s_se[];
-  float* s_mean = s_se;            // [4][C]
-  float* s_r = s_se + 4 * C;       // [4][64]
-  const int b0 = blockIdx.x * 4;
+// Fused MBConv front half: 1x1 expand conv (+BN+swish) -> LDS -> depthwise kxk (+BN+swish) -> Y, + SE sums.
+// The expanded activation (6x the block input, the largest tensor of every block) never leaves the CU.
+//   block = G consecutive clips x CC expanded channels.
+//   phase 1: E[G*H*W, CC] = swish(BN(X[G*H*W, Cin] . We[:, chunk])) on the fp32 MFMA (same transposed
+//            operand scheme and packed weights as pw_gemm_kernel), written to LDS as float4 rows.
+//   phase 2: depthwise from LDS.  PIXEL_LANES (big images): thread = (pixel lane, channel quad), one clip at
+//            a time, SE sums reduced through LDS;  otherwise (tiny images): thread = (clip, channel quad)
+//            walks all output pixels itself and owns its SE sums.
+struct FrontArgs {
+  const float* X; int Cin;
+  const float* WpE; const float* scE; const float* shE; int KC;
+  const float* Wd; const float* scD; const float* shD;
+  float* Y; float* sums;
+  int B, H, W, Ho, Wo, pt, pl, Cexp, G;
+};
+
+// Template: KS/S depthwise kernel & stride; CC channels per block; KCT > 0: big-image mode with exactly KCT
+// K chunks (weights in registers); KCT == 0: tiny-image mode with compile-time image size HT x WT.
+template <int KS, int S, int CC, int KCT, int HT, int WT>
+__global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(FrontArgs a) {
+  constexpr bool PIXEL_LANES = KCT > 0;
+  constexpr int NTHREADS = PIXEL_LANES ? 256 : 512;
+  extern __shared__ __attribute__((aligned(16))) float s_front[];
+  constexpr int LDE = CC + 4;
+  constexpr int NT = CC / 16;
+  constexpr int Q = CC / 4;
+  const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+  float* s_E = s_front;                        // [G*HW][LDE]
+  f32x4* s_red = reinterpret_cast<f32x4*>(s_front + (size_t)a.G * HW * LDE);   // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 4 * C; i += 256) {
-    const int bb = i / C, cc = i % C;
-    s_mean[i] = (b0 + bb < B) ? sums[(size_t)(b0 + bb) * C + cc] * inv_hw : 0.0f;
+  const int g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * a.G;
+  const int gvalid = (a.B - b0 < a.G) ? (a.B - b0) : a.G;
+  const int rows = gvalid * HW;
+  const int ch0 = blockIdx.y * CC;             // first expanded channel of this block
+  // nt_valid: n-tiles of this block that exist (the last chunk of a layer may be partial)
+  const int nt_valid = ((a.Cexp - ch0) / 16 < NT) ? (a.Cexp - ch0) / 16 : NT;
+  // ---- phase 1: expand into LDS ----
+  // Operand fragments go global -> registers through the vector L1 (64 B/clk/CU), which is what bounds
+  // small MFMA tiles; so weights are fetched as rarely as possible:
+  //   PIXEL_LANES (few K chunks, many row tiles): all weight fragments of the block live in registers;
+  //   tiny images (many K chunks, CC = 128): each weight fragment feeds MT = 2 row tiles.
+  {
+    const float* Xb = a.X + (size_t)b0 * HW * a.Cin;
+    const float* wbase = a.WpE + ((size_t)(ch0 / 16) * a.KC * 4 + g) * 64 + c * 4;
+    const int ntiles = (rows + 15) / 16;
+    auto epilogue = [&](int row, const f32x4 (&acc)[NT]) {
+      if (row < rows) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (nt < nt_valid) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scE + ch0 + nt * 16 + 4 * g);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shE + ch0 + nt * 16 + 4 * g);
+            f32x4 y = acc[nt] * sc + sh;
+            y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+            *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + nt * 16 + 4 * g) = y;
+          }
+        }
+      }
+    };
+    if constexpr (PIXEL_LANES) {
+      constexpr int MAXKC = KCT;             // exact K chunk count of the layer (Cin = 16, 24, 40 -> 1, 2, 3)
+      f32x4 wreg[MAXKC][NT];
+#pragma unroll
+      for (int j = 0; j < MAXKC; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          wreg[j][nt] = (j < a.KC && nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + ((size_t)nt * a.KC + j) * 256)
+                                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
+      // row tiles of this wave: wave, wave+4, ...; X fragments of D tiles in flight
+      constexpr int D = 4;
+      f32x4 xq[D][MAXKC];
+      auto loadx = [&](int t, f32x4 (&xv)[MAXKC]) {
+        const int row = t * 16 + c;
+#pragma unroll
+        for (int j = 0; j < MAXKC; ++j) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (j < a.KC && row < rows && (16 * j + 4 * g) < a.Cin) v = *reinterpret_cast<const f32x4*>(Xb + (size_t)row * a.Cin + 16 * j + 4 * g);
+          xv[j] = v;
+        }
+      };
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+        if (wave + 4 * d < ntiles) loadx(wave + 4 * d, xq[d]);
+      for (int t0 = wave; t0 < ntiles; t0 += 4 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const int t = t0 + 4 * d;
+          if (t < ntiles) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < MAXKC; ++j)
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][nt][s], xq[d][j][s], acc[nt], 0, 0, 0);
+            if (t + 4 * D < ntiles) loadx(t + 4 * D, xq[d]);
+            epilogue(t * 16 + c, acc);
+          }
+        }
+      }
+    } else {
+      // 8 waves = 4 row-pair lanes x 2 column halves: wave tile = 2 row tiles x NT/2 column tiles, so one
+      // K chunk costs 2 X + NT/2 weight fragments (6 KB) for 2*NT/2*4 = 16 MFMAs per quarter... (24 B/clk/CU)
+      constexpr int NTW = (NT >= 2) ? NT / 2 : 1;
+      const int nhalf = wave >> 2, plane = wave & 3;
+      const int npairs = (ntiles + 1) / 2;
+      for (int pr = plane; pr < npairs; pr += 4) {
+        const int row0 = pr * 32 + c, row1 = row0 + 16;
+        f32x4 acc0[NTW], acc1[NTW];
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) { acc0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        constexpr int D = 3;
+        f32x4 x0[D], x1[D], wq[D][NTW];
+        auto load = [&](int j, f32x4& v0, f32x4& v1, f32x4 (&wv)[NTW]) {
+          const bool kok = (16 * j + 4 * g) < a.Cin;
+          v0 = (kok && row0 < rows) ? *reinterpret_cast<const f32x4*>(Xb + (size_t)row0 * a.Cin + 16 * j + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          v1 = (kok && row1 < rows) ? *reinterpret_cast<const f32x4*>(Xb + (size_t)row1 * a.Cin + 16 * j + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) {
+            const int nt = nhalf * NTW + q;
+            wv[q] = (nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + ((size_t)nt * a.KC + j) * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+          if (d < a.KC) load(d, x0[d], x1[d], wq[d]);
+        for (int j0 = 0; j0 < a.KC; j0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const int j = j0 + d;
+            if (j < a.KC) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) {
+                  acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d][q][s], x0[d][s], acc0[q], 0, 0, 0);
+                  acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d][q][s], x1[d][s], acc1[q], 0, 0, 0);
+                }
+              if (j + D < a.KC) load(j + D, x0[d], x1[d], wq[d]);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+          const int nt = nhalf * NTW + q;
+          if (nt < nt_valid) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scE + ch0 + nt * 16 + 4 * g);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shE + ch0 + nt * 16 + 4 * g);
+            if (row0 < rows) {
+              f32x4 y = acc0[q] * sc + sh;
+              y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+              *reinterpret_cast<f32x4*>(s_E + (size_t)row0 * LDE + nt * 16 + 4 * g) = y;
+            }
+            if (row1 < rows) {
+              f32x4 y = acc1[q] * sc + sh;
+              y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+              *reinterpret_cast<f32x4*>(s_E + (size_t)row1 * LDE + nt * 16 + 4 * g) = y;
+            }
+          }
+        }
+      }
+    }
   }
   __syncthreads();
-  if (lane < se) {
-    const float* mrow = s_mean + wave * C;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    int cc = 0;
-    for (; cc + 3 < C; cc += 4) {
-      acc0 += mrow[cc] * Wr[(size_t)cc * se + lane];
-      acc1 += mrow[cc + 1] * Wr[(size_t)(cc + 1) * se + lane];
-      acc2 += mrow[cc + 2] * Wr[(size_t)(cc + 2) * se + lane];
-      acc3 += mrow[cc + 3] * Wr[(size_t)(cc + 3) * se + lane];
+  // ---- phase 2: depthwise from LDS ----
+  if constexpr (PIXEL_LANES) {
+    constexpr int PL = 256 / Q;
+    const int tq = tid % Q, tp = tid / Q;
+    const bool qok = tq < nt_valid * 4;
+    const int cq = qok ? ch0 + 4 * tq : ch0;
+    f32x4 wk[KS * KS];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) wk[t] = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)t * a.Cexp + cq);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
+    const int dh = PL / a.Wo, dwo = PL % a.Wo;
+    for (int gi = 0; gi < gvalid; ++gi) {
+      const float* E = s_E + (size_t)gi * HW * LDE + 4 * tq;
+      float* yout = a.Y + (size_t)(b0 + gi) * HoWo * a.Cexp + cq;
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+      int oh = tp / a.Wo, ow = tp % a.Wo;
+      for (int p = tp; qok && p < HoWo; p += PL) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          const int ih = oh * S - a.pt + i;
+          if (ih < 0 || ih >= a.H) continue;
+#pragma unroll
+          for (int jx = 0; jx < KS; ++jx) {
+            const int iw = ow * S - a.pl + jx;
+            if (iw < 0 || iw >= a.W) continue;
+            acc += *reinterpret_cast<const f32x4*>(E + (size_t)(ih * a.W + iw) * LDE) * wk[i * KS + jx];
+          }
+        }
+        f32x4 y = acc * sc + sh;
+        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+        *reinterpret_cast<f32x4*>(yout + (size_t)p * a.Cexp) = y;
+        ssum += y;
+        oh += dh; ow += dwo;
+        if (ow >= a.Wo) { ow -= a.Wo; ++oh; }
+      }
+      s_red[tid] = ssum;
+      __syncthreads();
+      if (tid < nt_valid * 4) {
+        f32x4 t = s_red[tid];
+        for (int k = 1; k < PL; ++k) t += s_red[k * Q + tid];
+        *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + ch0 + 4 * tid) = t;
+      }
+      __syncthreads();
     }
-    for (; cc < C; ++cc) acc0 += mrow[cc] * Wr[(size_t)cc * se + lane];
-    s_r[wave * 64 + lane] = swishf_(((acc0 + acc1) + (acc2 + acc3)) + br[lane]);
+  } else {
+    // image size is a template constant here: the tap loops unroll completely and taps that fall outside
+    // the 4x3 / 2x2 image disappear at compile time (most of a 5x5 kernel does)
+    constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1);
+    // Keras padding as constants: "same" for stride 1, correct_pad for stride 2
+    constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+    for (int task = tid; task < gvalid * Q; task += NTHREADS) {
+      const int tq = task % Q, gi = task / Q;
+      if (tq >= nt_valid * 4) continue;
+      const int cq = ch0 + 4 * tq;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
+      const float* E = s_E + (size_t)gi * (HT * WT) * LDE + 4 * tq;
+      const float* wd = a.Wd + cq;
+      float* yout = a.Y + (size_t)(b0 + gi) * (HoT * WoT) * a.Cexp + cq;
+      f32x4 ein[HT * WT];
+#pragma unroll
+      for (int pix = 0; pix < HT * WT; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(E + (size_t)pix * LDE);
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[HoT * WoT];
+#pragma unroll
+      for (int o = 0; o < HoT * WoT; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) {
+          // is this tap used by any output pixel?
+          bool used = false;
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+            }
+          if (!used) continue;
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wd + (size_t)(i * KS + jx) * a.Cexp);
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv;
+            }
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < HoT * WoT; ++o) {
+        f32x4 y = acc[o] * sc + sh;
+        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+        *reinterpret_cast<f32x4*>(yout + (size_t)o * a.Cexp) = y;
+        ssum += y;
+      }
+      *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + cq) = ssum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SE: mean = sums/HW; r = swish(mean @ Wr + br); gate = sigmoid(r @ We + be).
+// Both FCs run on the fp32 MFMA as (weights x 16 clips) tiles with pack_gemm-packed weights, and both are
+// spread over the whole chip (a single block per 16 clips would stream up to 442 KB of SE weights through
+// one CU):
+//   se_reduce_kernel  grid (B/16, nslices): K = C is split across blocks (and the 4 waves of a block);
+//                     raw partial r^T[se, 16] tiles go to a small global buffer (fixed-order, no atomics)
+//   se_expand_kernel  grid (B/16, nsplit):  sums the partials (+bias, swish), then computes its share of
+//                     the C/16 output row tiles of gate^T[C, 16] = We^T[C, se] . r^T[se, 16]
+template <int NTR>
+__global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict__ sums, float inv_hw, const float* __restrict__ WrP,
+                                                        float* __restrict__ part, int B, int C, int KCr, int nslices) {
+  __shared__ float s_part[4 * NTR * 256];
+  const int b0 = blockIdx.x * 16, z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int per = (KCr + nslices - 1) / nslices;
+  const int j0 = z * per;
+  const int j1 = (j0 + per < KCr) ? j0 + per : KCr;
+  const bool clip_ok = b0 + c < B;
+  const float* srow = sums + (size_t)(clip_ok ? b0 + c : 0) * C + 4 * g;
+  const float* wbase = WrP + (size_t)g * 64 + c * 4;
+  f32x4 acc[NTR];
+#pragma unroll
+  for (int nt = 0; nt < NTR; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 3;            // chunks per wave issued together (per <= 9 chunks, 4 waves)
+  for (int jb = j0 + wave; jb < j1; jb += 4 * U) {
+    f32x4 wv[U][NTR], xb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = jb + 4 * u;
+      const bool ok = j < j1;
+#pragma unroll
+      for (int nt = 0; nt < NTR; ++nt)
+        wv[u][nt] = ok ? *reinterpret_cast<const f32x4*>(wbase + ((size_t)nt * KCr + j) * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      xb[u] = (ok && clip_ok && 16 * j + 4 * g < C) ? *reinterpret_cast<const f32x4*>(srow + 16 * j) * inv_hw : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NTR; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][nt][s], xb[u][s], acc[nt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NTR; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_part[((wave * NTR + nt) * 16 + 4 * g + r) * 16 + c] = acc[nt][r];
+  __syncthreads();
+  float* dst = part + ((size_t)z * gridDim.x + blockIdx.x) * NTR * 256;
+  for (int t = tid; t < NTR * 256; t += 256)
+    dst[t] = (s_part[t] + s_part[NTR * 256 + t]) + (s_part[2 * NTR * 256 + t] + s_part[3 * NTR * 256 + t]);
+}
+
+template <int NTR>
+__global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict__ part, int nslices, const float* __restrict__ br,
+                                                        const float* __restrict__ WeP, const float* __restrict__ be,
+                                                        float* __restrict__ gate, int B, int C, int se, int NTe, int nsplit) {
+  constexpr int LDR = NTR * 16 + 4;
+  __shared__ __attribute__((aligned(16))) float s_r[16 * LDR];
+  const int b0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  for (int t = tid; t < NTR * 256; t += 256) {
+    const int n = t >> 4, clip = t & 15;
+    float v = 0.0f;
+    if (n < se) {
+      for (int z = 0; z < nslices; ++z) v += part[((size_t)z * gridDim.x + blockIdx.x) * NTR * 256 + t];
+      v = swishf_(v + br[n]);
+    }
+    s_r[clip * LDR + n] = v;
   }
   __syncthreads();
-  for (int cc = tid; cc < C; cc += 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int j = 0; j < se; ++j) {
-      const float w = We[(size_t)j * C + cc];
-      a0 += s_r[j] * w; a1 += s_r[64 + j] * w; a2 += s_r[128 + j] * w; a3 += s_r[192 + j] * w;
+  f32x4 rb[NTR];
+#pragma unroll
+  for (int jj = 0; jj < NTR; ++jj) rb[jj] = *reinterpret_cast<const f32x4*>(s_r + c * LDR + 16 * jj + 4 * g);
+  const int tper = (NTe + nsplit - 1) / nsplit;
+  const int t0 = blockIdx.y * tper;
+  const int t1 = (t0 + tper < NTe) ? t0 + tper : NTe;
+  constexpr int U = 3;
+  for (int tb = t0 + wave; tb < t1; tb += 4 * U) {
+    f32x4 wv[U][NTR], bias[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 4 * u;
+      const bool ok = t < t1;
+#pragma unroll
+      for (int jj = 0; jj < NTR; ++jj)
+        wv[u][jj] = ok ? *reinterpret_cast<const f32x4*>(WeP + (((size_t)t * NTR + jj) * 4 + g) * 64 + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      bias[u] = (ok && t * 16 + 4 * g < C) ? *reinterpret_cast<const f32x4*>(be + t * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const float bias = be[cc];
-    if (b0 + 0 < B) gate[(size_t)(b0 + 0) * C + cc] = sigmoidf_(a0 + bias);
-    if (b0 + 1 < B) gate[(size_t)(b0 + 1) * C + cc] = sigmoidf_(a1 + bias);
-    if (b0 + 2 < B) gate[(size_t)(b0 + 2) * C + cc] = sigmoidf_(a2 + bias);
-    if (b0 + 3 < B) gate[(size_t)(b0 + 3) * C + cc] = sigmoidf_(a3 + bias);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 4 * u;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < NTR; ++jj)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][jj][s], rb[jj][s], acc, 0, 0, 0);
+      const int n = t * 16 + 4 * g;
+      if (t < t1 && n < C && b0 + c < B) {
+        f32x4 y = acc + bias[u];
+        y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
+        *reinterpret_cast<f32x4*>(gate + (size_t)(b0 + c) * C + n) = y;
+      }
+    }
   }
 }
 
@@ -296,7 +686,7 @@ struct GemmLayer {   // device pointers into the weight blob
   int K = 0, N = 0, KC = 0, NTtot = 0;
 };
 struct DwLayer { const float* Wd = nullptr; const float* scale = nullptr; const float* shift = nullptr; };
-struct SeLayer { const float* Wr = nullptr; const float* br = nullptr; const float* We = nullptr; const float* be = nullptr; int se = 0; };
+struct SeLayer { const float* WrP = nullptr; const float* br = nullptr; const float* WeP = nullptr; const float* be = nullptr; int se = 0, KCr = 0, NTR = 0, NTe = 0; };
 
 struct BlockPlan {
   MBConvSpec spec;
@@ -322,15 +712,47 @@ struct mkws_embed {
   float *bufD = nullptr;                    // depthwise output (18720)
   float *sums = nullptr, *gate = nullptr;   // (1152 each)
   float *gap = nullptr, *d0 = nullptr, *d1 = nullptr;   // (1280, 2048, 2048)
+  float* se_part = nullptr;                              // SE reduce partials (8 slices x 48 = 384, + tile padding)
+  float* splitk_ws = nullptr; size_t splitk_floats = 0;  // (4 slices x 4 rows x 320 cols = 5120)
   // plan
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
+  bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
   int topH = 0, topW = 0;
 };
 
 namespace {
+
+// Optional per-launch timing (mkws_embed_profile): a hipEvent pair around every kernel launch.
+struct LaunchProf {
+  struct Rec { std::string stage, kernel; hipEvent_t e0, e1; double ms = 0.0; };
+  std::vector<Rec> recs;
+  size_t cursor = 0;
+  bool first = true;
+  hipStream_t stream = nullptr;
+  void begin(const std::string& stage, const std::string& kernel) {
+    if (first) {
+      Rec r; r.stage = stage; r.kernel = kernel;
+      (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+      recs.push_back(r);
+    }
+    (void)hipEventRecord(recs[cursor].e0, stream);
+  }
+  void end() { (void)hipEventRecord(recs[cursor].e1, stream); ++cursor; }
+  void finish_pass() {
+    (void)hipStreamSynchronize(stream);
+    for (auto& r : recs) { float ms = 0.f; (void)hipEventElapsedTime(&ms, r.e0, r.e1); r.ms += ms; }
+    cursor = 0; first = false;
+  }
+  ~LaunchProf() { for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); } }
+};
+static thread_local LaunchProf* g_prof = nullptr;
+struct ProfScope {
+  ProfScope(const std::string& stage, const std::string& kernel) { if (g_prof) g_prof->begin(stage, kernel); }
+  ~ProfScope() { if (g_prof) g_prof->end(); }
+};
 
 // ---- host-side packing -------------------------------------------------------------------------------
 struct Packer {
@@ -388,50 +810,89 @@ int pick_cqb(int cq) {   // largest divisor of cq that is <= 64
   return 1;
 }
 
-template <bool GATE>
+// split-K workspace of the handle whose forward is running (set by run_forward)
+static thread_local float* g_splitk_ws = nullptr;
+static thread_local size_t g_splitk_ws_floats = 0;
+
+template <int MT, bool GATE>
 void launch_gemm_nt(int NT, dim3 grid, hipStream_t s, const GemmArgs& a) {
   switch (NT) {
-    case 1: hipLaunchKernelGGL((pw_gemm_kernel<1, GATE>), grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((pw_gemm_kernel<2, GATE>), grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((pw_gemm_kernel<3, GATE>), grid, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((pw_gemm_kernel<4, GATE>), grid, dim3(256), 0, s, a); break;
-    case 5: hipLaunchKernelGGL((pw_gemm_kernel<5, GATE>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((pw_gemm_kernel<6, GATE>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((pw_gemm_kernel<MT, 1, GATE>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((pw_gemm_kernel<MT, 2, GATE>), grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((pw_gemm_kernel<MT, 3, GATE>), grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((pw_gemm_kernel<MT, 4, GATE>), grid, dim3(256), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((pw_gemm_kernel<MT, 5, GATE>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((pw_gemm_kernel<MT, 6, GATE>), grid, dim3(256), 0, s, a); break;
   }
 }
 
-void launch_gemm(hipStream_t s, const GemmLayer& L, const float* X, int ldx, int M, int act, const float* gate, int HW,
+// Tile / split-K choice.  Per K chunk a wave loads (MT+NT) KB for MT*NT*4 MFMAs, so big tiles mean little
+// L1/L2 operand traffic (B/clk/CU ~ 32*(MT+NT)/(MT*NT): 48 for 1x2, 32 for 2x2, 21 for 2x6), but small-M
+// layers then leave SIMDs idle.  Policy: among configs with >= kWantWaves waves take the least operand
+// traffic (then least N padding); if none gets there, split K (long-K layers only) and otherwise take the
+// config with the most waves.
+constexpr int kWantWaves = 2048;
+struct TileChoice { int MT, NT, splitk; };
+TileChoice pick_tile(int M, int NTtot, int KC) {
+  TileChoice best = {1, NTtot < 2 ? 1 : 2, 1};
+  double best_cost = 1e30;
+  long best_waves = -1;
+  bool found = false;
+  for (int sk = 1; sk <= 4; sk *= 2) {
+    if (sk > 1 && KC / sk < 16) break;               // keep >= 16 chunks per slice
+    for (int mt = 2; mt >= 1; --mt) {
+      for (int nt = 6; nt >= 1; --nt) {
+        if (nt > NTtot || (nt == 1 && NTtot > 1)) continue;
+        const long nblk = (NTtot + nt - 1) / nt;
+        const long waves = ((M + 16 * mt - 1) / (16 * mt)) * nblk * sk;
+        const double traffic = (double)(mt + nt) / (mt * nt) * (mt == 1 ? 1.5 : 1.0);   // MT = 1 tiles are vector-L1 bound
+        const double pad = (double)(nblk * nt) / NTtot;
+        const double cost = traffic * pad * (sk == 1 ? 1.0 : (sk == 2 ? 1.15 : 1.3));
+        if (waves >= kWantWaves) {
+          if (!found || cost < best_cost - 1e-9) { found = true; best_cost = cost; best = {mt, nt, sk}; }
+        } else if (!found && sk == 1 && waves > best_waves) {
+          best_waves = waves; best = {mt, nt, 1};
+        }
+      }
+    }
+  }
+  return best;
+}
+
+// Mplan = the row count this layer has at the handle's max_batch: tile and split-K choices are made for
+// THAT size, so a handle computes every clip with the same summation order whatever the batch it arrives
+// in (bit-identical results across batch sizes and batch compositions).
+void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const float* X, int ldx, int M, int Mplan, int act, const float* gate, int HW,
                  const float* R, int ldr, float* Y, int ldy) {
   GemmArgs a;
   a.X = X; a.ldx = ldx; a.Wp = L.Wp; a.scale = L.scale; a.shift = L.shift; a.gate = gate; a.HW = HW > 0 ? HW : 1;
   a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy; a.M = M; a.K = L.K; a.N = L.N; a.KC = L.KC; a.NTtot = L.NTtot; a.act = act;
-  const int nblk = (L.NTtot + 5) / 6;
-  const int NT = (L.NTtot + nblk - 1) / nblk;
-  dim3 grid((M + 127) / 128, (L.NTtot + NT - 1) / NT);
-  if (gate) launch_gemm_nt<true>(NT, grid, s, a);
-  else launch_gemm_nt<false>(NT, grid, s, a);
-}
-
-void launch_dw(hipStream_t s, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
-  const int cq = b.ce / 4;
-  const int CQB = pick_cqb(cq);
-  int P = 256 / CQB;
-  const int npix = b.Ho * b.Wo;
-  if (P > npix) P = npix;
-  dim3 grid(B, cq / CQB);
-#define MKWS_DW(KS, S) hipLaunchKernelGGL((dw_kernel<KS, S>), grid, dim3(256), 0, s, X, b.dw.Wd, b.dw.scale, b.dw.shift, Y, sums, \
-                                          b.H, b.W, b.ce, b.Ho, b.Wo, b.pt, b.pl, CQB, P)
-  if (b.spec.kernel == 3 && b.spec.stride == 1) MKWS_DW(3, 1);
-  else if (b.spec.kernel == 3) MKWS_DW(3, 2);
-  else if (b.spec.stride == 1) MKWS_DW(5, 1);
-  else MKWS_DW(5, 2);
-#undef MKWS_DW
+  const TileChoice tc = pick_tile(Mplan, L.NTtot, L.KC);
+  const int MT = tc.MT, NT = tc.NT;
+  a.splitk = tc.splitk; a.part = nullptr; a.ldp = L.NTtot * 16;
+  if (tc.splitk > 1) {
+    if (!g_splitk_ws || (size_t)tc.splitk * M * a.ldp > g_splitk_ws_floats) a.splitk = 1;   // no workspace: plain path
+    else a.part = g_splitk_ws;
+  }
+  dim3 grid((M + 64 * MT - 1) / (64 * MT), (L.NTtot + NT - 1) / NT, a.splitk);
+  {
+    ProfScope ps(stage, std::string("pw_gemm_kernel<") + std::to_string(MT) + "," + std::to_string(NT) + (gate ? ",true>" : ",false>"));
+    if (MT == 2) { if (gate) launch_gemm_nt<2, true>(NT, grid, s, a); else launch_gemm_nt<2, false>(NT, grid, s, a); }
+    else { if (gate) launch_gemm_nt<1, true>(NT, grid, s, a); else launch_gemm_nt<1, false>(NT, grid, s, a); }
+  }
+  if (a.splitk > 1) {
+    ProfScope ps(std::string(stage) + "#reduce", "splitk_reduce_kernel");
+    const long total = (long)M * (L.N / 4);
+    int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, a.part, a.splitk, M, L.N, a.ldp, L.scale, L.shift, act, R, ldr, Y, ldy);
+  }
 }
 
 // Runs the network; stops after `stop` (nullptr = run everything).  On stop, *tap_src/*tap_count describe
 // the buffer holding that stage's output.
 int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStream_t s, const char* stop,
                 const float** tap_src, size_t* tap_count) {
+  g_splitk_ws = em->splitk_ws; g_splitk_ws_floats = em->splitk_floats;
   auto hit = [&](const std::string& name, const float* p, size_t n) {
     if (stop && name == stop) { *tap_src = p; *tap_count = n; return true; }
     return false;
@@ -440,6 +901,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     const long pix = (long)B * 500;
     int grid = (int)((pix + 31) / 32);
     if (grid > 8192) grid = 8192;
+    ProfScope ps("stem", "stem_kernel");
     hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 0, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift,
                        em->norm_mean, em->norm_std, em->bufA, B);
   }
@@ -450,36 +912,40 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     const BlockPlan& b = em->blocks[i];
     const std::string p = std::string("block") + b.spec.name;
     const int Min = B * b.H * b.W, Mout = B * b.Ho * b.Wo;
-    const float* dw_in = cur;
-    if (b.has_expand) {
-      launch_gemm(s, b.expand, cur, b.spec.in_ch, Min, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
-      dw_in = em->bufE;
+    const bool want_expand_tap = stop && (p + "_expand") == stop;
+    if (b.has_expand && (want_expand_tap || !em->fuse_front)) {
+      // unfused path: kept for the "<block>_expand" parity tap and as an A/B switch (mkws_embed_set_option)
+      launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       if (hit(p + "_expand", em->bufE, (size_t)Min * b.ce)) return MKWS_OK;
+      launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
+    } else if (b.has_expand) {
+      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
+    } else {
+      launch_dw(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
     }
-    launch_dw(s, b, dw_in, em->bufD, em->sums, B);
     if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
-    hipLaunchKernelGGL(se_kernel, dim3((B + 3) / 4), dim3(256), (4 * b.ce + 256) * sizeof(float), s, em->sums,
-                       1.0f / (float)(b.Ho * b.Wo), b.se.Wr, b.se.br, b.se.We, b.se.be, em->gate, B, b.ce, b.se.se);
+    launch_se(s, (p + "_gate").c_str(), b, em->sums, em->se_part, em->gate, B);
     if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
-    launch_gemm(s, b.project, em->bufD, b.ce, Mout, ACT_NONE, em->gate, b.Ho * b.Wo, b.residual ? cur : nullptr,
+    launch_gemm(s, p.c_str(), b.project, em->bufD, b.ce, Mout, em->max_batch * b.Ho * b.Wo, ACT_NONE, em->gate, b.Ho * b.Wo, b.residual ? cur : nullptr,
                 b.spec.out_ch, nxt, b.spec.out_ch);
     if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
     float* t = cur; cur = nxt; nxt = t;
   }
   const int HWt = em->topH * em->topW;
-  launch_gemm(s, em->top, cur, em->top.K, B * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, kTopCh);
+  launch_gemm(s, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, kTopCh);
   if (hit("top", em->bufE, (size_t)B * HWt * kTopCh)) return MKWS_OK;
   {
     const long total = (long)B * (kTopCh / 4);
+    ProfScope ps("gap", "mean_hw_kernel");
     hipLaunchKernelGGL(mean_hw_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, em->bufE, em->gap, B, HWt, kTopCh);
   }
   if (hit("gap", em->gap, (size_t)B * kTopCh)) return MKWS_OK;
-  launch_gemm(s, em->dense0, em->gap, kTopCh, B, ACT_RELU, nullptr, 0, nullptr, 0, em->d0, kDense0);
+  launch_gemm(s, "dense", em->dense0, em->gap, kTopCh, B, em->max_batch, ACT_RELU, nullptr, 0, nullptr, 0, em->d0, kDense0);
   if (hit("dense", em->d0, (size_t)B * kDense0)) return MKWS_OK;
-  launch_gemm(s, em->dense1, em->d0, kDense0, B, ACT_RELU, nullptr, 0, nullptr, 0, em->d1, kDense1);
+  launch_gemm(s, "dense_1", em->dense1, em->d0, kDense0, B, em->max_batch, ACT_RELU, nullptr, 0, nullptr, 0, em->d1, kDense1);
   if (hit("dense_1", em->d1, (size_t)B * kDense1)) return MKWS_OK;
   float* out = d_emb ? d_emb : em->d0;
-  launch_gemm(s, em->dense2, em->d1, kDense1, B, ACT_SELU, nullptr, 0, nullptr, 0, out, kEmbDim);
+  launch_gemm(s, "dense_2", em->dense2, em->d1, kDense1, B, em->max_batch, ACT_SELU, nullptr, 0, nullptr, 0, out, kEmbDim);
   if (hit("dense_2", out, (size_t)B * kEmbDim)) return MKWS_OK;
   if (stop) return fail(MKWS_ERR_INVALID_ARG, "unknown stage '%s'", stop);
   return MKWS_OK;
@@ -545,7 +1011,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   fold_bn(T("stem_bn/gamma"), T("stem_bn/beta"), T("stem_bn/moving_mean"), T("stem_bn/moving_variance"), kStemCh, &sc, &sh);
   const size_t o_stem_sc = pk.add(sc.data(), kStemCh), o_stem_sh = pk.add(sh.data(), kStemCh);
 
-  struct BlockOff { GemmOff expand, project; size_t dw_w, dw_sc, dw_sh, se_wr, se_br, se_we, se_be; } bo[kNumBlocks];
+  struct BlockOff { GemmOff expand, project, se_r, se_e; size_t dw_w, dw_sc, dw_sh; } bo[kNumBlocks];
   int H = 25, W = 20;
   for (int i = 0; i < kNumBlocks; ++i) {
     BlockPlan& b = em->blocks[i];
@@ -575,10 +1041,13 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     bo[i].dw_w = pk.add(T(p + "_dwconv/depthwise_kernel"), (size_t)b.spec.kernel * b.spec.kernel * b.ce);
     fold_bn(T(p + "_bn/gamma"), T(p + "_bn/beta"), T(p + "_bn/moving_mean"), T(p + "_bn/moving_variance"), b.ce, &sc, &sh);
     bo[i].dw_sc = pk.add(sc.data(), b.ce); bo[i].dw_sh = pk.add(sh.data(), b.ce);
-    bo[i].se_wr = pk.add(T(p + "_se_reduce/kernel"), (size_t)b.ce * se);
-    bo[i].se_br = pk.add(T(p + "_se_reduce/bias"), se);
-    bo[i].se_we = pk.add(T(p + "_se_expand/kernel"), (size_t)se * b.ce);
-    bo[i].se_be = pk.add(T(p + "_se_expand/bias"), b.ce);
+    {
+      std::vector<float> one_r(se, 1.0f), bias_r(T(p + "_se_reduce/bias"), T(p + "_se_reduce/bias") + se);
+      bo[i].se_r = pack_gemm(pk, T(p + "_se_reduce/kernel"), b.ce, se, one_r, bias_r);
+      std::vector<float> one_e(b.ce, 1.0f), bias_e(T(p + "_se_expand/bias"), T(p + "_se_expand/bias") + b.ce);
+      bo[i].se_e = pack_gemm(pk, T(p + "_se_expand/kernel"), se, b.ce, one_e, bias_e);
+      if (bo[i].se_r.NTtot > 3) { delete em; return fail(MKWS_ERR_UNSUPPORTED, "SE width %d > 48", se); }
+    }
     fold_bn(T(p + "_project_bn/gamma"), T(p + "_project_bn/beta"), T(p + "_project_bn/moving_mean"), T(p + "_project_bn/moving_variance"), b.spec.out_ch, &sc, &sh);
     bo[i].project = pack_gemm(pk, T(p + "_project_conv/kernel"), b.ce, b.spec.out_ch, sc, sh);
     H = b.Ho; W = b.Wo;
@@ -608,20 +1077,24 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     if (b.has_expand) b.expand = G(bo[i].expand);
     b.project = G(bo[i].project);
     b.dw.Wd = d + bo[i].dw_w; b.dw.scale = d + bo[i].dw_sc; b.dw.shift = d + bo[i].dw_sh;
-    b.se.Wr = d + bo[i].se_wr; b.se.br = d + bo[i].se_br; b.se.We = d + bo[i].se_we; b.se.be = d + bo[i].se_be;
+    b.se.WrP = d + bo[i].se_r.Wp; b.se.br = d + bo[i].se_r.shift; b.se.WeP = d + bo[i].se_e.Wp; b.se.be = d + bo[i].se_e.shift;
+    b.se.KCr = bo[i].se_r.KC; b.se.NTR = bo[i].se_r.NTtot; b.se.NTe = bo[i].se_e.NTtot;
+    // the expand FC's K (= se) is padded to NTR*16 by pack_gemm: KC of se_e == NTR by construction
   }
   em->top = G(o_top); em->dense0 = G(o_d0); em->dense1 = G(o_d1); em->dense2 = G(o_d2);
 
   // workspace
-  const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2;
-  const size_t ws = per_clip * (size_t)max_batch + 64;
+  const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 5120 + 384;
+  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
   }
   float* w = em->d_ws;
   const size_t mb = (size_t)max_batch;
   em->bufA = w; w += 16000 * mb; em->bufB = w; w += 16000 * mb; em->bufE = w; w += 48000 * mb; em->bufD = w; w += 18720 * mb;
-  em->sums = w; w += 1152 * mb; em->gate = w; w += 1152 * mb; em->gap = w; w += 1280 * mb; em->d0 = w; w += 2048 * mb; em->d1 = w;
+  em->sums = w; w += 1152 * mb; em->gate = w; w += 1152 * mb; em->gap = w; w += 1280 * mb; em->d0 = w; w += 2048 * mb; em->d1 = w; w += 2048 * mb;
+  em->splitk_ws = w; em->splitk_floats = 5120 * mb; w += 5120 * mb;
+  em->se_part = w;      // 8 slices x ceil(mb/16) groups x 768 floats <= 384*mb + 6144
   *out = em;
   return MKWS_OK;
 }
@@ -643,6 +1116,42 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
   if (rc != MKWS_OK) return rc;
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
+}
+
+int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
+  if (!em || !name) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
+  if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
+  return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+int mkws_embed_profile(mkws_embed* em, const float* d_spec, int B, int reps, float* d_emb, char* dst, size_t cap, void* stream) {
+  if (!em) return fail(MKWS_ERR_INVALID_ARG, "embed handle is NULL");
+  if (B <= 0 || B > em->max_batch || reps <= 0) return fail(MKWS_ERR_INVALID_ARG, "bad batch/reps");
+  if (!d_spec || !d_emb) return fail(MKWS_ERR_INVALID_ARG, "d_spec/d_emb is NULL");
+  LaunchProf prof;
+  prof.stream = static_cast<hipStream_t>(stream);
+  g_prof = &prof;
+  int rc = MKWS_OK;
+  for (int r = 0; r < reps && rc == MKWS_OK; ++r) {
+    const float* src; size_t cnt;
+    rc = run_forward(em, d_spec, B, d_emb, prof.stream, nullptr, &src, &cnt);
+    prof.finish_pass();
+  }
+  g_prof = nullptr;
+  if (rc != MKWS_OK) return rc;
+  MKWS_HIP(hipGetLastError());
+  std::string out;
+  char line[256];
+  for (const auto& r : prof.recs) {
+    snprintf(line, sizeof(line), "%s\t%s\t%.6f\n", r.stage.c_str(), r.kernel.c_str(), r.ms / reps);
+    out += line;
+  }
+  if (dst && cap > 0) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(dst, out.data(), n);
+    dst[n] = 0;
+  }
+  return (int)out.size();
 }
 
 int mkws_embed_forward_tap(mkws_embed* em, const float* d_spec, int B, const char* stage, float* d_dst, size_t cap_floats, void* stream) {

@@ -581,9 +581,9 @@ int frontend_forward_impl(mkws_frontend* fe, const T* d_audio, int B, int n_samp
   if (!fe) return fail(MKWS_ERR_INVALID_ARG, "frontend handle is NULL");
   if (B < 0 || n_samples < 0) return fail(MKWS_ERR_INVALID_ARG, "negative batch or sample count");
   if (n_samples > fe->max_samples) return fail(MKWS_ERR_INVALID_ARG, "n_samples %d exceeds max_samples %d given at create", n_samples, fe->max_samples);
-  if (!d_spec && !d_raw) return fail(MKWS_ERR_INVALID_ARG, "both outputs are NULL");
   const int frames = mkws_frontend_num_frames(&fe->cfg, n_samples);
   if (B == 0 || frames == 0) return MKWS_OK;   // empty input -> empty output, like the op
+  if (!d_spec && !d_raw) return fail(MKWS_ERR_INVALID_ARG, "both outputs are NULL");
   if (!d_audio) return fail(MKWS_ERR_INVALID_ARG, "d_audio is NULL");
   const size_t lds = clip_lds_bytes(fe, frames);
   if (lds > 64 * 1024)

@@ -76,3 +76,22 @@ class EmbeddingModel:
             n = _lib.check(self.L.mkws_embed_forward_tap(self.h, ctypes.c_void_p(spec.data_ptr()), B, stage.encode(),
                                                          ctypes.c_void_p(dst.data_ptr()), dst.numel(), _lib.current_stream_ptr()))
         return dst[:n]
+
+    def set_option(self, name, value):
+        _lib.check(self.L.mkws_embed_set_option(self.h, name.encode(), int(value)))
+
+    def profile(self, spec, reps=5):
+        """[(stage, kernel_name, avg_ms)] per kernel launch of one forward pass (hipEvent-timed)."""
+        import torch
+        spec = self._prep(spec)
+        B = spec.shape[0]
+        emb = torch.empty((B, EMBEDDING_DIM), dtype=torch.float32, device=self.device)
+        buf = ctypes.create_string_buffer(1 << 16)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mkws_embed_profile(self.h, ctypes.c_void_p(spec.data_ptr()), B, int(reps),
+                                                 ctypes.c_void_p(emb.data_ptr()), buf, len(buf), _lib.current_stream_ptr()))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            stage, kernel, ms = line.split("\t")
+            rows.append((stage, kernel, float(ms)))
+        return rows

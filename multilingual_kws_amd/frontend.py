@@ -78,6 +78,8 @@ class Frontend:
         spec = out if out is not None else torch.empty((B, F, self.num_channels), dtype=torch.float32, device=audio.device)
         raw = torch.empty((B, F, self.num_channels), dtype=torch.int16, device=audio.device) if want_raw else None
         rp = ctypes.c_void_p(raw.data_ptr()) if want_raw else None
+        if B == 0 or F == 0:                  # empty in -> empty out, like the op
+            return (spec, raw) if want_raw else spec
         if audio.dtype == torch.float32:
             fn = self.L.mkws_frontend_forward_f32
         elif audio.dtype == torch.int16:

@@ -1,0 +1,114 @@
+"""-m gpu: the HIP embedding forward against the PyTorch-CPU oracle, stage by stage, through the C-ABI.
+Tolerance: north_star asks for 1e-3 relative (fp32); measured error is ~1e-6, asserted at 1e-4."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+REL_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    from oracle.efficientnet_oracle import EmbeddingOracle
+    blob = weights.synthetic_blob()
+    return dict(blob=blob, em=EmbeddingModel(blob, max_batch=1024), oracle=EmbeddingOracle(blob), dev=torch.device("cuda:0"))
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _spec(rng, n):
+    return (rng.integers(0, 670, size=(n, 49, 40)).astype(np.float32) * np.float32(10 / 256))
+
+
+def test_every_stage_matches_oracle(ctx):
+    rng = np.random.default_rng(0)
+    spec = _spec(rng, 5)
+    spec[3] = 0.0                      # an all-silent clip
+    spec[4] = (rng.integers(500, 671, size=(49, 40)) * np.float32(10 / 256))     # a uniformly loud clip
+    taps = {}
+    ref = ctx["oracle"].forward(spec, taps).numpy()
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    assert len(taps) == 69
+    for name, exp in taps.items():
+        got = ctx["em"].tap(x, name).cpu().numpy().reshape(exp.shape)
+        assert _rel(got[:3], exp[:3]) < REL_TOL, name            # ordinary clips: fp32-roundoff class
+        assert _rel(got[3:], exp[3:]) < 1e-3, name               # silent / loud clips: north_star tolerance
+    emb = ctx["em"].forward(x).cpu().numpy()
+    assert emb.shape == (5, 1024) and _rel(emb[:3], ref[:3]) < REL_TOL and _rel(emb, ref) < 1e-3
+    assert np.array_equal(emb.argmax(1), ref.argmax(1))
+    assert np.array_equal(ctx["em"].predict(spec[..., None]), emb)          # Keras-style numpy API, NHWC input
+
+
+def test_golden_embedding_on_device(ctx, golden_dir):
+    from multilingual_kws_amd import synth
+    from multilingual_kws_amd.frontend import Frontend
+    G = json.load(open(os.path.join(golden_dir, "embedding_golden.json")))
+    audio = torch.from_numpy(synth.clips_float32(4)).to(ctx["dev"])
+    emb = ctx["em"].forward(Frontend().forward(audio)).cpu().numpy()
+    assert np.allclose(emb[:, :8], np.asarray(G["embedding_first8"]), rtol=1e-3, atol=1e-5)
+    assert np.allclose(np.linalg.norm(emb, axis=1), G["embedding_l2"], rtol=1e-4)
+    assert [int(r.argmax()) for r in emb] == G["embedding_argmax"]
+
+
+def test_ragged_batch_sizes_and_row_masks(ctx):
+    """M = B*H*W is rarely a multiple of the 128-row GEMM tile: every B must give the same rows."""
+    rng = np.random.default_rng(1)
+    spec = _spec(rng, 37)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    full = ctx["em"].forward(x)
+    ref = ctx["oracle"].forward(spec).numpy()
+    assert _rel(full.cpu().numpy(), ref) < REL_TOL
+    for b in (1, 2, 3, 7, 16, 33):
+        assert torch.equal(ctx["em"].forward(x[:b]), full[:b]), b      # bit-identical: rows never interact
+    assert ctx["em"].forward(x[:0]).shape == (0, 1024)
+
+
+def test_full_batch_properties(ctx):
+    """BASELINE size (B=1024): oracle on a subset, batch-composition invariance and determinism on all."""
+    rng = np.random.default_rng(2)
+    spec = _spec(rng, 1024)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    emb = ctx["em"].forward(x)
+    idx = np.arange(0, 1024, 97)
+    assert _rel(emb[idx].cpu().numpy(), ctx["oracle"].forward(spec[idx]).numpy()) < REL_TOL
+    perm = torch.randperm(1024, device=ctx["dev"])
+    assert torch.equal(ctx["em"].forward(x[perm]), emb[perm])
+    assert torch.equal(ctx["em"].forward(x), emb)
+    assert torch.isfinite(emb).all()
+    big = torch.cat([x, x[:100]])                                       # B > max_batch is chunked by the host wrapper
+    assert torch.equal(ctx["em"].forward(big)[1024:], emb[:100])
+
+
+def test_uncalibrated_weights_and_bad_blobs(ctx):
+    """A second weight set (raw random BN statistics) and the error contract of mkws_embed_create."""
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd._lib import MkwsError
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    from oracle.efficientnet_oracle import EmbeddingOracle
+    blob = weights.synthetic_blob(seed=7, calibrate=False)
+    spec = _spec(np.random.default_rng(3), 3)
+    em = EmbeddingModel(blob, max_batch=4)
+    assert _rel(em.forward(torch.from_numpy(spec).to(ctx["dev"])).cpu().numpy(), EmbeddingOracle(blob).forward(spec).numpy()) < REL_TOL
+    with pytest.raises(MkwsError):
+        em.forward(torch.zeros((2, 49, 40), device=ctx["dev"]), out=None) if False else EmbeddingModel(blob[:-1], max_batch=4)
+    bad = blob.copy(); bad[1000] = np.nan
+    with pytest.raises(MkwsError):
+        EmbeddingModel(bad, max_batch=4)
+    with pytest.raises(ValueError):
+        em.forward(torch.zeros((2, 48, 40), device=ctx["dev"]))
+
+
+def test_weight_container_roundtrip(ctx, tmp_path):
+    from multilingual_kws_amd import weights
+    weights.save(str(tmp_path / "w"), ctx["blob"])
+    assert np.array_equal(weights.load(str(tmp_path / "w")), ctx["blob"])
+    named = {t["name"]: ctx["blob"][t["offset"]:t["offset"] + t["count"]].reshape(t["shape"]) for t in weights.manifest()}
+    assert np.array_equal(weights.from_named_tensors(named), ctx["blob"])
