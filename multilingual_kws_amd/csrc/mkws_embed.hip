@@ -888,6 +888,105 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
   }
 }
 
+void launch_dw(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
+  ProfScope ps(stage, std::string("dw_kernel<") + std::to_string(b.spec.kernel) + "," + std::to_string(b.spec.stride) + ">");
+  const int cq = b.ce / 4;
+  const int CQB = pick_cqb(cq);
+  int P = 256 / CQB;
+  const int npix = b.Ho * b.Wo;
+  if (P > npix) P = npix;
+  dim3 grid(B, cq / CQB);
+#define MKWS_DW(KS, S) hipLaunchKernelGGL((dw_kernel<KS, S>), grid, dim3(256), 0, s, X, b.dw.Wd, b.dw.scale, b.dw.shift, Y, sums, \
+                                          b.H, b.W, b.ce, b.Ho, b.Wo, b.pt, b.pl, CQB, P)
+  if (b.spec.kernel == 3 && b.spec.stride == 1) MKWS_DW(3, 1);
+  else if (b.spec.kernel == 3) MKWS_DW(3, 2);
+  else if (b.spec.stride == 1) MKWS_DW(5, 1);
+  else MKWS_DW(5, 2);
+#undef MKWS_DW
+}
+
+// Fused expand + depthwise (mbconv_front_kernel): geometry per layer.
+bool front_supported(const BlockPlan& b) {
+  const int ks = b.spec.kernel, st = b.spec.stride, kc = (b.spec.in_ch + 15) / 16;
+  const int HW = b.H * b.W;
+  if (HW > 16) {
+    if ((size_t)HW * 36 * 4 > 76 * 1024) return false;
+    return (ks == 3 && st == 2 && kc == 1) || (ks == 3 && st == 1 && kc == 2) || (ks == 5 && st == 2 && kc == 2) ||
+           (ks == 5 && st == 1 && kc == 3) || (ks == 3 && st == 2 && kc == 3);
+  }
+  if (b.H == 4 && b.W == 3) return (ks == 3 && st == 1) || (ks == 5 && st == 1) || (ks == 5 && st == 2);
+  if (b.H == 2 && b.W == 2) return (ks == 5 && st == 1) || (ks == 3 && st == 1);
+  return false;
+}
+
+void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
+  FrontArgs a;
+  a.X = X; a.Cin = b.spec.in_ch; a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KC = b.expand.KC;
+  a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift; a.Y = Y; a.sums = sums;
+  a.B = B; a.H = b.H; a.W = b.W; a.Ho = b.Ho; a.Wo = b.Wo; a.pt = b.pt; a.pl = b.pl; a.Cexp = b.ce;
+  const int HW = b.H * b.W;
+  const bool tiny = HW <= 16;
+  int CC, G;
+  if (tiny) {                       // 4x3 and 2x2 images: wide channel chunks, 128 LDS rows per block
+    CC = 128;
+    G = 128 / HW;
+  } else {                          // big images: 32 channels, as many clips as give ~256 rows / <= 44 KB
+    CC = 32;
+    G = 256 / HW; if (G < 1) G = 1; if (G > 8) G = 8;
+    while (G > 1 && (size_t)G * HW * (CC + 4) * 4 > 44 * 1024) --G;
+  }
+  if (G > B) G = B;
+  a.G = G;
+  const size_t lds = ((size_t)G * HW * (CC + 4) + 256 * 4) * sizeof(float);
+  const dim3 grid((B + G - 1) / G, (b.ce + CC - 1) / CC);
+  const int ks = b.spec.kernel, st = b.spec.stride, kc = b.expand.KC;
+  ProfScope ps(stage, std::string("mbconv_front_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(CC) + "," +
+                          (tiny ? "0," + std::to_string(b.H) + "," + std::to_string(b.W) : std::to_string(kc) + ",0,0") + ">");
+#define MKWS_FRONT(KS, S, C_, KC_, H_, W_) \
+  hipLaunchKernelGGL((mbconv_front_kernel<KS, S, C_, KC_, H_, W_>), grid, dim3((KC_) > 0 ? 256 : 512), lds, s, a)
+  if (!tiny) {
+    if (ks == 3 && st == 2 && kc == 1) MKWS_FRONT(3, 2, 32, 1, 0, 0);        // 2a
+    else if (ks == 3 && st == 1 && kc == 2) MKWS_FRONT(3, 1, 32, 2, 0, 0);   // 2b
+    else if (ks == 5 && st == 2 && kc == 2) MKWS_FRONT(5, 2, 32, 2, 0, 0);   // 3a
+    else if (ks == 5 && st == 1 && kc == 3) MKWS_FRONT(5, 1, 32, 3, 0, 0);   // 3b
+    else if (ks == 3 && st == 2 && kc == 3) MKWS_FRONT(3, 2, 32, 3, 0, 0);   // 4a
+  } else if (b.H == 4 && b.W == 3) {
+    if (ks == 3 && st == 1) MKWS_FRONT(3, 1, 128, 0, 4, 3);                  // 4b, 4c
+    else if (ks == 5 && st == 1) MKWS_FRONT(5, 1, 128, 0, 4, 3);             // 5a, 5b, 5c
+    else if (ks == 5 && st == 2) MKWS_FRONT(5, 2, 128, 0, 4, 3);             // 6a
+  } else if (b.H == 2 && b.W == 2) {
+    if (ks == 5 && st == 1) MKWS_FRONT(5, 1, 128, 0, 2, 2);                  // 6b, 6c, 6d
+    else if (ks == 3 && st == 1) MKWS_FRONT(3, 1, 128, 0, 2, 2);             // 7a
+  }
+#undef MKWS_FRONT
+}
+
+void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B) {
+  const SeLayer& L = b.se;
+  int nsl = L.KCr / 4; if (nsl < 1) nsl = 1; if (nsl > 8) nsl = 8;       // K slices of the reduce FC
+  int nsp = L.NTe / 4; if (nsp < 1) nsp = 1; if (nsp > 8) nsp = 8;       // column slices of the expand FC
+  const int nb = (B + 15) / 16;
+  const float inv = 1.0f / (float)(b.Ho * b.Wo);
+#define MKWS_SE(N)                                                                                                            \
+  do {                                                                                                                        \
+    {                                                                                                                         \
+      ProfScope ps(std::string(stage) + "#reduce", std::string("se_reduce_kernel<") + std::to_string(N) + ">");             \
+      hipLaunchKernelGGL((se_reduce_kernel<N>), dim3(nb, nsl), dim3(256), 0, s, sums, inv, L.WrP, part, B, b.ce, L.KCr, nsl);  \
+    }                                                                                                                         \
+    {                                                                                                                         \
+      ProfScope ps(stage, std::string("se_expand_kernel<") + std::to_string(N) + ">");                                      \
+      hipLaunchKernelGGL((se_expand_kernel<N>), dim3(nb, nsp), dim3(256), 0, s, part, nsl, L.br, L.WeP, L.be, gate, B, b.ce, \
+                         L.se, L.NTe, nsp);                                                                                  \
+    }                                                                                                                         \
+  } while (0)
+  switch (L.NTR) {
+    case 1: MKWS_SE(1); break;
+    case 2: MKWS_SE(2); break;
+    default: MKWS_SE(3); break;
+  }
+#undef MKWS_SE
+}
+
 // Runs the network; stops after `stop` (nullptr = run everything).  On stop, *tap_src/*tap_count describe
 // the buffer holding that stage's output.
 int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStream_t s, const char* stop,
@@ -918,8 +1017,11 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       if (hit(p + "_expand", em->bufE, (size_t)Min * b.ce)) return MKWS_OK;
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
-    } else if (b.has_expand) {
+    } else if (b.has_expand && front_supported(b)) {
       launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
+    } else if (b.has_expand) {
+      launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
+      launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else {
       launch_dw(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
     }
