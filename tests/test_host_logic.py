@@ -104,6 +104,8 @@ def test_synthetic_clip_generator_is_pinned():
 
 def test_stage_costs_match_survey_totals():
     c = arch.stage_costs(1)
-    assert sum(f for f, _ in c.values()) - c["gap"][0] == 2 * 32974496
+    assert sum(f for k, (f, _) in c.items() if not k.endswith("_front")) - c["gap"][0] == 2 * 32974496
+    assert c["block2a_front"][0] == c["block2a_expand"][0] + c["block2a_dw"][0]        # fused launch = both stages' flops
+    assert c["block2a_front"][1] < c["block2a_expand"][1]                               # ...without the expanded tensor's bytes
     assert arch.FRONTEND_BYTES_PER_CLIP_F32 == 71840
     assert c["block2a_expand"][0] == 2 * 768000 and c["block7a"][0] == 2 * 1474560
