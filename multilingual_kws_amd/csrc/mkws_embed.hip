@@ -21,6 +21,7 @@
 #include "mkws_embed_arch.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ spe
 
 // ------------------------------------------------------------------------------------------------
 // 1x1 conv / dense GEMM.  Y[m, n] = act((sum_k X[m,k] * gate[m/HW, k] * W[k,n]) * scale[n] + shift[n]) + R[m,n]
-// Packed weights: Wp[((nt*KC + j)*4 + g)*64 + c*4 + s] = W[16j + 4g + s][16nt + c]  (zero padded).
+// Packed weights (chunk-major): Wp[((j*NTtot + nt)*4 + g)*64 + c*4 + s] = W[16j + 4g + s][16nt + c], zero
+// padded -- the NT tiles a wave needs for one K chunk are contiguous, consecutive n-blocks read consecutive
+// KBs (no power-of-two strides that would alias onto one L2 channel).
 // Block = 4 waves; wave w owns MT row tiles (16 rows each) starting at blockIdx.x*64*MT + 16*MT*w and NT
 // n-tiles starting at blockIdx.y*NT.  (MT, NT) is picked per layer so that small-M layers still put several
 // waves on every SIMD (launch_gemm).
@@ -110,6 +113,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   const int nt0 = blockIdx.y * NT;
   if (m0 >= a.M) return;
 
+  // Operand pointers are CLAMPED instead of predicated (rows past M re-read row M-1, tiles past NTtot
+  // re-read the last tile; their results are never stored), so the K loop has no per-load branches.
+  // Only the K tail (K % 16 == 8: lane groups 2,3 of the last chunk) needs a zero, done by a select.
   const float* xrow[MT];
   const float* grow[MT];
   bool rowok[MT];
@@ -121,7 +127,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
     xrow[mt] = a.X + (size_t)mm * a.ldx + 4 * g;
     grow[mt] = GATE ? (a.gate + (size_t)(mm / a.HW) * a.K + 4 * g) : nullptr;
   }
-  const float* wbase = a.Wp + ((size_t)nt0 * a.KC * 4 + g) * 64 + c * 4;
+  const float* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int t = (nt0 + nt < a.NTtot) ? nt0 + nt : a.NTtot - 1;
+    wrow[nt] = a.Wp + ((size_t)t * 4 + g) * 64 + c * 4;
+  }
   // K range of this block (split-K over blockIdx.z)
   int jbeg = 0, jend = a.KC;
   if (a.splitk > 1) {
@@ -129,6 +140,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
     jbeg = blockIdx.z * per;
     jend = (jbeg + per < a.KC) ? jbeg + per : a.KC;
   }
+  // K tail (K % 16 == 8, only the unfused expand convs with Cin = 24 / 40): the last chunk's lane groups
+  // 2,3 have no X columns.  It is peeled off the pipelined loop so the steady state stays branch-free.
+  const bool ktail = (a.K & 15) != 0;          // uniform
+  const int jpipe_end = (ktail && jend == a.KC) ? jend - 1 : jend;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -136,46 +151,67 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // D-deep register ring over the K chunks: slot d is refilled with chunk j+D right after chunk j's MFMAs
-  // were issued, so D chunk loads are always in flight (small-tile configs are load-latency bound).
+  // D-deep register ring over the K chunks.  Shape matters for hipcc's s_waitcnt placement: with
+  // conditional reloads inside the loop it falls back to vmcnt(0) at the loop head (measured: the ring
+  // degenerated to depth 1).  So: unconditional prologue, a steady-state loop in which every slot does
+  // exactly "MFMAs, then reload" (the compiler then emits counted vmcnt(N) and D-1 chunks stay in flight),
+  // and a drain.
   constexpr int D = (MT * NT >= 10) ? 3 : 4;
   f32x4 xq[D][MT], wq[D][NT];
   auto load = [&](int j, f32x4 (&xv)[MT], f32x4 (&wv)[NT]) {
-    const bool kok = (16 * j + 4 * g) < a.K;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kok && rowok[mt]) {
-        v = *reinterpret_cast<const f32x4*>(xrow[mt] + 16 * j);
-        if (GATE) v *= *reinterpret_cast<const f32x4*>(grow[mt] + 16 * j);
-      }
+      f32x4 v = *reinterpret_cast<const f32x4*>(xrow[mt] + 16 * j);
+      if (GATE) v *= *reinterpret_cast<const f32x4*>(grow[mt] + 16 * j);
       xv[mt] = v;
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (nt0 + nt < a.NTtot) v = *reinterpret_cast<const f32x4*>(wbase + ((size_t)nt * a.KC + j) * 256);
-      wv[nt] = v;
-    }
+    for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const f32x4*>(wrow[nt] + (size_t)j * a.NTtot * 256);
   };
+  auto compute = [&](const f32x4 (&xv)[MT], const f32x4 (&wv)[NT]) {
 #pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (jbeg + d < jend) load(jbeg + d, xq[d], wq[d]);
-  for (int j0 = jbeg; j0 < jend; j0 += D) {
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int j = j0 + d;
-      if (j < jend) {
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][s], xv[mt][s], acc[mt][nt], 0, 0, 0);
+  };
+  const int n = jpipe_end - jbeg;
+  if (n >= D) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
+    for (int d = 0; d < D; ++d) load(jbeg + d, xq[d], wq[d]);
+    int j = jbeg;
+    for (; j + 2 * D <= jpipe_end; j += D) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d][nt][s], xq[d][mt][s], acc[mt][nt], 0, 0, 0);
-        if (j + D < jend) load(j + D, xq[d], wq[d]);
+      for (int d = 0; d < D; ++d) {
+        compute(xq[d], wq[d]);
+        load(j + D + d, xq[d], wq[d]);
       }
     }
+    // here D <= jpipe_end - j < 2D: one more group with partial reloads, then the drain
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      compute(xq[d], wq[d]);
+      if (j + D + d < jpipe_end) load(j + D + d, xq[d], wq[d]);
+    }
+    j += D;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (j + d < jpipe_end) compute(xq[d], wq[d]);
+  } else {
+    for (int j = jbeg; j < jpipe_end; ++j) {
+      load(j, xq[0], wq[0]);
+      compute(xq[0], wq[0]);
+    }
+  }
+  if (jpipe_end != jend) {        // peeled K-tail chunk
+    load(jend - 1, xq[0], wq[0]);
+    if (g >= 2) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xq[0][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    compute(xq[0], wq[0]);
   }
   if (a.splitk > 1) {     // raw partial sums; epilogue happens in splitk_reduce_kernel
     float* P = a.part + (size_t)blockIdx.z * a.M * a.ldp;
@@ -294,7 +330,7 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X, co
 //            walks all output pixels itself and owns its SE sums.
 struct FrontArgs {
   const float* X; int Cin;
-  const float* WpE; const float* scE; const float* shE; int KC;
+  const float* WpE; const float* scE; const float* shE; int KC; int NTtotE;
   const float* Wd; const float* scD; const float* shD;
   float* Y; float* sums;
   int B, H, W, Ho, Wo, pt, pl, Cexp, G;
@@ -328,7 +364,8 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   //   tiny images (many K chunks, CC = 128): each weight fragment feeds MT = 2 row tiles.
   {
     const float* Xb = a.X + (size_t)b0 * HW * a.Cin;
-    const float* wbase = a.WpE + ((size_t)(ch0 / 16) * a.KC * 4 + g) * 64 + c * 4;
+    const float* wbase = a.WpE + ((size_t)(ch0 / 16) * 4 + g) * 64 + c * 4;     // + (j*NTtotE + nt)*256
+    const size_t wchunk = (size_t)a.NTtotE * 256;
     const int ntiles = (rows + 15) / 16;
     auto epilogue = [&](int row, const f32x4 (&acc)[NT]) {
       if (row < rows) {
@@ -351,7 +388,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
       for (int j = 0; j < MAXKC; ++j)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          wreg[j][nt] = (j < a.KC && nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + ((size_t)nt * a.KC + j) * 256)
+          wreg[j][nt] = (j < a.KC && nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + (size_t)j * wchunk + nt * 256)
                                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
       // row tiles of this wave: wave, wave+4, ...; X fragments of D tiles in flight
       constexpr int D = 4;
@@ -407,7 +444,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #pragma unroll
           for (int q = 0; q < NTW; ++q) {
             const int nt = nhalf * NTW + q;
-            wv[q] = (nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + ((size_t)nt * a.KC + j) * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            wv[q] = (nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + (size_t)j * wchunk + nt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         };
 #pragma unroll
@@ -589,7 +626,7 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict_
       const bool ok = j < j1;
 #pragma unroll
       for (int nt = 0; nt < NTR; ++nt)
-        wv[u][nt] = ok ? *reinterpret_cast<const f32x4*>(wbase + ((size_t)nt * KCr + j) * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        wv[u][nt] = ok ? *reinterpret_cast<const f32x4*>(wbase + ((size_t)j * NTR + nt) * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
       xb[u] = (ok && clip_ok && 16 * j + 4 * g < C) ? *reinterpret_cast<const f32x4*>(srow + 16 * j) * inv_hw : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -643,7 +680,7 @@ __global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict_
       const bool ok = t < t1;
 #pragma unroll
       for (int jj = 0; jj < NTR; ++jj)
-        wv[u][jj] = ok ? *reinterpret_cast<const f32x4*>(WeP + (((size_t)t * NTR + jj) * 4 + g) * 64 + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        wv[u][jj] = ok ? *reinterpret_cast<const f32x4*>(WeP + (((size_t)jj * NTe + t) * 4 + g) * 64 + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
       bias[u] = (ok && t * 16 + 4 * g < C) ? *reinterpret_cast<const f32x4*>(be + t * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -781,7 +818,7 @@ GemmOff pack_gemm(Packer& pk, const float* W, int K, int N, const std::vector<fl
         for (int c = 0; c < 16; ++c)
           for (int s = 0; s < 4; ++s) {
             const int k = 16 * j + 4 * g + s, col = 16 * nt + c;
-            dst[(((size_t)nt * o.KC + j) * 4 + g) * 64 + c * 4 + s] = (k < K && col < N) ? W[(size_t)k * N + col] : 0.0f;
+            dst[(((size_t)j * o.NTtot + nt) * 4 + g) * 64 + c * 4 + s] = (k < K && col < N) ? W[(size_t)k * N + col] : 0.0f;
           }
   const int Np = o.NTtot * 16;
   std::vector<float> sc(Np, 0.0f), sh(Np, 0.0f);
@@ -826,48 +863,34 @@ void launch_gemm_nt(int NT, dim3 grid, hipStream_t s, const GemmArgs& a) {
   }
 }
 
-// Tile / split-K choice.  Per K chunk a wave loads (MT+NT) KB for MT*NT*4 MFMAs, so big tiles mean little
-// L1/L2 operand traffic (B/clk/CU ~ 32*(MT+NT)/(MT*NT): 48 for 1x2, 32 for 2x2, 21 for 2x6), but small-M
-// layers then leave SIMDs idle.  Policy: among configs with >= kWantWaves waves take the least operand
-// traffic (then least N padding); if none gets there, split K (long-K layers only) and otherwise take the
-// config with the most waves.
+// Tile / split-K choice, from a sweep on MI355X (profiles/r01_gemm_sweep.txt): no (MT,NT) gets past ~60 % of
+// the fp32 MFMA peak with operands fetched straight into registers, and what matters most is having >= 2
+// waves per SIMD.  NT = 3, 5, 6 tiles were consistently slower than 2 / 4.  Rule:
+//   wide, long-K layers with few rows (the dense layers): 2x4 tiles if that still gives 1 wave per SIMD;
+//   otherwise NT = 2, MT = 2 if that reaches kWantWaves, else MT = 1, else split K (2, then 4).
 constexpr int kWantWaves = 2048;
 struct TileChoice { int MT, NT, splitk; };
 TileChoice pick_tile(int M, int NTtot, int KC) {
-  TileChoice best = {1, NTtot < 2 ? 1 : 2, 1};
-  double best_cost = 1e30;
-  long best_waves = -1;
-  bool found = false;
-  for (int sk = 1; sk <= 4; sk *= 2) {
-    if (sk > 1 && KC / sk < 16) break;               // keep >= 16 chunks per slice
-    for (int mt = 2; mt >= 1; --mt) {
-      for (int nt = 6; nt >= 1; --nt) {
-        if (nt > NTtot || (nt == 1 && NTtot > 1)) continue;
-        const long nblk = (NTtot + nt - 1) / nt;
-        const long waves = ((M + 16 * mt - 1) / (16 * mt)) * nblk * sk;
-        const double traffic = (double)(mt + nt) / (mt * nt) * (mt == 1 ? 1.5 : 1.0);   // MT = 1 tiles are vector-L1 bound
-        const double pad = (double)(nblk * nt) / NTtot;
-        const double cost = traffic * pad * (sk == 1 ? 1.0 : (sk == 2 ? 1.15 : 1.3));
-        if (waves >= kWantWaves) {
-          if (!found || cost < best_cost - 1e-9) { found = true; best_cost = cost; best = {mt, nt, sk}; }
-        } else if (!found && sk == 1 && waves > best_waves) {
-          best_waves = waves; best = {mt, nt, 1};
-        }
-      }
-    }
-  }
-  return best;
+  if (NTtot == 1) return {2, 1, 1};
+  auto waves = [&](int mt, int nt, int sk) { return (long)((M + 16 * mt - 1) / (16 * mt)) * ((NTtot + nt - 1) / nt) * sk; };
+  if (NTtot >= 64 && KC >= 64 && waves(2, 4, 1) >= 1024) return {2, 4, 1};
+  if (waves(2, 2, 1) >= kWantWaves) return {2, 2, 1};
+  if (waves(1, 2, 1) >= kWantWaves) return {1, 2, 1};
+  if (KC >= 32 && waves(1, 2, 2) >= kWantWaves) return {1, 2, 2};
+  if (KC >= 64) return {1, 2, 4};
+  return {1, 2, 1};
 }
 
-// Mplan = the row count this layer has at the handle's max_batch: tile and split-K choices are made for
-// THAT size, so a handle computes every clip with the same summation order whatever the batch it arrives
-// in (bit-identical results across batch sizes and batch compositions).
 void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const float* X, int ldx, int M, int Mplan, int act, const float* gate, int HW,
                  const float* R, int ldr, float* Y, int ldy) {
   GemmArgs a;
   a.X = X; a.ldx = ldx; a.Wp = L.Wp; a.scale = L.scale; a.shift = L.shift; a.gate = gate; a.HW = HW > 0 ? HW : 1;
   a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy; a.M = M; a.K = L.K; a.N = L.N; a.KC = L.KC; a.NTtot = L.NTtot; a.act = act;
-  const TileChoice tc = pick_tile(Mplan, L.NTtot, L.KC);
+  TileChoice tc = pick_tile(Mplan, L.NTtot, L.KC);
+  if (const char* f = getenv("MKWS_GEMM_FORCE")) {       // experiment hook: "Mmax,MT,NT,SK" applies to layers with Mplan <= Mmax
+    int mmax = 0, fmt = 0, fnt = 0, fsk = 0;
+    if (sscanf(f, "%d,%d,%d,%d", &mmax, &fmt, &fnt, &fsk) == 4 && Mplan <= mmax && fnt <= L.NTtot) tc = {fmt, fnt, fsk};
+  }
   const int MT = tc.MT, NT = tc.NT;
   a.splitk = tc.splitk; a.part = nullptr; a.ldp = L.NTtot * 16;
   if (tc.splitk > 1) {
@@ -922,6 +945,7 @@ bool front_supported(const BlockPlan& b) {
 void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
   FrontArgs a;
   a.X = X; a.Cin = b.spec.in_ch; a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KC = b.expand.KC;
+  a.NTtotE = b.expand.NTtot;
   a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift; a.Y = Y; a.sums = sums;
   a.B = B; a.H = b.H; a.W = b.W; a.Ho = b.Ho; a.Wo = b.Wo; a.pt = b.pt; a.pl = b.pl; a.Cexp = b.ce;
   const int HW = b.H * b.W;
