@@ -164,7 +164,12 @@ def main():
             if stage.endswith("#reduce"):
                 cost = (0.0, 0.0)          # helper launch (split-K / SE partial): its work is booked on the main stage
             else:
-                cost = costs[stage.replace("_dw", "_front")] if kernel.startswith("mbconv_front") else costs[stage]
+                if kernel.startswith("mbconv_front"):
+                    cost = costs[stage.replace("_dw", "_front")]
+                elif kernel.startswith("mbconv_block"):
+                    cost = costs[stage + "_block"]
+                else:
+                    cost = costs[stage]
             k["flops"] += cost[0]
             k["bytes"] += cost[1]
         dom_name = max(per_kernel, key=lambda n: per_kernel[n]["ms"])
@@ -179,7 +184,7 @@ def main():
                 traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        if dom_name.startswith("pw_gemm") and t_flops >= t_bytes:
+        if t_flops >= t_bytes:
             ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic}

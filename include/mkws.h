@@ -144,7 +144,10 @@ void mkws_embed_destroy(mkws_embed* em);
 int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, void* stream);
 /* Execution options (A/B switches for measurement; results are equal up to fp32 rounding):
  *   "fuse_front" (default 1): expand 1x1 conv + depthwise conv in one kernel (expanded tensor stays in LDS);
- *                 0 = separate GEMM and depthwise kernels. */
+ *                 0 = separate GEMM and depthwise kernels.
+ *   "fuse_block" (default 1): blocks with 2x2 images (6b..7a) run expand -> depthwise -> SE -> project as ONE
+ *                 kernel with the activations resident in LDS; 2 = also the 4x3 blocks (4b..6a; slower on
+ *                 MI355X, kept for A/B); 0 = the multi-kernel path everywhere. */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
 
 /* Measurement aid (NOT capturable: it records a hipEvent pair around every kernel launch and

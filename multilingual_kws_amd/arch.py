@@ -42,6 +42,10 @@ def stage_costs(B):
             c[p + "_front"] = (c[p + "_expand"][0] + c[p + "_dw"][0],
                                4 * (m_in * cin + cin * ce + m_out * ce + k * k * ce + B * ce))
         c[p + "_gate"] = (2 * B * 2 * ce * se, 4 * (2 * B * ce + 2 * ce * se))
+        if e != 1:   # whole-block launch (tiny images): block input + output + every weight of the block, once
+            wbytes = cin * ce + k * k * ce + 2 * ce * se + ce * cout
+            c[p + "_block"] = (2 * (m_in * cin * ce + m_out * k * k * ce + B * 2 * ce * se + m_out * ce * cout),
+                               4 * (m_in * cin + m_out * cout + (m_out * cout if (s == 1 and cin == cout) else 0) + wbytes))
         res = m_out * cout if (s == 1 and cin == cout) else 0
         c[p] = (2 * m_out * ce * cout, 4 * (m_out * ce + B * ce + m_out * cout + res + ce * cout))
     m = B * h * w

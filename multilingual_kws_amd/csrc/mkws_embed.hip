@@ -593,6 +593,282 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole-MBConv kernel for the tiny-image blocks (4x3 and 2x2 inputs: blocks 4b..7a).
+// One workgroup owns one 16-row MFMA tile of activations (4 clips of 2x2, or 1 clip of 4x3) and carries it
+// through expand -> depthwise -> SE -> gated project entirely in LDS; every weight of the block streams
+// through the workgroup exactly once as MFMA A-operand fragments, the activations are the B operand read
+// from LDS.  Nothing but the block input and output touches HBM, and there is one launch per block.
+//   phase A  E[16, Cexp]   = swish(BN(X[16, Cin] . We))                     (waves split the Cexp/16 tiles)
+//   phase B  E <- swish(BN(depthwise(E))) in place, S[clip, Cexp] = sum over pixels   (thread = clip x quad)
+//   phase C  r = swish(S/HW . Wr + br);  gate = sigmoid(r . We2 + be)       (K split over waves / tiles over waves)
+//   phase D  Y[16, Cout]   = BN((E * gate) . Wp) (+ X)                      (waves split the Cout/16 tiles)
+struct BlockArgs {
+  const float* X; int Cin;
+  const float* WpE; const float* scE; const float* shE; int KCe; int NTe;
+  const float* Wd; const float* scD; const float* shD;
+  const float* WrP; const float* br; int NTR;
+  const float* We2P; const float* be;
+  const float* WpP; const float* scP; const float* shP; int NTp;
+  float* Y; int Cout; int residual;
+  float* dbg_dw; float* dbg_gate;
+  int B, Cexp, se;
+};
+
+// acc[q] += sum_j W(j, tile0 + tstride*q) . xfrag(j) for j in [0, KC): weight fragments via a DEPTH-deep
+// register ring (prologue / branch-free steady state / drain, so hipcc emits counted vmcnt waits).
+template <int NTW, int DEPTH, typename XF>
+__device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW], const float* __restrict__ wlane, size_t chunk_stride, int tile0, int tstride,
+                                            int ntiles, int KC, XF xfrag) {
+  const float* wp[NTW];
+#pragma unroll
+  for (int q = 0; q < NTW; ++q) {
+    int t = tile0 + tstride * q;
+    if (t >= ntiles) t = ntiles - 1;             // clamped: result unused
+    wp[q] = wlane + (size_t)t * 256;
+  }
+  f32x4 wq[DEPTH][NTW];
+  auto load = [&](int j, f32x4 (&wv)[NTW]) {
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wp[q] + (size_t)j * chunk_stride);
+  };
+  auto compute = [&](int j, const f32x4 (&wv)[NTW]) {
+    const f32x4 x = xfrag(j);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[s], acc[q], 0, 0, 0);
+  };
+  if (KC >= DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load(d, wq[d]);
+    int j = 0;
+    for (; j + 2 * DEPTH <= KC; j += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        compute(j + d, wq[d]);
+        load(j + DEPTH + d, wq[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      compute(j + d, wq[d]);
+      if (j + DEPTH + d < KC) load(j + DEPTH + d, wq[d]);
+    }
+    j += DEPTH;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (j + d < KC) compute(j + d, wq[d]);
+  } else {
+    for (int j = 0; j < KC; ++j) {
+      load(j, wq[0]);
+      compute(j, wq[0]);
+    }
+  }
+}
+
+template <int KS, int S, int HT, int WT>
+__global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_blk[];
+  constexpr int HW = HT * WT;
+  constexpr int G = 16 / HW;                                   // clips per workgroup (4 for 2x2, 1 for 4x3)
+  constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1);
+  constexpr int HoWo = HoT * WoT;
+  constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+  const int Cexp = a.Cexp, LDE = Cexp + 4;
+  const int KCx = Cexp / 16;                                   // K chunks of the SE-reduce and project GEMMs
+  constexpr int LDR = 52;                                      // r rows: up to 48 SE units + pad
+  float* s_X = s_blk;                                          // [KCe][64][4]   block input as B-operand fragments
+  float* s_E = s_X + (size_t)a.KCe * 256;                      // [16][LDE]
+  float* s_S = s_E + 16 * LDE;                                 // [G][Cexp]  SE means
+  float* s_G = s_S + G * Cexp;                                 // [G][Cexp]  SE gate
+  float* s_P = s_G + G * Cexp;                                 // [4 waves][48][16] SE-reduce partials
+  float* s_R = s_P + 4 * 48 * 16;                              // [16][LDR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * G;
+  const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
+  const int rows_in = gvalid * HW, rows_out = gvalid * HoWo;
+  const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
+
+  // ---- stage the input tile as fragments: s_X[j][lane] = X[row = c][16j + 4g .. +3] ----
+  for (int j = wave; j < a.KCe; j += 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < rows_in && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
+    *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = v;
+  }
+  __syncthreads();
+
+  // ---- phase A: expand ----
+  {
+    const float* wlane = a.WpE + (size_t)g * 64 + c * 4;
+    const size_t cstride = (size_t)a.NTe * 256;
+    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)j * 64 + lane) * 4); };
+    constexpr int NTW = 2;
+    for (int t0 = wave * NTW; t0 < a.NTe; t0 += 4 * NTW) {
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      stream_mfma<NTW, 4>(acc, wlane, cstride, t0, 1, a.NTe, a.KCe, xfrag);
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < a.NTe) {
+          f32x4 y = acc[q] * *reinterpret_cast<const f32x4*>(a.scE + n) + *reinterpret_cast<const f32x4*>(a.shE + n);
+          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+          if (c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(s_E + (size_t)c * LDE + n) = y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: depthwise in place + SE sums ----
+  {
+    const int Q = Cexp / 4;
+    for (int task = tid; task < G * Q; task += 256) {
+      const int gi = task / Q, q4 = (task - gi * Q) * 4;
+      float* Eg = s_E + (size_t)gi * HW * LDE + q4;
+      f32x4 ein[HW];
+#pragma unroll
+      for (int pix = 0; pix < HW; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(Eg + (size_t)pix * LDE);
+      f32x4 acc[HoWo];
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) {
+          bool used = false;
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+            }
+          if (!used) continue;
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + q4);
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv;
+            }
+        }
+      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + q4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + q4);
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+      float* Eo = s_E + (size_t)gi * HoWo * LDE + q4;        // output rows: clip gi's HoWo pixels (== input rows when S == 1)
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) {
+        f32x4 y = acc[o] * sc + sh;
+        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+        if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Eo + (size_t)o * LDE) = y;
+        ssum += y;
+        if (a.dbg_dw && gi < gvalid) *reinterpret_cast<f32x4*>(a.dbg_dw + (row0_out + gi * HoWo + o) * Cexp + q4) = y;
+      }
+      *reinterpret_cast<f32x4*>(s_S + (size_t)gi * Cexp + q4) = ssum * (1.0f / (float)HoWo);
+    }
+  }
+  __syncthreads();
+  // rows [rows_out, 16) of E must read as zero in phase D (stride-2 block: rows HoWo..HW-1 still hold phase-A data)
+  if (S != 1) {
+    for (int i = tid; i < (16 - G * HoWo) * (Cexp / 4); i += 256) {
+      const int r = G * HoWo + i / (Cexp / 4), q4 = (i % (Cexp / 4)) * 4;
+      *reinterpret_cast<f32x4*>(s_E + (size_t)r * LDE + q4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // ---- phase C1: r^T[se, clips] = Wr^T . mean^T, K = Cexp split over the 4 waves ----
+  {
+    const float* wlane = a.WrP + (size_t)g * 64 + c * 4;
+    const size_t cstride = (size_t)a.NTR * 256;
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int per = (KCx + 3) / 4;
+    const int j0 = wave * per;
+    const int kc = (j0 + per <= KCx) ? per : (KCx > j0 ? KCx - j0 : 0);
+    auto xfrag = [&](int j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < G) v = *reinterpret_cast<const f32x4*>(s_S + (size_t)c * Cexp + 16 * (j0 + j) + 4 * g);
+      return v;
+    };
+    if (kc > 0) stream_mfma<3, 3>(acc, wlane + (size_t)j0 * cstride, cstride, 0, 1, a.NTR, kc, xfrag);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * 16 + c] = acc[q][r];
+  }
+  __syncthreads();
+  for (int t = tid; t < 48 * 16; t += 256) {
+    const int n = t >> 4, clip = t & 15;
+    float v = 0.0f;
+    if (n < a.se && clip < G) {
+      v = (s_P[(0 * 48 + n) * 16 + clip] + s_P[(1 * 48 + n) * 16 + clip]) + (s_P[(2 * 48 + n) * 16 + clip] + s_P[(3 * 48 + n) * 16 + clip]);
+      v = swishf_(v + a.br[n]);
+    }
+    s_R[clip * LDR + n] = v;
+  }
+  __syncthreads();
+  // ---- phase C2: gate^T[Cexp, clips] = We2^T . r^T, tiles over waves ----
+  {
+    const float* wlane = a.We2P + (size_t)g * 64 + c * 4;
+    const size_t cstride = (size_t)KCx * 256;                 // We2 packed with N = Cexp -> NTtot = Cexp/16
+    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_R + c * LDR + 16 * j + 4 * g); };
+    constexpr int NTW = 3;
+    for (int t0 = wave * NTW; t0 < KCx; t0 += 4 * NTW) {
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      stream_mfma<NTW, 3>(acc, wlane, cstride, t0, 1, KCx, a.NTR, xfrag);
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < KCx && c < G) {
+          f32x4 y = acc[q] + *reinterpret_cast<const f32x4*>(a.be + n);
+          y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
+          *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
+          if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + n) = y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase D: gated project (+ residual) ----
+  {
+    const float* wlane = a.WpP + (size_t)g * 64 + c * 4;
+    const size_t cstride = (size_t)a.NTp * 256;
+    const int clip = (c < rows_out) ? c / HoWo : 0;
+    const float* erow = s_E + (size_t)c * LDE + 4 * g;
+    const float* grow = s_G + (size_t)clip * Cexp + 4 * g;
+    auto xfrag = [&](int j) {
+      return *reinterpret_cast<const f32x4*>(erow + 16 * j) * *reinterpret_cast<const f32x4*>(grow + 16 * j);
+    };
+    constexpr int NTW = 5;                                     // Cout/16 <= 20 tiles -> <= 5 per wave
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stream_mfma<NTW, 3>(acc, wlane, cstride, wave, 4, a.NTp, KCx, xfrag);
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+      const int t = wave + 4 * q;
+      const int n = t * 16 + 4 * g;
+      if (t < a.NTp && c < rows_out) {
+        f32x4 y = acc[q] * *reinterpret_cast<const f32x4*>(a.scP + n) + *reinterpret_cast<const f32x4*>(a.shP + n);
+        if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + n);
+        *reinterpret_cast<f32x4*>(a.Y + (row0_out + c) * a.Cout + n) = y;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // SE: mean = sums/HW; r = swish(mean @ Wr + br); gate = sigmoid(r @ We + be).
 // Both FCs run on the fp32 MFMA as (weights x 16 clips) tiles with pack_gemm-packed weights, and both are
 // spread over the whole chip (a single block per 16 clips would stream up to 442 KB of SE weights through
@@ -755,6 +1031,7 @@ struct mkws_embed {
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
+  int fuse_block = 1;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images, 2 = also 4x3
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
   int topH = 0, topW = 0;
@@ -985,6 +1262,44 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
 #undef MKWS_FRONT
 }
 
+// Whole-block kernel for 4x3 / 2x2 images (blocks 4b..7a).
+bool block_supported(const BlockPlan& b, int mode) {
+  const int ks = b.spec.kernel, st = b.spec.stride;
+  if (!b.has_expand || b.ce % 16 != 0 || b.spec.out_ch % 16 != 0 || b.spec.out_ch > 320 || b.se.NTR > 3) return false;
+  // 4x3 images are implemented (and tested through fuse_block = 2) but lose to the multi-kernel path on
+  // MI355X: one clip per workgroup re-streams the block's weights 1024 times (profiles/r01_notes.md).
+  if (b.H == 4 && b.W == 3) return mode >= 2 && ((ks == 3 && st == 1) || (ks == 5 && st == 1) || (ks == 5 && st == 2));
+  if (b.H == 2 && b.W == 2) return (ks == 5 && st == 1) || (ks == 3 && st == 1);
+  return false;
+}
+
+void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+  BlockArgs a;
+  a.X = X; a.Cin = b.spec.in_ch;
+  a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KCe = b.expand.KC; a.NTe = b.expand.NTtot;
+  a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift;
+  a.WrP = b.se.WrP; a.br = b.se.br; a.NTR = b.se.NTR; a.We2P = b.se.WeP; a.be = b.se.be;
+  a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift; a.NTp = b.project.NTtot;
+  a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
+  a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
+  a.B = B; a.Cexp = b.ce; a.se = b.se.se;
+  const int HW = b.H * b.W, G = 16 / HW;
+  const size_t lds = ((size_t)b.expand.KC * 256 + 16 * (b.ce + 4) + 2 * (size_t)G * b.ce + 4 * 48 * 16 + 16 * 52) * sizeof(float);
+  const dim3 grid((B + G - 1) / G);
+  const int ks = b.spec.kernel, st = b.spec.stride;
+  ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
+#define MKWS_BLOCK(KS, S, H_, W_) hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_>), grid, dim3(256), lds, s, a)
+  if (b.H == 4 && b.W == 3) {
+    if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3);
+    else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3);
+    else MKWS_BLOCK(5, 2, 4, 3);
+  } else {
+    if (ks == 5) MKWS_BLOCK(5, 1, 2, 2);
+    else MKWS_BLOCK(3, 1, 2, 2);
+  }
+#undef MKWS_BLOCK
+}
+
 void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B) {
   const SeLayer& L = b.se;
   int nsl = L.KCr / 4; if (nsl < 1) nsl = 1; if (nsl > 8) nsl = 8;       // K slices of the reduce FC
@@ -1036,6 +1351,16 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     const std::string p = std::string("block") + b.spec.name;
     const int Min = B * b.H * b.W, Mout = B * b.Ho * b.Wo;
     const bool want_expand_tap = stop && (p + "_expand") == stop;
+    if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
+      // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
+      const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
+      launch_block(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+      if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
+      if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
+      if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
+      float* t = cur; cur = nxt; nxt = t;
+      continue;
+    }
     if (b.has_expand && (want_expand_tap || !em->fuse_front)) {
       // unfused path: kept for the "<block>_expand" parity tap and as an A/B switch (mkws_embed_set_option)
       launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
@@ -1247,6 +1572,7 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (!em || !name) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
   if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
+  if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

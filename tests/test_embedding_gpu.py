@@ -47,6 +47,26 @@ def test_every_stage_matches_oracle(ctx):
     assert np.array_equal(ctx["em"].predict(spec[..., None]), emb)          # Keras-style numpy API, NHWC input
 
 
+def test_execution_options_agree(ctx):
+    """fuse_front / fuse_block are A/B switches: every combination must match the oracle."""
+    spec = _spec(np.random.default_rng(12), 9)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    ref = ctx["oracle"].forward(spec).numpy()
+    try:
+        for front, block in ((0, 0), (1, 0), (1, 2), (0, 2), (1, 1)):
+            ctx["em"].set_option("fuse_front", front)
+            ctx["em"].set_option("fuse_block", block)
+            assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block)
+            for name in ("block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a"):
+                taps = {}
+                ctx["oracle"].forward(spec[:3], taps)
+                got = ctx["em"].tap(x[:3], name).cpu().numpy().reshape(taps[name].shape)
+                assert _rel(got, taps[name]) < REL_TOL, (front, block, name)
+    finally:
+        ctx["em"].set_option("fuse_front", 1)
+        ctx["em"].set_option("fuse_block", 1)
+
+
 def test_golden_embedding_on_device(ctx, golden_dir):
     from multilingual_kws_amd import synth
     from multilingual_kws_amd.frontend import Frontend
