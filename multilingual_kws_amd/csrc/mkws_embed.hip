@@ -666,9 +666,76 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW], const float* __re
   }
 }
 
-template <int KS, int S, int HT, int WT>
-__global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
+// Flattened variant of stream_mfma for MANY short accumulation runs (phase A, SE expand): run r = tiles
+// [tile_of(r), +NTW), each KC chunks long.  The weight ring keeps DEPTH chunks in flight ACROSS runs, so a
+// run's first loads are already issued while the previous run computes (no per-run latency bubble).  The
+// epilogue must not issue global loads (they would drain the in-order vmcnt ring): constants come from LDS.
+template <int NTW, int DEPTH, typename XF, typename TOF, typename EPI>
+__device__ __forceinline__ void stream_mfma_runs(const float* __restrict__ wlane, size_t chunk_stride, int ntiles, int nruns, int KC,
+                                                 TOF tile_of, XF xfrag, EPI epilogue) {
+  const int T = nruns * KC;
+  if (T <= 0) return;
+  f32x4 wq[DEPTH][NTW];
+  int lr = 0, lj = 0;                                  // load cursor (run, chunk)
+  auto load = [&](f32x4 (&wv)[NTW]) {
+    const int t0 = tile_of(lr);
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+      int t = t0 + q;
+      if (t >= ntiles) t = ntiles - 1;
+      wv[q] = *reinterpret_cast<const f32x4*>(wlane + (size_t)t * 256 + (size_t)lj * chunk_stride);
+    }
+    if (++lj == KC) { lj = 0; ++lr; }
+  };
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int cr = 0, cj = 0;                                  // compute cursor
+  auto compute = [&](const f32x4 (&wv)[NTW]) {
+    const f32x4 x = xfrag(cj);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[s], acc[q], 0, 0, 0);
+    if (++cj == KC) {
+      epilogue(tile_of(cr), acc);
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cj = 0; ++cr;
+    }
+  };
+  if (T >= DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load(wq[d]);
+    int it = 0;
+    for (; it + 2 * DEPTH <= T; it += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        compute(wq[d]);
+        load(wq[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      compute(wq[d]);
+      if (it + DEPTH + d < T) load(wq[d]);
+    }
+    it += DEPTH;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (it + d < T) compute(wq[d]);
+  } else {
+    for (int it = 0; it < T; ++it) {
+      load(wq[0]);
+      compute(wq[0]);
+    }
+  }
+}
+
+template <int KS, int S, int HT, int WT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_blk[];
+  constexpr int NTHR = NWAVES * 64;
   constexpr int HW = HT * WT;
   constexpr int G = 16 / HW;                                   // clips per workgroup (4 for 2x2, 1 for 4x3)
   constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1);
@@ -680,9 +747,13 @@ __global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
   float* s_X = s_blk;                                          // [KCe][64][4]   block input as B-operand fragments
   float* s_E = s_X + (size_t)a.KCe * 256;                      // [16][LDE]
   float* s_S = s_E + 16 * LDE;                                 // [G][Cexp]  SE means
-  float* s_G = s_S + G * Cexp;                                 // [G][Cexp]  SE gate
-  float* s_P = s_G + G * Cexp;                                 // [4 waves][48][16] SE-reduce partials
-  float* s_R = s_P + 4 * 48 * 16;                              // [16][LDR]
+  float* s_G = s_S + G * Cexp;                                 // [G][Cexp]  SE gate  (phase C2 onwards)
+  float* s_P = s_G;                                            // [NWAVES][48][16] SE-reduce partials (phase C1 only: same space)
+  const int gp = (G * Cexp > NWAVES * 48 * 16) ? G * Cexp : NWAVES * 48 * 16;
+  float* s_R = s_G + gp;                                       // [16][LDR]
+  float* s_scE = s_R + 16 * LDR;                               // [Cexp] expand BN scale, shift; SE expand bias
+  float* s_shE = s_scE + Cexp;
+  float* s_be = s_shE + Cexp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * G;
@@ -690,43 +761,42 @@ __global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
   const int rows_in = gvalid * HW, rows_out = gvalid * HoWo;
   const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
 
-  // ---- stage the input tile as fragments: s_X[j][lane] = X[row = c][16j + 4g .. +3] ----
-  for (int j = wave; j < a.KCe; j += 4) {
+  // ---- stage the input tile as fragments: s_X[j][lane] = X[row = c][16j + 4g .. +3]; epilogue constants ----
+  for (int j = wave; j < a.KCe; j += NWAVES) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (c < rows_in && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
     *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = v;
   }
+  for (int i = tid; i < Cexp; i += NTHR) { s_scE[i] = a.scE[i]; s_shE[i] = a.shE[i]; s_be[i] = a.be[i]; }
   __syncthreads();
 
   // ---- phase A: expand ----
   {
-    const float* wlane = a.WpE + (size_t)g * 64 + c * 4;
-    const size_t cstride = (size_t)a.NTe * 256;
-    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)j * 64 + lane) * 4); };
     constexpr int NTW = 2;
-    for (int t0 = wave * NTW; t0 < a.NTe; t0 += 4 * NTW) {
-      f32x4 acc[NTW];
-#pragma unroll
-      for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      stream_mfma<NTW, 4>(acc, wlane, cstride, t0, 1, a.NTe, a.KCe, xfrag);
+    const int ngroups = (a.NTe + NTW - 1) / NTW;
+    const int nruns = (ngroups > wave) ? (ngroups - wave + NWAVES - 1) / NWAVES : 0;
+    auto tile_of = [&](int r) { return (wave + NWAVES * r) * NTW; };
+    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)j * 64 + lane) * 4); };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTW]) {
 #pragma unroll
       for (int q = 0; q < NTW; ++q) {
         const int n = (t0 + q) * 16 + 4 * g;
         if (t0 + q < a.NTe) {
-          f32x4 y = acc[q] * *reinterpret_cast<const f32x4*>(a.scE + n) + *reinterpret_cast<const f32x4*>(a.shE + n);
+          f32x4 y = acc[q] * *reinterpret_cast<const f32x4*>(s_scE + n) + *reinterpret_cast<const f32x4*>(s_shE + n);
           y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
           if (c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
           *reinterpret_cast<f32x4*>(s_E + (size_t)c * LDE + n) = y;
         }
       }
-    }
+    };
+    stream_mfma_runs<NTW, 4>(a.WpE + (size_t)g * 64 + c * 4, (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xfrag, epi);
   }
   __syncthreads();
 
   // ---- phase B: depthwise in place + SE sums ----
   {
     const int Q = Cexp / 4;
-    for (int task = tid; task < G * Q; task += 256) {
+    for (int task = tid; task < G * Q; task += NTHR) {
       const int gi = task / Q, q4 = (task - gi * Q) * 4;
       float* Eg = s_E + (size_t)gi * HW * LDE + q4;
       f32x4 ein[HW];
@@ -777,20 +847,20 @@ __global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
   __syncthreads();
   // rows [rows_out, 16) of E must read as zero in phase D (stride-2 block: rows HoWo..HW-1 still hold phase-A data)
   if (S != 1) {
-    for (int i = tid; i < (16 - G * HoWo) * (Cexp / 4); i += 256) {
+    for (int i = tid; i < (16 - G * HoWo) * (Cexp / 4); i += NTHR) {
       const int r = G * HoWo + i / (Cexp / 4), q4 = (i % (Cexp / 4)) * 4;
       *reinterpret_cast<f32x4*>(s_E + (size_t)r * LDE + q4) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
 
-  // ---- phase C1: r^T[se, clips] = Wr^T . mean^T, K = Cexp split over the 4 waves ----
+  // ---- phase C1: r^T[se, clips] = Wr^T . mean^T, K = Cexp split over the waves ----
   {
     const float* wlane = a.WrP + (size_t)g * 64 + c * 4;
     const size_t cstride = (size_t)a.NTR * 256;
     f32x4 acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int per = (KCx + 3) / 4;
+    const int per = (KCx + NWAVES - 1) / NWAVES;
     const int j0 = wave * per;
     const int kc = (j0 + per <= KCx) ? per : (KCx > j0 ? KCx - j0 : 0);
     auto xfrag = [&](int j) {
@@ -805,11 +875,12 @@ __global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
       for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * 16 + c] = acc[q][r];
   }
   __syncthreads();
-  for (int t = tid; t < 48 * 16; t += 256) {
+  for (int t = tid; t < 48 * 16; t += NTHR) {
     const int n = t >> 4, clip = t & 15;
     float v = 0.0f;
     if (n < a.se && clip < G) {
-      v = (s_P[(0 * 48 + n) * 16 + clip] + s_P[(1 * 48 + n) * 16 + clip]) + (s_P[(2 * 48 + n) * 16 + clip] + s_P[(3 * 48 + n) * 16 + clip]);
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * 16 + clip];
       v = swishf_(v + a.br[n]);
     }
     s_R[clip * LDR + n] = v;
@@ -817,26 +888,24 @@ __global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
   __syncthreads();
   // ---- phase C2: gate^T[Cexp, clips] = We2^T . r^T, tiles over waves ----
   {
-    const float* wlane = a.We2P + (size_t)g * 64 + c * 4;
-    const size_t cstride = (size_t)KCx * 256;                 // We2 packed with N = Cexp -> NTtot = Cexp/16
-    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_R + c * LDR + 16 * j + 4 * g); };
     constexpr int NTW = 3;
-    for (int t0 = wave * NTW; t0 < KCx; t0 += 4 * NTW) {
-      f32x4 acc[NTW];
-#pragma unroll
-      for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      stream_mfma<NTW, 3>(acc, wlane, cstride, t0, 1, KCx, a.NTR, xfrag);
+    const int ngroups = (KCx + NTW - 1) / NTW;
+    const int nruns = (ngroups > wave) ? (ngroups - wave + NWAVES - 1) / NWAVES : 0;
+    auto tile_of = [&](int r) { return (wave + NWAVES * r) * NTW; };
+    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_R + c * LDR + 16 * j + 4 * g); };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTW]) {
 #pragma unroll
       for (int q = 0; q < NTW; ++q) {
         const int n = (t0 + q) * 16 + 4 * g;
         if (t0 + q < KCx && c < G) {
-          f32x4 y = acc[q] + *reinterpret_cast<const f32x4*>(a.be + n);
+          f32x4 y = acc[q] + *reinterpret_cast<const f32x4*>(s_be + n);
           y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
           *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
           if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + n) = y;
         }
       }
-    }
+    };
+    stream_mfma_runs<NTW, 3>(a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, nruns, a.NTR, tile_of, xfrag, epi);
   }
   __syncthreads();
 
@@ -850,14 +919,14 @@ __global__ __launch_bounds__(256) void mbconv_block_kernel(BlockArgs a) {
     auto xfrag = [&](int j) {
       return *reinterpret_cast<const f32x4*>(erow + 16 * j) * *reinterpret_cast<const f32x4*>(grow + 16 * j);
     };
-    constexpr int NTW = 5;                                     // Cout/16 <= 20 tiles -> <= 5 per wave
+    constexpr int NTW = (20 + NWAVES - 1) / NWAVES;           // Cout/16 <= 20 tiles
     f32x4 acc[NTW];
 #pragma unroll
     for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    stream_mfma<NTW, 3>(acc, wlane, cstride, wave, 4, a.NTp, KCx, xfrag);
+    stream_mfma<NTW, 4>(acc, wlane, cstride, wave, NWAVES, a.NTp, KCx, xfrag);
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
-      const int t = wave + 4 * q;
+      const int t = wave + NWAVES * q;
       const int n = t * 16 + 4 * g;
       if (t < a.NTp && c < rows_out) {
         f32x4 y = acc[q] * *reinterpret_cast<const f32x4*>(a.scP + n) + *reinterpret_cast<const f32x4*>(a.shP + n);
@@ -1284,18 +1353,20 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
   const int HW = b.H * b.W, G = 16 / HW;
-  const size_t lds = ((size_t)b.expand.KC * 256 + 16 * (b.ce + 4) + 2 * (size_t)G * b.ce + 4 * 48 * 16 + 16 * 52) * sizeof(float);
+  const int nwaves = (HW == 4) ? 8 : 4;
+  const size_t gp = ((size_t)G * b.ce > (size_t)nwaves * 48 * 16) ? (size_t)G * b.ce : (size_t)nwaves * 48 * 16;
+  const size_t lds = ((size_t)b.expand.KC * 256 + 16 * (b.ce + 4) + (size_t)G * b.ce + gp + 16 * 52 + 3 * (size_t)b.ce) * sizeof(float);
   const dim3 grid((B + G - 1) / G);
   const int ks = b.spec.kernel, st = b.spec.stride;
   ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
-#define MKWS_BLOCK(KS, S, H_, W_) hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_>), grid, dim3(256), lds, s, a)
+#define MKWS_BLOCK(KS, S, H_, W_, NW) hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_, NW>), grid, dim3(NW * 64), lds, s, a)
   if (b.H == 4 && b.W == 3) {
-    if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3);
-    else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3);
-    else MKWS_BLOCK(5, 2, 4, 3);
+    if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 4);
+    else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 4);
+    else MKWS_BLOCK(5, 2, 4, 3, 4);
   } else {
-    if (ks == 5) MKWS_BLOCK(5, 1, 2, 2);
-    else MKWS_BLOCK(3, 1, 2, 2);
+    if (ks == 5) MKWS_BLOCK(5, 1, 2, 2, 8);
+    else MKWS_BLOCK(3, 1, 2, 2, 8);
   }
 #undef MKWS_BLOCK
 }
