@@ -164,7 +164,9 @@ def main():
             if stage.endswith("#reduce"):
                 cost = (0.0, 0.0)          # helper launch (split-K / SE partial): its work is booked on the main stage
             else:
-                if kernel.startswith("mbconv_front"):
+                if kernel == "stem_dw_kernel":
+                    cost = costs["stem_dw"]
+                elif kernel.startswith("mbconv_front"):
                     cost = costs[stage.replace("_dw", "_front")]
                 elif kernel.startswith("mbconv_block"):
                     cost = costs[stage + "_block"]

@@ -28,6 +28,8 @@ def stage_costs(B):
     c = {}
     h, w = 25, 20
     c["stem"] = (2 * B * h * w * 9 * 32, 4 * (B * 49 * 40 + B * h * w * 32 + 9 * 32))
+    # fused stem + block-1a depthwise launch: spectrogram in, depthwise output out
+    c["stem_dw"] = (c["stem"][0] + 2 * B * h * w * 9 * 32, 4 * (B * 49 * 40 + B * h * w * 32 + 2 * 9 * 32 + B * 32))
     for name, cin, cout, k, s, e in BLOCKS:
         p = "block" + name
         ce, se = cin * e, max(1, int(cin * 0.25))

@@ -86,6 +86,88 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ spe
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused stem + block-1a depthwise: spectrogram [49,40] -> (Rescaling, Normalization, pad, 3x3 s2 conv, BN,
+// swish) -> LDS [25x20x32 with a zero halo] -> depthwise 3x3 "same" + BN + swish -> Y [B,25,20,32] + SE sums.
+// One workgroup per clip; the 64 KB stem output never goes to HBM; halos make every tap unconditional.
+__global__ __launch_bounds__(256) void stem_dw_kernel(const float* __restrict__ spec, const float* __restrict__ w /*[9][32]*/,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, float norm_mean,
+                                                      float norm_std, const float* __restrict__ Wd /*[9][32]*/, const float* __restrict__ scD,
+                                                      const float* __restrict__ shD, float* __restrict__ Y, float* __restrict__ sums) {
+  constexpr int H = kInH, W = kInW, Ho = 25, Wo = 20, C = 32;
+  constexpr int TH = H + 2, TW = W + 1;                 // input tile with halo: rows -1..49, cols 0..40
+  constexpr int EH = Ho + 2, EW = Wo + 2;               // stem-output tile with a 1-pixel zero halo
+  extern __shared__ __attribute__((aligned(16))) float s_sd[];
+  float* s_in = s_sd;                                   // [TH][TW]
+  float* s_E = s_in + ((TH * TW + 3) & ~3);             // [EH][EW][C]
+  f32x4* s_red = reinterpret_cast<f32x4*>(s_E + EH * EW * C);   // [256]
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.x;
+  const float* img = spec + b * H * W;
+  for (int i = tid; i < TH * TW; i += 256) {
+    const int r = i / TW - 1, cc = i % TW;
+    float v = 0.0f;
+    if (r >= 0 && r < H && cc < W) v = __fdiv_rn(img[r * W + cc] * (1.0f / 255.0f) - norm_mean, norm_std);
+    s_in[i] = v;
+  }
+  for (int i = tid; i < EH * EW * C / 4; i += 256) {     // zero the halo (interior is overwritten below)
+    const int pix = i / (C / 4);
+    const int r = pix / EW, cc = pix % EW;
+    if (r == 0 || r == EH - 1 || cc == 0 || cc == EW - 1) reinterpret_cast<f32x4*>(s_E)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const int q = tid & 7;                                 // channel quad of this thread (256 % 8 == 0: fixed)
+  {
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(w + t * C + q * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+    for (int pix = tid >> 3; pix < Ho * Wo; pix += 32) {
+      const int oh = pix / Wo, ow = pix % Wo;
+      const float* in0 = s_in + (2 * oh) * TW + 2 * ow;   // tile row 2*oh == image row 2*oh - 1
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += wk[i * 3 + j] * in0[i * TW + j];
+      f32x4 y = acc * sc + sh;
+      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+      *reinterpret_cast<f32x4*>(s_E + ((size_t)(oh + 1) * EW + (ow + 1)) * C + q * 4) = y;
+    }
+  }
+  __syncthreads();
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+  {
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(Wd + t * C + q * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scD + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shD + q * 4);
+    float* yout = Y + b * Ho * Wo * C + q * 4;
+    for (int pix = tid >> 3; pix < Ho * Wo; pix += 32) {
+      const int oh = pix / Wo, ow = pix % Wo;
+      const float* e0 = s_E + ((size_t)oh * EW + ow) * C + q * 4;     // top-left tap (halo offset cancels the -1)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + j) * C) * wk[i * 3 + j];
+      f32x4 y = acc * sc + sh;
+      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+      *reinterpret_cast<f32x4*>(yout + (size_t)pix * C) = y;
+      ssum += y;
+    }
+  }
+  s_red[tid] = ssum;
+  __syncthreads();
+  if (tid < 8) {
+    f32x4 t = s_red[tid];
+    for (int k = 1; k < 32; ++k) t += s_red[k * 8 + tid];
+    *reinterpret_cast<f32x4*>(sums + b * C + tid * 4) = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1x1 conv / dense GEMM.  Y[m, n] = act((sum_k X[m,k] * gate[m/HW, k] * W[k,n]) * scale[n] + shift[n]) + R[m,n]
 // Packed weights (chunk-major): Wp[((j*NTtot + nt)*4 + g)*64 + c*4 + s] = W[16j + 4g + s][16nt + c], zero
 // padded -- the NT tiles a wave needs for one K chunk are contiguous, consecutive n-blocks read consecutive
@@ -1100,6 +1182,7 @@ struct mkws_embed {
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
+  bool fuse_stem = true;           // stem conv + block-1a depthwise in one kernel (stem_dw_kernel)
   int fuse_block = 1;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images, 2 = also 4x3
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
@@ -1406,15 +1489,24 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     if (stop && name == stop) { *tap_src = p; *tap_count = n; return true; }
     return false;
   };
-  {
+  const bool want_stem_tap = stop && strcmp(stop, "stem") == 0;
+  const bool fused_stem = em->fuse_stem && !want_stem_tap;
+  if (fused_stem) {
+    // stem + block-1a depthwise in one launch: bufD <- dw output, sums <- SE sums (bufA is not produced)
+    const BlockPlan& b1 = em->blocks[0];
+    ProfScope ps("block1a_dw", "stem_dw_kernel");
+    const size_t lds = ((size_t)((51 * 41 + 3) & ~3) + 27 * 22 * 32 + 256 * 4) * sizeof(float);
+    hipLaunchKernelGGL(stem_dw_kernel, dim3(B), dim3(256), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
+                       em->norm_std, b1.dw.Wd, b1.dw.scale, b1.dw.shift, em->bufD, em->sums);
+  } else {
     const long pix = (long)B * 500;
     int grid = (int)((pix + 31) / 32);
     if (grid > 8192) grid = 8192;
     ProfScope ps("stem", "stem_kernel");
     hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 0, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift,
                        em->norm_mean, em->norm_std, em->bufA, B);
+    if (hit("stem", em->bufA, (size_t)B * 500 * kStemCh)) return MKWS_OK;
   }
-  if (hit("stem", em->bufA, (size_t)B * 500 * kStemCh)) return MKWS_OK;
   float* cur = em->bufA;
   float* nxt = em->bufB;
   for (int i = 0; i < kNumBlocks; ++i) {
@@ -1442,7 +1534,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     } else if (b.has_expand) {
       launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
-    } else {
+    } else if (!(i == 0 && fused_stem)) {
       launch_dw(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
     }
     if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
@@ -1644,6 +1736,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (!em || !name) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
   if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value != 0; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

@@ -19,7 +19,7 @@ rows = em.profile(x, reps=10)
 costs = arch.stage_costs(B)
 tot = 0
 for stage, kern, ms in rows:
-    f, b = (0.0, 0.0) if stage.endswith("#reduce") else (costs[stage.replace("_dw", "_front")] if kern.startswith("mbconv_front") else (costs[stage + "_block"] if kern.startswith("mbconv_block") else costs[stage]))
+    f, b = costs["stem_dw"] if kern == "stem_dw_kernel" else (0.0, 0.0) if stage.endswith("#reduce") else (costs[stage.replace("_dw", "_front")] if kern.startswith("mbconv_front") else (costs[stage + "_block"] if kern.startswith("mbconv_block") else costs[stage]))
     tot += ms
     print(f"{stage:16s} {kern:28s} {ms*1000:8.1f} us  {f/ms/1e9:7.1f} TF/s  {b/ms/1e6:7.0f} GB/s  ({f/1e9:.2f} GF, {b/1e6:.1f} MB)")
 print("total ms", tot)
