@@ -1441,7 +1441,7 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   const size_t lds = ((size_t)b.expand.KC * 256 + 16 * (b.ce + 4) + (size_t)G * b.ce + gp + 16 * 52 + 3 * (size_t)b.ce) * sizeof(float);
   const dim3 grid((B + G - 1) / G);
   const int ks = b.spec.kernel, st = b.spec.stride;
-  ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
+  ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + "," + std::to_string(nwaves) + ">");
 #define MKWS_BLOCK(KS, S, H_, W_, NW) hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_, NW>), grid, dim3(NW * 64), lds, s, a)
   if (b.H == 4 && b.W == 3) {
     if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 4);

@@ -1,0 +1,121 @@
+"""Drop-in for the streaming-inference core of multilingual_kws/embedding/batch_streaming_analysis.py.
+
+The reference (:99-117) slices a long recording into 1 s windows every 20 ms, calls the micro-frontend op
+on each window in a Python loop and runs one full model per keyword.  Here one call produces every
+window's features on the GPU with per-frame FFT / filterbank work shared across the 49x-overlapping
+windows (mkws_frontend_stream_f32; bit-identical to per-window calls), the embedding is computed once and
+any number of few-shot heads are applied to it.  The detector (SingleTargetRecognizeCommands) stays on the
+host.  Accuracy bookkeeping against ground-truth files (accuracy_utils / tpr_fpr) is out of scope."""
+import os
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from . import input_data
+from .single_target_recognize_commands import RecognizeResult, SingleTargetRecognizeCommands
+
+
+@dataclass(frozen=True)
+class StreamFlags:
+    wav: os.PathLike
+    ground_truth: os.PathLike
+    target_keyword: str
+    detection_thresholds: List[float]
+    clip_duration_ms: int = 1000
+    clip_stride_ms: int = 20
+    average_window_duration_ms: int = 100
+    suppression_ms: int = 500
+    time_tolerance_ms: int = 750
+    minimum_count: int = 4
+    max_chunk_length_sec: int = 1200
+
+    def labels(self) -> List[str]:
+        return [input_data.SILENCE_LABEL, input_data.UNKNOWN_WORD_LABEL, self.target_keyword]
+
+
+def window_offsets(data_samples, clip_duration_samples, clip_stride_samples):
+    """Start sample of every window the reference evaluates: range(0, data_samples - clip, stride)."""
+    return list(range(0, data_samples - clip_duration_samples, clip_stride_samples))
+
+
+def stream_spectrograms(model_settings, audio, clip_duration_samples, clip_stride_samples, max_chunk_samples=None):
+    """float32 audio [n] -> CUDA tensor [num_windows, frames, channels], windows as window_offsets()."""
+    import torch
+    audio_t = torch.as_tensor(np.asarray(audio, dtype=np.float32)) if not torch.is_tensor(audio) else audio
+    audio_t = audio_t.cuda().contiguous()
+    n = audio_t.shape[0]
+    nwin = len(window_offsets(n, clip_duration_samples, clip_stride_samples))
+    frames, chans = model_settings["spectrogram_length"], model_settings["fingerprint_width"]
+    if nwin <= 0:
+        return torch.empty((0, frames, chans), dtype=torch.float32, device=audio_t.device)
+    fe = input_data._frontend_for(model_settings, n)
+    if clip_stride_samples % model_settings["window_stride_samples"] != 0:
+        # hop not a multiple of the frame step: no frame sharing possible, fall back to explicit windows
+        idx = (torch.arange(clip_duration_samples, device=audio_t.device)[None]
+               + torch.arange(nwin, device=audio_t.device)[:, None] * clip_stride_samples)
+        return fe.forward(audio_t[idx])
+    return fe.stream(audio_t, clip_duration_samples, clip_stride_samples)[:nwin]
+
+
+def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_duration_ms=1000, clip_stride_ms=20,
+                         batch_windows=4096):
+    """Softmax outputs for every window.  `models`: one TransferLearnedModel or a list sharing one embedding
+    (multi-keyword serving: the EfficientNet forward runs once, each keyword adds only its 18.5 k-parameter
+    head).  Returns [num_windows, 3] (or a list of them)."""
+    import torch
+    single = not isinstance(models, (list, tuple))
+    mlist = [models] if single else list(models)
+    clip = int(clip_duration_ms * sample_rate / 1000)
+    stride = int(clip_stride_ms * sample_rate / 1000)
+    specs = stream_spectrograms(model_settings, audio, clip, stride)
+    outs = [[] for _ in mlist]
+    emb_model = mlist[0].embedding
+    for s in range(0, specs.shape[0], batch_windows):
+        emb = emb_model.forward(specs[s:s + batch_windows])
+        for k, m in enumerate(mlist):
+            outs[k].append(m.head.forward(emb))
+    res = [torch.cat(o).cpu().numpy() if o else np.zeros((0, 3), np.float32) for o in outs]
+    return res[0] if single else res
+
+
+def detect(inferences, flags: StreamFlags, threshold, sample_rate=16000, data_samples=None):
+    """Runs the detector over per-window softmax outputs; returns (found_words, found_words_w_confidences)
+    exactly as the reference collects them (:143-167)."""
+    clip = int(flags.clip_duration_ms * sample_rate / 1000)
+    stride = int(flags.clip_stride_ms * sample_rate / 1000)
+    offsets = window_offsets(data_samples, clip, stride) if data_samples is not None else [i * stride for i in range(len(inferences))]
+    element = RecognizeResult()
+    rc = SingleTargetRecognizeCommands(labels=flags.labels(), average_window_duration_ms=flags.average_window_duration_ms,
+                                       detection_threshold=threshold, suppression_ms=flags.suppression_ms,
+                                       minimum_count=flags.minimum_count, target_id=2)
+    found, found_conf = [], []
+    for ix, off in enumerate(offsets):
+        t_ms = int(off * 1000 / sample_rate)
+        rc.process_latest_result(inferences[ix], t_ms, element)
+        if element.is_new_command and element.found_command != "_silence_":
+            found.append([element.found_command, t_ms])
+            found_conf.append([element.found_command, t_ms, element.score])
+    return found, found_conf
+
+
+def calculate_streaming_accuracy(model, model_settings, flag_list, existing_inferences=None):
+    """Reference signature (:50-179): one wav, several StreamFlags; returns (results, inferences) with
+    results = [(FLAGS, {threshold: (found_words, found_words_w_confidences)})]."""
+    assert len(set([f.wav for f in flag_list])) == 1, "can only process one wav"
+    assert len(set([f.clip_duration_ms for f in flag_list])) == 1, "cannot vary"
+    assert len(set([f.clip_stride_ms for f in flag_list])) == 1, "cannot vary"
+    with open(flag_list[0].wav, "rb") as f:
+        audio, sample_rate = input_data.decode_wav(f.read())
+    if existing_inferences is not None:
+        inferences = existing_inferences
+    else:
+        inferences = streaming_inferences(model, model_settings, audio, sample_rate, flag_list[0].clip_duration_ms,
+                                          flag_list[0].clip_stride_ms)
+    results = []
+    for FLAGS in flag_list:
+        res_thresh = {}
+        for threshold in FLAGS.detection_thresholds:
+            res_thresh[threshold] = detect(inferences, FLAGS, threshold, sample_rate, data_samples=audio.shape[0])
+        results.append((FLAGS, res_thresh))
+    return results, inferences

@@ -1,0 +1,106 @@
+"""Streaming row (SURVEY 8a9 + 8f-1): the host-side detector on CPU, the GPU window loop under -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from multilingual_kws_amd.embedding import batch_streaming_analysis as bsa
+from multilingual_kws_amd.embedding.single_target_recognize_commands import RecognizeResult, SingleTargetRecognizeCommands
+from tests.util_data import tone_clip, write_wav
+
+
+def _run(scores, thr=0.5, avg_ms=100, sup_ms=500, min_count=4, stride_ms=20):
+    rc = SingleTargetRecognizeCommands(["_silence_", "_unknown_", "kw"], avg_ms, thr, sup_ms, min_count, 2)
+    el, events = RecognizeResult(), []
+    for i, s in enumerate(scores):
+        rc.process_latest_result(np.array([1 - s, 0.0, s]), i * stride_ms, el)
+        if el.is_new_command:
+            events.append((i * stride_ms, el.found_command, round(float(el.score), 6)))
+    return events
+
+
+def test_detector_needs_minimum_count_and_fires_once():
+    # 100 ms window at 20 ms hops holds 6 results (times t-100..t); first evaluation once 4 results cover >= 25 ms
+    ev = _run([0.9] * 40)
+    assert ev[0] == (60, "kw", 0.9)                      # 4th window (t = 60 ms)
+    assert [e for e in ev if e[1] == "kw"] == [ev[0]]    # suppressed afterwards: label unchanged, no re-fire
+
+
+def test_detector_release_and_refire_respect_suppression():
+    scores = [0.9] * 10 + [0.0] * 60 + [0.9] * 10
+    ev = _run(scores)
+    kinds = [(t, c) for t, c, _ in ev]
+    assert kinds[0] == (60, "kw")
+    # average drops below 0.5 a few windows after t = 200 ms, but the release needs > 500 ms since the last event
+    rel = [t for t, c in kinds if c == "_silence_"]
+    assert rel and rel[0] == 580                          # first hop with t - 60 > 500
+    fire2 = [t for t, c in kinds if c == "kw"][1:]
+    assert fire2 and fire2[0] >= rel[0] + 500             # re-fire also waits out the suppression window
+    with pytest.raises(ValueError):
+        SingleTargetRecognizeCommands(["a", "b", "c"], 100, 0.5, 500, 4, 2).process_latest_result(np.zeros(2), 0, RecognizeResult())
+
+
+def test_detector_average_is_over_the_window():
+    # one spike cannot fire: mean over >= 4 windows stays below threshold
+    assert [e for e in _run([0.0] * 10 + [1.0] + [0.0] * 10) if e[1] == "kw"] == []
+    # three of six above: mean 0.5 is not > 0.5
+    assert [e for e in _run([0.0, 1.0] * 20) if e[1] == "kw"] == []
+
+
+def test_detector_matches_reference_golden_vectors(golden_dir):
+    """Step-by-step equality with outputs of the reference's own detector (tests/golden/make_detector_golden.py)."""
+    import json
+    G = json.load(open(os.path.join(golden_dir, "detector_golden.json")))
+    assert len(G["cases"]) == 12
+    n_events = 0
+    for case in G["cases"]:
+        cfg = case["config"]
+        rc = SingleTargetRecognizeCommands(["_silence_", "_unknown_", "kw"], cfg["avg"], cfg["thr"], cfg["sup"], cfg["minc"], 2)
+        el = RecognizeResult()
+        for i, (p, exp) in enumerate(zip(case["probs"], case["outputs"])):
+            rc.process_latest_result(np.asarray(p), i * cfg["stride"], el)
+            assert el.found_command == exp[0] and bool(el.is_new_command) == exp[2], (cfg, i)
+            assert float(el.score) == exp[1], (cfg, i)          # same accumulation order -> bit-equal float64
+            n_events += exp[2]
+    assert n_events > 50
+
+
+def test_window_offsets_and_flags():
+    assert bsa.window_offsets(16000, 16000, 320) == []                       # the reference evaluates NO window here
+    assert bsa.window_offsets(16000 + 640, 16000, 320) == [0, 320]
+    assert bsa.window_offsets(16000 + 641, 16000, 320) == [0, 320, 640]
+    f = bsa.StreamFlags(wav="x.wav", ground_truth="g.txt", target_keyword="kw", detection_thresholds=[0.5])
+    assert f.labels() == ["_silence_", "_unknown_", "kw"] and (f.clip_stride_ms, f.average_window_duration_ms, f.suppression_ms, f.minimum_count) == (20, 100, 500, 4)
+
+
+@pytest.mark.gpu
+def test_streaming_inferences_match_per_window_predict(tmp_path):
+    torch = pytest.importorskip("torch")
+    from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+    from multilingual_kws_amd.head import Head
+    ms = input_data.standard_microspeech_model_settings(3)
+    rng = np.random.default_rng(0)
+    pcm = np.concatenate([tone_clip(400 + 300 * k, rng, n=8000) for k in range(7)])       # 3.5 s
+    wav = str(tmp_path / "stream.wav")
+    write_wav(wav, pcm)
+    emb, blob = tl.load_base_model("synthetic", max_batch=256)
+    models = [tl.TransferLearnedModel(emb, Head(max_batch=256, seed=s), blob, "synthetic") for s in (1, 2, 3)]
+    audio = pcm.astype(np.float32) / 32768
+    inf = bsa.streaming_inferences(models, ms, audio)
+    offs = bsa.window_offsets(len(pcm), 16000, 320)
+    assert all(i.shape == (len(offs), 3) for i in inf) and len(offs) == 125
+    # reference semantics: every window = to_micro_spectrogram(slice) -> model.predict
+    wins = np.stack([audio[o:o + 16000] for o in offs])
+    specs = input_data.to_micro_spectrogram(ms, wins)
+    for m, got in zip(models, inf):
+        assert np.array_equal(got, m.predict(specs[..., None]))            # bit-identical: frame sharing changes nothing
+    assert not np.array_equal(inf[0], inf[1])
+    flags = bsa.StreamFlags(wav=wav, ground_truth="", target_keyword="kw", detection_thresholds=[0.3, 0.6])
+    results, inferences = bsa.calculate_streaming_accuracy(models[0], ms, [flags])
+    assert np.array_equal(inferences, inf[0]) and set(results[0][1]) == {0.3, 0.6}
+    found, found_conf = results[0][1][0.3]
+    assert all(w == "kw" for w, _ in found) and len(found) == len(found_conf)
+    # odd hop (not a multiple of the 320-sample frame step) falls back to explicit windows
+    sp = bsa.stream_spectrograms(ms, audio, 16000, 500)
+    ref = input_data.to_micro_spectrogram(ms, np.stack([audio[o:o + 16000] for o in bsa.window_offsets(len(pcm), 16000, 500)]))
+    assert np.array_equal(sp.cpu().numpy(), ref)
