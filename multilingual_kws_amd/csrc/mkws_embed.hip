@@ -328,6 +328,156 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged variant of the 1x1-conv / dense GEMM (same math, same packed weights, same epilogue).
+// pw_gemm_kernel fetches every operand fragment straight into registers; that path is bounded by the
+// vector L1: an X fragment load touches 16 cache lines for 1 KB, and the waves of a block re-fetch
+// operands they share.  Here a block of WM x WN waves stages a (BM rows x 32 k) X tile and the matching
+// weight fragments in LDS once per 32-k stage:
+//   * X is read from global with 8 lanes per row = whole 128-byte lines, gated (SE) on the way, and written
+//     to LDS in MFMA-fragment order, so every wave then pulls its fragments with lane-linear ds_read_b128;
+//   * weights are already fragment-ordered in global (pack_gemm) and are copied as they are;
+//   * two LDS buffers, one __syncthreads per stage, next stage's global loads in flight during the MFMAs.
+template <int WM, int WN, int MT, int NT, bool GATE>
+__global__ __launch_bounds__(256) void pw_gemm_lds_kernel(GemmArgs a) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int BMT = WM * MT;             // m-tiles per block
+  constexpr int BM = BMT * 16;             // rows per block
+  constexpr int BNT = WN * NT;             // n-tiles per block
+  constexpr int XF4 = BM * 8 / 256;        // float4 per thread per stage for X
+  constexpr int WF4 = (2 * BNT * 64 + 255) / 256;   // float4 per thread per stage for W
+  extern __shared__ __attribute__((aligned(16))) float s_g[];
+  float* s_X = s_g;                               // [2 buffers][2 chunks][BMT][64][4]
+  float* s_W = s_g + 2 * 2 * BMT * 256;           // [2 buffers][2 chunks][BNT][64][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM;
+  const int nt0 = blockIdx.y * BNT;
+  // K range (in 32-k stages) of this block
+  const int nstages_all = (a.KC + 1) / 2;
+  int sbeg = 0, send = nstages_all;
+  if (a.splitk > 1) {
+    const int per = (nstages_all + a.splitk - 1) / a.splitk;
+    sbeg = blockIdx.z * per;
+    send = (sbeg + per < nstages_all) ? sbeg + per : nstages_all;
+  }
+  // staging assignments
+  const float* xsrc[XF4]; const float* gsrc[XF4]; int xdst[XF4]; int xk[XF4];
+#pragma unroll
+  for (int i = 0; i < XF4; ++i) {
+    const int idx = tid + 256 * i;
+    const int row = idx >> 3, part = idx & 7;
+    int m = m0 + row; if (m >= a.M) m = a.M - 1;
+    xsrc[i] = a.X + (size_t)m * a.ldx + 4 * part;
+    gsrc[i] = GATE ? (a.gate + (size_t)(m / a.HW) * a.K + 4 * part) : nullptr;
+    xk[i] = 4 * part;
+    xdst[i] = (((part >> 2) * BMT + (row >> 4)) * 64 + (part & 3) * 16 + (row & 15)) * 4;
+  }
+  f32x4 xr[XF4], wr[WF4];
+  auto gload = [&](int st) {
+    const int kb = 32 * st;
+#pragma unroll
+    for (int i = 0; i < XF4; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kb + xk[i] < a.K) {
+        v = *reinterpret_cast<const f32x4*>(xsrc[i] + kb);
+        if (GATE) v *= *reinterpret_cast<const f32x4*>(gsrc[i] + kb);
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WF4; ++i) {
+      const int idx = tid + 256 * i;              // (chunk jl, tile t, lane l)
+      const int jl = idx / (BNT * 64), rem = idx - jl * (BNT * 64);
+      int t = nt0 + rem / 64; if (t >= a.NTtot) t = a.NTtot - 1;
+      const int j = 2 * st + jl;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < 2 * BNT * 64 && j < a.KC) v = *reinterpret_cast<const f32x4*>(a.Wp + ((size_t)j * a.NTtot + t) * 256 + (rem & 63) * 4);
+      wr[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* xs = s_X + buf * (2 * BMT * 256);
+    float* ws = s_W + buf * (2 * BNT * 256);
+#pragma unroll
+    for (int i = 0; i < XF4; ++i) *reinterpret_cast<f32x4*>(xs + xdst[i]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WF4; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 2 * BNT * 64) *reinterpret_cast<f32x4*>(ws + (size_t)idx * 4) = wr[i];
+    }
+  };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (sbeg < send) {
+    gload(sbeg);
+    lstore(0);
+    __syncthreads();
+    for (int st = sbeg; st < send; ++st) {
+      const int buf = (st - sbeg) & 1;
+      if (st + 1 < send) gload(st + 1);
+      const float* xs = s_X + buf * (2 * BMT * 256);
+      const float* ws = s_W + buf * (2 * BNT * 256);
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        f32x4 xf[MT], wf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f32x4*>(xs + ((jl * BMT + wm * MT + mt) * 64 + lane) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4*>(ws + ((jl * BNT + wn * NT + nt) * 64 + lane) * 4);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s4], xf[mt][s4], acc[mt][nt], 0, 0, 0);
+      }
+      if (st + 1 < send) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // epilogue (identical to pw_gemm_kernel's): lane (g, c) holds rows m, channels n .. n+3
+  const int mw = m0 + wm * MT * 16;
+  const int ntw = nt0 + wn * NT;
+  if (a.splitk > 1) {
+    float* P = a.part + (size_t)blockIdx.z * a.M * a.ldp;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (ntw + nt) * 16 + 4 * g;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mw + mt * 16 + c;
+        if (m < a.M) *reinterpret_cast<f32x4*>(P + (size_t)m * a.ldp + n) = acc[mt][nt];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (ntw + nt) * 16 + 4 * g;
+    if (n >= a.N) continue;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const size_t m = (size_t)(mw + mt * 16 + c);
+      if (m >= (size_t)a.M) continue;
+      f32x4 y = acc[mt][nt] * sc + sh;
+      if (a.act != ACT_NONE) {
+        y.x = apply_act(y.x, a.act); y.y = apply_act(y.y, a.act); y.z = apply_act(y.z, a.act); y.w = apply_act(y.w, a.act);
+      }
+      if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+      *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = y;
+    }
+  }
+}
+
 // split-K epilogue: Y = act(sum_z part[z] * scale + shift) + R, one float4 per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splitk, int M, int N, int ldp,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, int act,
@@ -1182,6 +1332,7 @@ struct mkws_embed {
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
+  int gemm_lds = 0;                // 1x1-conv/dense GEMM: 0 = direct-to-register kernel (faster on MI355X, profiles/r01_notes.md), 1 = planner may pick the LDS-staged kernel
   bool fuse_stem = true;           // stem conv + block-1a depthwise in one kernel (stem_dw_kernel)
   int fuse_block = 1;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images, 2 = also 4x3
   BlockPlan blocks[kNumBlocks];
@@ -1310,6 +1461,62 @@ TileChoice pick_tile(int M, int NTtot, int KC) {
   return {1, 2, 1};
 }
 
+// LDS-staged kernel configurations (WM, WN, MT, NT) -> block tile (WM*MT*16) x (WN*NT*16)
+struct LdsCfg { int id, WM, WN, MT, NT; };
+static const LdsCfg kLdsCfgs[] = {
+    {0, 4, 1, 1, 5},   //  64 x  80
+    {1, 4, 1, 1, 7},   //  64 x 112
+    {2, 2, 2, 2, 3},   //  64 x  96
+    {3, 2, 2, 2, 4},   //  64 x 128
+    {4, 2, 2, 4, 4},   // 128 x 128
+    {5, 4, 1, 2, 5},   // 128 x  80
+    {6, 4, 1, 2, 7},   // 128 x 112
+    {7, 1, 4, 4, 3},   //  64 x 192
+};
+constexpr int kNumLdsCfgs = sizeof(kLdsCfgs) / sizeof(kLdsCfgs[0]);
+static thread_local int g_gemm_lds_mode = 0;      // 0: never, 1: planner decides, >= 100: force config (mode - 100)
+
+template <bool GATE>
+void launch_gemm_lds(int id, dim3 grid, size_t lds, hipStream_t s, const GemmArgs& a) {
+#define MKWS_L(WM, WN, MT, NT) hipLaunchKernelGGL((pw_gemm_lds_kernel<WM, WN, MT, NT, GATE>), grid, dim3(256), lds, s, a)
+  switch (id) {
+    case 0: MKWS_L(4, 1, 1, 5); break;
+    case 1: MKWS_L(4, 1, 1, 7); break;
+    case 2: MKWS_L(2, 2, 2, 3); break;
+    case 3: MKWS_L(2, 2, 2, 4); break;
+    case 4: MKWS_L(2, 2, 4, 4); break;
+    case 5: MKWS_L(4, 1, 2, 5); break;
+    case 6: MKWS_L(4, 1, 2, 7); break;
+    default: MKWS_L(1, 4, 4, 3); break;
+  }
+#undef MKWS_L
+}
+
+// Picks an LDS config for a layer (or -1 to use the direct kernel): the narrowest block that covers N with
+// little padding, row tile sized so the grid still has >= 512 blocks when possible; split-K for long K.
+int pick_lds(int M, int NTtot, int KC, int* splitk) {
+  *splitk = 1;
+  if (NTtot < 4 || KC < 4) return -1;
+  int best = -1; double best_cost = 1e30; int best_sk = 1;
+  for (int i = 0; i < kNumLdsCfgs; ++i) {
+    const LdsCfg& c = kLdsCfgs[i];
+    const int bnt = c.WN * c.NT, bm = c.WM * c.MT * 16;
+    const long nb = (NTtot + bnt - 1) / bnt, mb = (M + bm - 1) / bm;
+    const double pad = (double)(nb * bnt) / NTtot;
+    for (int sk = 1; sk <= 4; sk *= 2) {
+      if (sk > 1 && KC / (2 * sk) < 4) break;
+      const long blocks = nb * mb * sk;
+      // cost ~ padded work / parallel efficiency; prefer >= 512 blocks, mild penalty for split-K and tiny wave tiles
+      const double par = blocks >= 512 ? 1.0 : (double)blocks / 512.0;
+      const double tile_eff = (c.MT * c.NT >= 8) ? 1.0 : (c.MT * c.NT >= 5 ? 0.9 : 0.75);
+      const double cost = pad / (par * tile_eff) * (sk == 1 ? 1.0 : (sk == 2 ? 1.1 : 1.2));
+      if (cost < best_cost) { best_cost = cost; best = i; best_sk = sk; }
+    }
+  }
+  *splitk = best_sk;
+  return best;
+}
+
 void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const float* X, int ldx, int M, int Mplan, int act, const float* gate, int HW,
                  const float* R, int ldr, float* Y, int ldy) {
   GemmArgs a;
@@ -1319,6 +1526,33 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
   if (const char* f = getenv("MKWS_GEMM_FORCE")) {       // experiment hook: "Mmax,MT,NT,SK" applies to layers with Mplan <= Mmax
     int mmax = 0, fmt = 0, fnt = 0, fsk = 0;
     if (sscanf(f, "%d,%d,%d,%d", &mmax, &fmt, &fnt, &fsk) == 4 && Mplan <= mmax && fnt <= L.NTtot) tc = {fmt, fnt, fsk};
+  }
+  // LDS-staged kernel?
+  int lds_sk = 1;
+  int lds_id = (g_gemm_lds_mode == 0) ? -1 : (g_gemm_lds_mode >= 100 ? g_gemm_lds_mode - 100 : pick_lds(Mplan, L.NTtot, L.KC, &lds_sk));
+  if (lds_id >= kNumLdsCfgs || L.NTtot < 4 || (L.K & 3)) lds_id = -1;
+  if (lds_id >= 0) {
+    const LdsCfg& c = kLdsCfgs[lds_id];
+    const int bnt = c.WN * c.NT, bm = c.WM * c.MT * 16;
+    a.splitk = lds_sk; a.part = nullptr; a.ldp = L.NTtot * 16;
+    if (a.splitk > 1) {
+      if (!g_splitk_ws || (size_t)a.splitk * M * a.ldp > g_splitk_ws_floats) a.splitk = 1;
+      else a.part = g_splitk_ws;
+    }
+    const size_t lds = (size_t)(2 * 2 * c.WM * c.MT * 256 + 2 * 2 * bnt * 256) * sizeof(float);
+    dim3 grid((M + bm - 1) / bm, (L.NTtot + bnt - 1) / bnt, a.splitk);
+    {
+      ProfScope ps(stage, std::string("pw_gemm_lds_kernel<") + std::to_string(c.WM) + "," + std::to_string(c.WN) + "," + std::to_string(c.MT) + "," +
+                              std::to_string(c.NT) + (gate ? ",true>" : ",false>"));
+      if (gate) launch_gemm_lds<true>(lds_id, grid, lds, s, a); else launch_gemm_lds<false>(lds_id, grid, lds, s, a);
+    }
+    if (a.splitk > 1) {
+      ProfScope ps(std::string(stage) + "#reduce", "splitk_reduce_kernel");
+      const long total = (long)M * (L.N / 4);
+      int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, a.part, a.splitk, M, L.N, a.ldp, L.scale, L.shift, act, R, ldr, Y, ldy);
+    }
+    return;
   }
   const int MT = tc.MT, NT = tc.NT;
   a.splitk = tc.splitk; a.part = nullptr; a.ldp = L.NTtot * 16;
@@ -1485,6 +1719,7 @@ void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float
 int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStream_t s, const char* stop,
                 const float** tap_src, size_t* tap_count) {
   g_splitk_ws = em->splitk_ws; g_splitk_ws_floats = em->splitk_floats;
+  g_gemm_lds_mode = em->gemm_lds;
   auto hit = [&](const std::string& name, const float* p, size_t n) {
     if (stop && name == stop) { *tap_src = p; *tap_count = n; return true; }
     return false;
@@ -1737,6 +1972,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value != 0; return MKWS_OK; }
+  if (strcmp(name, "gemm_lds") == 0) { em->gemm_lds = value; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
