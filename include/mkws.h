@@ -148,6 +148,8 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "gemm_lds" (default 0): 0 = 1x1-conv / dense layers use the direct-to-register MFMA kernel; 1 = a planner may
  *                 pick the LDS-staged GEMM kernel (operands shared by the block's waves, full-line activation
  *                 loads; measured slower on MI355X for these shapes); 100+i forces LDS configuration i.
+ *   "fuse_se" (default 0): 1 = the partial sums of the SE reduce FC are produced by the depthwise kernels
+ *                 themselves (one SE launch per block instead of two; measured slower on MI355X).
  *   "fuse_stem" (default 1): stem conv + block-1a depthwise in one kernel (stem output stays in LDS).
  *   "fuse_block" (default 1): blocks with 2x2 images (6b..7a) run expand -> depthwise -> SE -> project as ONE
  *                 kernel with the activations resident in LDS; 2 = also the 4x3 blocks (4b..6a; slower on

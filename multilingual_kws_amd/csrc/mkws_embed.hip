@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ spe
 __global__ __launch_bounds__(256) void stem_dw_kernel(const float* __restrict__ spec, const float* __restrict__ w /*[9][32]*/,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, float norm_mean,
                                                       float norm_std, const float* __restrict__ Wd /*[9][32]*/, const float* __restrict__ scD,
-                                                      const float* __restrict__ shD, float* __restrict__ Y, float* __restrict__ sums) {
+                                                      const float* __restrict__ shD, float* __restrict__ Y, float* __restrict__ sums,
+                                                      const float* __restrict__ Wr, int se, float* __restrict__ separt, int Btot) {
   constexpr int H = kInH, W = kInW, Ho = 25, Wo = 20, C = 32;
   constexpr int TH = H + 2, TW = W + 1;                 // input tile with halo: rows -1..49, cols 0..40
   constexpr int EH = Ho + 2, EW = Wo + 2;               // stem-output tile with a 1-pixel zero halo
@@ -160,11 +161,24 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const float* __restrict__ 
   }
   s_red[tid] = ssum;
   __syncthreads();
+  float* s_sumc = s_in;                                  // input tile is dead by now: reuse for the 32 channel sums
   if (tid < 8) {
     f32x4 t = s_red[tid];
     for (int k = 1; k < 32; ++k) t += s_red[k * 8 + tid];
     *reinterpret_cast<f32x4*>(sums + b * C + tid * 4) = t;
+    *reinterpret_cast<f32x4*>(s_sumc + tid * 4) = t;
   }
+  __syncthreads();
+  if (separt && tid < 48) {                              // SE reduce-FC partial (the only chunk of block 1a)
+    float v = 0.0f;
+    if (tid < se)
+    {
+#pragma unroll 32
+      for (int cc = 0; cc < C; ++cc) v += s_sumc[cc] * (1.0f / (Ho * Wo)) * Wr[cc * se + tid];
+    }
+    separt[b * 48 + tid] = v;
+  }
+  (void)Btot;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -561,6 +575,8 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X, co
 //            a time, SE sums reduced through LDS;  otherwise (tiny images): thread = (clip, channel quad)
 //            walks all output pixels itself and owns its SE sums.
 struct FrontArgs {
+  // fused SE squeeze -> reduce-FC partials: separt[chunk][clip][48] = sum_{c in chunk} mean[clip][c] * Wr[c][n]
+  const float* Wr; int se; float* separt; float inv_hw;
   const float* X; int Cin;
   const float* WpE; const float* scE; const float* shE; int KC; int NTtotE;
   const float* Wd; const float* scD; const float* shD;
@@ -759,10 +775,25 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
       }
       s_red[tid] = ssum;
       __syncthreads();
+      float* s_sumc = reinterpret_cast<float*>(s_red + 256);         // [CC] channel sums of this clip
       if (tid < nt_valid * 4) {
         f32x4 t = s_red[tid];
         for (int k = 1; k < PL; ++k) t += s_red[k * Q + tid];
         *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + ch0 + 4 * tid) = t;
+        *reinterpret_cast<f32x4*>(s_sumc + 4 * tid) = t;
+      }
+      __syncthreads();
+      if (a.separt && tid < 48) {
+        float v = 0.0f;
+        if (tid < a.se) {
+          const int nc = nt_valid * 16;
+        {
+          const float* wr = a.Wr + (size_t)ch0 * a.se + tid;
+#pragma unroll 16
+          for (int cc = 0; cc < nc; ++cc) v += s_sumc[cc] * a.inv_hw * wr[(size_t)cc * a.se];
+        }
+        }
+        a.separt[((size_t)blockIdx.y * a.B + (b0 + gi)) * 48 + tid] = v;
       }
       __syncthreads();
     }
@@ -820,6 +851,29 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
         ssum += y;
       }
       *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + cq) = ssum;
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(s_red + 256) + (size_t)gi * CC + 4 * tq) = ssum;
+    }
+    if (a.separt) {
+      float* s_sumc = reinterpret_cast<float*>(s_red + 256);        // [G][CC]
+      __syncthreads();
+      const int nc = nt_valid * 16;
+      for (int o = tid; o < gvalid * 48; o += NTHREADS) {
+        const int gi = o / 48, n = o - gi * 48;
+        float v = 0.0f;
+        if (n < a.se) {
+          const float* wr = a.Wr + (size_t)ch0 * a.se + n;
+          float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll 8
+          for (int cc = 0; cc < nc; cc += 4) {       // nc is a multiple of 16; 4 independent chains, 32 loads in flight
+            v0 += s_sumc[gi * CC + cc] * wr[(size_t)cc * a.se];
+            v1 += s_sumc[gi * CC + cc + 1] * wr[(size_t)(cc + 1) * a.se];
+            v2 += s_sumc[gi * CC + cc + 2] * wr[(size_t)(cc + 2) * a.se];
+            v3 += s_sumc[gi * CC + cc + 3] * wr[(size_t)(cc + 3) * a.se];
+          }
+          v = ((v0 + v1) + (v2 + v3)) * a.inv_hw;
+        }
+        a.separt[((size_t)blockIdx.y * a.B + (b0 + gi)) * 48 + n] = v;
+      }
     }
   }
 }
@@ -1223,7 +1277,8 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict_
     dst[t] = (s_part[t] + s_part[NTR * 256 + t]) + (s_part[2 * NTR * 256 + t] + s_part[3 * NTR * 256 + t]);
 }
 
-template <int NTR>
+// PARTS_BY_CLIP: partials come from the producing kernels (mbconv_front / stem_dw) as [chunk][clip][48]
+template <int NTR, bool PARTS_BY_CLIP = false>
 __global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict__ part, int nslices, const float* __restrict__ br,
                                                         const float* __restrict__ WeP, const float* __restrict__ be,
                                                         float* __restrict__ gate, int B, int C, int se, int NTe, int nsplit) {
@@ -1236,7 +1291,12 @@ __global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict_
     const int n = t >> 4, clip = t & 15;
     float v = 0.0f;
     if (n < se) {
-      for (int z = 0; z < nslices; ++z) v += part[((size_t)z * gridDim.x + blockIdx.x) * NTR * 256 + t];
+      if (PARTS_BY_CLIP) {
+        if (b0 + clip < B)
+          for (int z = 0; z < nslices; ++z) v += part[((size_t)z * B + (b0 + clip)) * 48 + n];
+      } else {
+        for (int z = 0; z < nslices; ++z) v += part[((size_t)z * gridDim.x + blockIdx.x) * NTR * 256 + t];
+      }
       v = swishf_(v + br[n]);
     }
     s_r[clip * LDR + n] = v;
@@ -1300,7 +1360,7 @@ struct GemmLayer {   // device pointers into the weight blob
   int K = 0, N = 0, KC = 0, NTtot = 0;
 };
 struct DwLayer { const float* Wd = nullptr; const float* scale = nullptr; const float* shift = nullptr; };
-struct SeLayer { const float* WrP = nullptr; const float* br = nullptr; const float* WeP = nullptr; const float* be = nullptr; int se = 0, KCr = 0, NTR = 0, NTe = 0; };
+struct SeLayer { const float* Wr = nullptr; const float* WrP = nullptr; const float* br = nullptr; const float* WeP = nullptr; const float* be = nullptr; int se = 0, KCr = 0, NTR = 0, NTe = 0; };
 
 struct BlockPlan {
   MBConvSpec spec;
@@ -1333,6 +1393,8 @@ struct mkws_embed {
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
   int gemm_lds = 0;                // 1x1-conv/dense GEMM: 0 = direct-to-register kernel (faster on MI355X, profiles/r01_notes.md), 1 = planner may pick the LDS-staged kernel
+  bool fuse_se = false;            // SE squeeze -> reduce-FC partials inside the producing kernel (saves the se_reduce launch, but the
+                                   // serial tails cost more than the launch on MI355X: 624k vs 643k clips/s; kept for A/B)
   bool fuse_stem = true;           // stem conv + block-1a depthwise in one kernel (stem_dw_kernel)
   int fuse_block = 1;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images, 2 = also 4x3
   BlockPlan blocks[kNumBlocks];
@@ -1605,8 +1667,9 @@ bool front_supported(const BlockPlan& b) {
   return false;
 }
 
-void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
+void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, float* separt, int B) {
   FrontArgs a;
+  a.Wr = b.se.Wr; a.se = b.se.se; a.separt = separt; a.inv_hw = 1.0f / (float)(b.Ho * b.Wo);
   a.X = X; a.Cin = b.spec.in_ch; a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KC = b.expand.KC;
   a.NTtotE = b.expand.NTtot;
   a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift; a.Y = Y; a.sums = sums;
@@ -1624,7 +1687,7 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   }
   if (G > B) G = B;
   a.G = G;
-  const size_t lds = ((size_t)G * HW * (CC + 4) + 256 * 4) * sizeof(float);
+  const size_t lds = ((size_t)G * HW * (CC + 4) + 256 * 4 + (tiny ? (size_t)G * CC : CC)) * sizeof(float);
   const dim3 grid((B + G - 1) / G, (b.ce + CC - 1) / CC);
   const int ks = b.spec.kernel, st = b.spec.stride, kc = b.expand.KC;
   ProfScope ps(stage, std::string("mbconv_front_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(CC) + "," +
@@ -1688,8 +1751,21 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
 #undef MKWS_BLOCK
 }
 
-void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B) {
+void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B, int se_chunks) {
   const SeLayer& L = b.se;
+  if (se_chunks > 0) {           // reduce-FC partials already written by the producing kernel as [chunk][clip][48]
+    int nsp2 = L.NTe / 4; if (nsp2 < 1) nsp2 = 1; if (nsp2 > 8) nsp2 = 8;
+    const int nb2 = (B + 15) / 16;
+    ProfScope ps(stage, std::string("se_expand_kernel<") + std::to_string(L.NTR) + ",true>");
+#define MKWS_SE2(N) hipLaunchKernelGGL((se_expand_kernel<N, true>), dim3(nb2, nsp2), dim3(256), 0, s, part, se_chunks, L.br, L.WeP, L.be, gate, B, b.ce, L.se, L.NTe, nsp2)
+    switch (L.NTR) {
+      case 1: MKWS_SE2(1); break;
+      case 2: MKWS_SE2(2); break;
+      default: MKWS_SE2(3); break;
+    }
+#undef MKWS_SE2
+    return;
+  }
   int nsl = L.KCr / 4; if (nsl < 1) nsl = 1; if (nsl > 8) nsl = 8;       // K slices of the reduce FC
   int nsp = L.NTe / 4; if (nsp < 1) nsp = 1; if (nsp > 8) nsp = 8;       // column slices of the expand FC
   const int nb = (B + 15) / 16;
@@ -1732,7 +1808,8 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     ProfScope ps("block1a_dw", "stem_dw_kernel");
     const size_t lds = ((size_t)((51 * 41 + 3) & ~3) + 27 * 22 * 32 + 256 * 4) * sizeof(float);
     hipLaunchKernelGGL(stem_dw_kernel, dim3(B), dim3(256), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
-                       em->norm_std, b1.dw.Wd, b1.dw.scale, b1.dw.shift, em->bufD, em->sums);
+                       em->norm_std, b1.dw.Wd, b1.dw.scale, b1.dw.shift, em->bufD, em->sums, b1.se.Wr, b1.se.se,
+                       em->fuse_se ? em->se_part : nullptr, B);
   } else {
     const long pix = (long)B * 500;
     int grid = (int)((pix + 31) / 32);
@@ -1749,6 +1826,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     const std::string p = std::string("block") + b.spec.name;
     const int Min = B * b.H * b.W, Mout = B * b.Ho * b.Wo;
     const bool want_expand_tap = stop && (p + "_expand") == stop;
+    int se_chunks = 0;            // > 0: SE reduce partials were already produced by the upstream kernel
     if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
@@ -1765,15 +1843,18 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       if (hit(p + "_expand", em->bufE, (size_t)Min * b.ce)) return MKWS_OK;
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else if (b.has_expand && front_supported(b)) {
-      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
+      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, em->fuse_se ? em->se_part : nullptr, B);
+      se_chunks = em->fuse_se ? (b.ce + (b.H * b.W <= 16 ? 128 : 32) - 1) / (b.H * b.W <= 16 ? 128 : 32) : 0;
     } else if (b.has_expand) {
       launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else if (!(i == 0 && fused_stem)) {
       launch_dw(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
+    } else if (em->fuse_se) {
+      se_chunks = 1;
     }
     if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
-    launch_se(s, (p + "_gate").c_str(), b, em->sums, em->se_part, em->gate, B);
+    launch_se(s, (p + "_gate").c_str(), b, em->sums, em->se_part, em->gate, B, se_chunks);
     if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
     launch_gemm(s, p.c_str(), b.project, em->bufD, b.ce, Mout, em->max_batch * b.Ho * b.Wo, ACT_NONE, em->gate, b.Ho * b.Wo, b.residual ? cur : nullptr,
                 b.spec.out_ch, nxt, b.spec.out_ch);
@@ -1860,7 +1941,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   fold_bn(T("stem_bn/gamma"), T("stem_bn/beta"), T("stem_bn/moving_mean"), T("stem_bn/moving_variance"), kStemCh, &sc, &sh);
   const size_t o_stem_sc = pk.add(sc.data(), kStemCh), o_stem_sh = pk.add(sh.data(), kStemCh);
 
-  struct BlockOff { GemmOff expand, project, se_r, se_e; size_t dw_w, dw_sc, dw_sh; } bo[kNumBlocks];
+  struct BlockOff { GemmOff expand, project, se_r, se_e; size_t dw_w, dw_sc, dw_sh, se_wr; } bo[kNumBlocks];
   int H = 25, W = 20;
   for (int i = 0; i < kNumBlocks; ++i) {
     BlockPlan& b = em->blocks[i];
@@ -1893,6 +1974,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     {
       std::vector<float> one_r(se, 1.0f), bias_r(T(p + "_se_reduce/bias"), T(p + "_se_reduce/bias") + se);
       bo[i].se_r = pack_gemm(pk, T(p + "_se_reduce/kernel"), b.ce, se, one_r, bias_r);
+      bo[i].se_wr = pk.add(T(p + "_se_reduce/kernel"), (size_t)b.ce * se);     // plain [C][se] for the fused partials
       std::vector<float> one_e(b.ce, 1.0f), bias_e(T(p + "_se_expand/bias"), T(p + "_se_expand/bias") + b.ce);
       bo[i].se_e = pack_gemm(pk, T(p + "_se_expand/kernel"), se, b.ce, one_e, bias_e);
       if (bo[i].se_r.NTtot > 3) { delete em; return fail(MKWS_ERR_UNSUPPORTED, "SE width %d > 48", se); }
@@ -1926,14 +2008,14 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     if (b.has_expand) b.expand = G(bo[i].expand);
     b.project = G(bo[i].project);
     b.dw.Wd = d + bo[i].dw_w; b.dw.scale = d + bo[i].dw_sc; b.dw.shift = d + bo[i].dw_sh;
-    b.se.WrP = d + bo[i].se_r.Wp; b.se.br = d + bo[i].se_r.shift; b.se.WeP = d + bo[i].se_e.Wp; b.se.be = d + bo[i].se_e.shift;
+    b.se.Wr = d + bo[i].se_wr; b.se.WrP = d + bo[i].se_r.Wp; b.se.br = d + bo[i].se_r.shift; b.se.WeP = d + bo[i].se_e.Wp; b.se.be = d + bo[i].se_e.shift;
     b.se.KCr = bo[i].se_r.KC; b.se.NTR = bo[i].se_r.NTtot; b.se.NTe = bo[i].se_e.NTtot;
     // the expand FC's K (= se) is padded to NTR*16 by pack_gemm: KC of se_e == NTR by construction
   }
   em->top = G(o_top); em->dense0 = G(o_d0); em->dense1 = G(o_d1); em->dense2 = G(o_d2);
 
   // workspace
-  const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 5120 + 384;
+  const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 5120 + 9 * 48;
   const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
@@ -1973,6 +2055,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value != 0; return MKWS_OK; }
   if (strcmp(name, "gemm_lds") == 0) { em->gemm_lds = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_se") == 0) { em->fuse_se = value != 0; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

@@ -58,6 +58,7 @@ def test_execution_options_agree(ctx):
             ctx["em"].set_option("fuse_block", block)
             ctx["em"].set_option("fuse_stem", front)
             ctx["em"].set_option("gemm_lds", block % 2)
+            ctx["em"].set_option("fuse_se", 1 - block % 2)
             assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block)
             for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a"):
                 taps = {}
@@ -69,6 +70,7 @@ def test_execution_options_agree(ctx):
         ctx["em"].set_option("fuse_block", 1)
         ctx["em"].set_option("fuse_stem", 1)
         ctx["em"].set_option("gemm_lds", 0)
+        ctx["em"].set_option("fuse_se", 0)
 
 
 def test_golden_embedding_on_device(ctx, golden_dir):
