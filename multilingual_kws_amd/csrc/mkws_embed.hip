@@ -596,13 +596,14 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   constexpr int Q = CC / 4;
   const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
   float* s_E = s_front;                        // [G*HW][LDE]
-  f32x4* s_red = reinterpret_cast<f32x4*>(s_front + (size_t)a.G * HW * LDE);   // [256]
+  f32x4* s_red = reinterpret_cast<f32x4*>(s_front + ((size_t)a.G * HW + 1) * LDE);   // [256], after the zero row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * a.G;
   const int gvalid = (a.B - b0 < a.G) ? (a.B - b0) : a.G;
   const int rows = gvalid * HW;
   const int ch0 = blockIdx.y * CC;             // first expanded channel of this block
+  if (tid < LDE / 4) *reinterpret_cast<f32x4*>(s_front + (size_t)a.G * HW * LDE + 4 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f};
   // nt_valid: n-tiles of this block that exist (the last chunk of a layer may be partial)
   const int nt_valid = ((a.Cexp - ch0) / 16 < NT) ? (a.Cexp - ch0) / 16 : NT;
   // ---- phase 1: expand into LDS ----
@@ -615,118 +616,137 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
     const float* wbase = a.WpE + ((size_t)(ch0 / 16) * 4 + g) * 64 + c * 4;     // + (j*NTtotE + nt)*256
     const size_t wchunk = (size_t)a.NTtotE * 256;
     const int ntiles = (rows + 15) / 16;
-    auto epilogue = [&](int row, const f32x4 (&acc)[NT]) {
-      if (row < rows) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (nt < nt_valid) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scE + ch0 + nt * 16 + 4 * g);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shE + ch0 + nt * 16 + 4 * g);
-            f32x4 y = acc[nt] * sc + sh;
-            y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
-            *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + nt * 16 + 4 * g) = y;
-          }
-        }
-      }
-    };
     if constexpr (PIXEL_LANES) {
+      // All loads of the tile loop are unconditional (clamped row / k offsets; padded k positions meet zero
+      // weights), the BN constants sit in registers, and the X ring is prologue / steady state / tail, so
+      // hipcc emits counted vmcnt waits instead of draining the ring at every tile.
       constexpr int MAXKC = KCT;             // exact K chunk count of the layer (Cin = 16, 24, 40 -> 1, 2, 3)
-      f32x4 wreg[MAXKC][NT];
+      f32x4 wreg[MAXKC][NT], scr[NT], shr[NT];
 #pragma unroll
-      for (int j = 0; j < MAXKC; ++j)
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ntc = nt < nt_valid ? nt : nt_valid - 1;
+        scr[nt] = *reinterpret_cast<const f32x4*>(a.scE + ch0 + ntc * 16 + 4 * g);
+        shr[nt] = *reinterpret_cast<const f32x4*>(a.shE + ch0 + ntc * 16 + 4 * g);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          wreg[j][nt] = (j < a.KC && nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + (size_t)j * wchunk + nt * 256)
-                                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
-      // row tiles of this wave: wave, wave+4, ...; X fragments of D tiles in flight
+        for (int j = 0; j < MAXKC; ++j) wreg[j][nt] = *reinterpret_cast<const f32x4*>(wbase + (size_t)j * wchunk + ntc * 256);
+      }
+      int koff[MAXKC];
+#pragma unroll
+      for (int j = 0; j < MAXKC; ++j) koff[j] = (16 * j + 4 * g < a.Cin - 4) ? 16 * j + 4 * g : a.Cin - 4;
+      constexpr int NW = NTHREADS / 64;
+      const int nmy = (ntiles - wave + NW - 1) / NW;          // row tiles of this wave: wave, wave + NW, ...
       constexpr int D = 4;
       f32x4 xq[D][MAXKC];
-      auto loadx = [&](int t, f32x4 (&xv)[MAXKC]) {
-        const int row = t * 16 + c;
+      auto loadx = [&](int i, f32x4 (&xv)[MAXKC]) {
+        int row = (wave + NW * i) * 16 + c;
+        row = row < rows ? row : rows - 1;
+        const float* xp = Xb + (size_t)row * a.Cin;
 #pragma unroll
-        for (int j = 0; j < MAXKC; ++j) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (j < a.KC && row < rows && (16 * j + 4 * g) < a.Cin) v = *reinterpret_cast<const f32x4*>(Xb + (size_t)row * a.Cin + 16 * j + 4 * g);
-          xv[j] = v;
+        for (int j = 0; j < MAXKC; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xp + koff[j]);
+      };
+      auto tile = [&](int i, const f32x4 (&xv)[MAXKC]) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < MAXKC; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][nt][s], xv[j][s], acc[nt], 0, 0, 0);
+        const int row = (wave + NW * i) * 16 + c;
+        if (row < rows) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (nt < nt_valid) {
+              f32x4 y = acc[nt] * scr[nt] + shr[nt];
+              y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+              *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + nt * 16 + 4 * g) = y;
+            }
+          }
         }
       };
 #pragma unroll
-      for (int d = 0; d < D; ++d)
-        if (wave + 4 * d < ntiles) loadx(wave + 4 * d, xq[d]);
-      for (int t0 = wave; t0 < ntiles; t0 += 4 * D) {
+      for (int d = 0; d < D; ++d) loadx(d, xq[d]);
+      int i = 0;
+      for (; i + D <= nmy; i += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          const int t = t0 + 4 * d;
-          if (t < ntiles) {
-            f32x4 acc[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < MAXKC; ++j)
-#pragma unroll
-              for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][nt][s], xq[d][j][s], acc[nt], 0, 0, 0);
-            if (t + 4 * D < ntiles) loadx(t + 4 * D, xq[d]);
-            epilogue(t * 16 + c, acc);
-          }
+          tile(i + d, xq[d]);
+          loadx(i + d + D, xq[d]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+        if (i + d < nmy) tile(i + d, xq[d]);
     } else {
       // 8 waves = 4 row-pair lanes x 2 column halves: wave tile = 2 row tiles x NT/2 column tiles, so one
-      // K chunk costs 2 X + NT/2 weight fragments (6 KB) for 2*NT/2*4 = 16 MFMAs per quarter... (24 B/clk/CU)
+      // K chunk costs 2 X + NT/2 weight fragments for 2*(NT/2)*4 MFMAs.  Same load discipline as above.
       constexpr int NTW = (NT >= 2) ? NT / 2 : 1;
       const int nhalf = wave >> 2, plane = wave & 3;
       const int npairs = (ntiles + 1) / 2;
+      f32x4 scr[NTW], shr[NTW];
+      const float* wpq[NTW];
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        const int nt = nhalf * NTW + q;
+        const int ntc = nt < nt_valid ? nt : nt_valid - 1;
+        scr[q] = *reinterpret_cast<const f32x4*>(a.scE + ch0 + ntc * 16 + 4 * g);
+        shr[q] = *reinterpret_cast<const f32x4*>(a.shE + ch0 + ntc * 16 + 4 * g);
+        wpq[q] = wbase + (size_t)ntc * 256;
+      }
       for (int pr = plane; pr < npairs; pr += 4) {
         const int row0 = pr * 32 + c, row1 = row0 + 16;
+        const float* xp0 = Xb + (size_t)(row0 < rows ? row0 : rows - 1) * a.Cin;
+        const float* xp1 = Xb + (size_t)(row1 < rows ? row1 : rows - 1) * a.Cin;
         f32x4 acc0[NTW], acc1[NTW];
 #pragma unroll
         for (int q = 0; q < NTW; ++q) { acc0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         constexpr int D = 3;
         f32x4 x0[D], x1[D], wq[D][NTW];
         auto load = [&](int j, f32x4& v0, f32x4& v1, f32x4 (&wv)[NTW]) {
-          const bool kok = (16 * j + 4 * g) < a.Cin;
-          v0 = (kok && row0 < rows) ? *reinterpret_cast<const f32x4*>(Xb + (size_t)row0 * a.Cin + 16 * j + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          v1 = (kok && row1 < rows) ? *reinterpret_cast<const f32x4*>(Xb + (size_t)row1 * a.Cin + 16 * j + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          j = j < a.KC ? j : a.KC - 1;                      // past the end: harmless reload, never consumed
+          const int ko = (16 * j + 4 * g < a.Cin - 4) ? 16 * j + 4 * g : a.Cin - 4;
+          v0 = *reinterpret_cast<const f32x4*>(xp0 + ko);
+          v1 = *reinterpret_cast<const f32x4*>(xp1 + ko);
 #pragma unroll
-          for (int q = 0; q < NTW; ++q) {
-            const int nt = nhalf * NTW + q;
-            wv[q] = (nt < nt_valid) ? *reinterpret_cast<const f32x4*>(wbase + (size_t)j * wchunk + nt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
+          for (int q = 0; q < NTW; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wpq[q] + (size_t)j * wchunk);
+        };
+        auto compute = [&](const f32x4& v0, const f32x4& v1, const f32x4 (&wv)[NTW]) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) {
+              acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], v0[s], acc0[q], 0, 0, 0);
+              acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], v1[s], acc1[q], 0, 0, 0);
+            }
         };
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-          if (d < a.KC) load(d, x0[d], x1[d], wq[d]);
-        for (int j0 = 0; j0 < a.KC; j0 += D) {
+        for (int d = 0; d < D; ++d) load(d, x0[d], x1[d], wq[d]);
+        int j = 0;
+        for (; j + D <= a.KC; j += D) {
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            const int j = j0 + d;
-            if (j < a.KC) {
-#pragma unroll
-              for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int q = 0; q < NTW; ++q) {
-                  acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d][q][s], x0[d][s], acc0[q], 0, 0, 0);
-                  acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[d][q][s], x1[d][s], acc1[q], 0, 0, 0);
-                }
-              if (j + D < a.KC) load(j + D, x0[d], x1[d], wq[d]);
-            }
+            compute(x0[d], x1[d], wq[d]);
+            load(j + d + D, x0[d], x1[d], wq[d]);
+            __builtin_amdgcn_sched_barrier(0);     // keep the reload right behind its slot's MFMAs
           }
         }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+          if (j + d < a.KC) compute(x0[d], x1[d], wq[d]);
 #pragma unroll
         for (int q = 0; q < NTW; ++q) {
           const int nt = nhalf * NTW + q;
           if (nt < nt_valid) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scE + ch0 + nt * 16 + 4 * g);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shE + ch0 + nt * 16 + 4 * g);
             if (row0 < rows) {
-              f32x4 y = acc0[q] * sc + sh;
+              f32x4 y = acc0[q] * scr[q] + shr[q];
               y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
               *reinterpret_cast<f32x4*>(s_E + (size_t)row0 * LDE + nt * 16 + 4 * g) = y;
             }
             if (row1 < rows) {
-              f32x4 y = acc1[q] * sc + sh;
+              f32x4 y = acc1[q] * scr[q] + shr[q];
               y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
               *reinterpret_cast<f32x4*>(s_E + (size_t)row1 * LDE + nt * 16 + 4 * g) = y;
             }
@@ -748,22 +768,29 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
     const int dh = PL / a.Wo, dwo = PL % a.Wo;
+    const int zrow = a.G * HW;                 // LDS row of zeros: out-of-image taps read it (no branches, so
+                                               // all KS*KS ds_reads of a pixel are in flight together)
     for (int gi = 0; gi < gvalid; ++gi) {
-      const float* E = s_E + (size_t)gi * HW * LDE + 4 * tq;
+      const float* E = s_E + 4 * tq;
+      const int ebase = gi * HW;
       float* yout = a.Y + (size_t)(b0 + gi) * HoWo * a.Cexp + cq;
       f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
       int oh = tp / a.Wo, ow = tp % a.Wo;
       for (int p = tp; qok && p < HoWo; p += PL) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int ih0 = oh * S - a.pt, iw0 = ow * S - a.pl;
+        int colv[KS];
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) colv[jx] = ((unsigned)(iw0 + jx) < (unsigned)a.W) ? ebase + iw0 + jx : -1;
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
-          const int ih = oh * S - a.pt + i;
-          if (ih < 0 || ih >= a.H) continue;
+          const int ih = ih0 + i;
+          const bool rok = (unsigned)ih < (unsigned)a.H;
+          const int rbase = ih * a.W;
 #pragma unroll
           for (int jx = 0; jx < KS; ++jx) {
-            const int iw = ow * S - a.pl + jx;
-            if (iw < 0 || iw >= a.W) continue;
-            acc += *reinterpret_cast<const f32x4*>(E + (size_t)(ih * a.W + iw) * LDE) * wk[i * KS + jx];
+            const int r = (rok && colv[jx] >= 0) ? rbase + colv[jx] : zrow;
+            acc += *reinterpret_cast<const f32x4*>(E + (size_t)r * LDE) * wk[i * KS + jx];
           }
         }
         f32x4 y = acc * sc + sh;
@@ -773,12 +800,19 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
         oh += dh; ow += dwo;
         if (ow >= a.Wo) { ow -= a.Wo; ++oh; }
       }
-      s_red[tid] = ssum;
+      // channel sums of this clip: lanes of a wave that share tq (lane % Q) fold with shuffles, then the
+      // NW wave partials are added in fixed order (deterministic, batch-size independent)
+#pragma unroll
+      for (int m = Q; m < 64; m <<= 1) {
+        ssum.x += __shfl_xor(ssum.x, m); ssum.y += __shfl_xor(ssum.y, m);
+        ssum.z += __shfl_xor(ssum.z, m); ssum.w += __shfl_xor(ssum.w, m);
+      }
+      if (lane < Q) s_red[wave * Q + lane] = ssum;
       __syncthreads();
       float* s_sumc = reinterpret_cast<float*>(s_red + 256);         // [CC] channel sums of this clip
       if (tid < nt_valid * 4) {
         f32x4 t = s_red[tid];
-        for (int k = 1; k < PL; ++k) t += s_red[k * Q + tid];
+        for (int k = 1; k < NTHREADS / 64; ++k) t += s_red[k * Q + tid];
         *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + ch0 + 4 * tid) = t;
         *reinterpret_cast<f32x4*>(s_sumc + 4 * tid) = t;
       }
@@ -1687,7 +1721,7 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   }
   if (G > B) G = B;
   a.G = G;
-  const size_t lds = ((size_t)G * HW * (CC + 4) + 256 * 4 + (tiny ? (size_t)G * CC : CC)) * sizeof(float);
+  const size_t lds = (((size_t)G * HW + 1) * (CC + 4) + 256 * 4 + (tiny ? (size_t)G * CC : CC)) * sizeof(float);
   const dim3 grid((B + G - 1) / G, (b.ce + CC - 1) / CC);
   const int ks = b.spec.kernel, st = b.spec.stride, kc = b.expand.KC;
   ProfScope ps(stage, std::string("mbconv_front_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(CC) + "," +
