@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--profile-reps", type=int, default=5)
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B execution switch passed to mkws_embed_set_option (e.g. fuse_block=1); default = shipped plan")
     return ap.parse_args()
 
 
@@ -113,6 +115,9 @@ def main():
     blob = weights.synthetic_blob()
     fe = Frontend(max_samples=16000)
     em = EmbeddingModel(blob, max_batch=B, device=dev)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        em.set_option(name, int(val))
     audio_np = synth.clips_float32(B, first_clip=rank * B)      # each rank gets its own shard of clips
     audio = torch.from_numpy(audio_np).to(dev)
     spec = torch.empty((B, 49, 40), dtype=torch.float32, device=dev)

@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmkws_hip.so")
+# MKWS_LIB selects another build of the same library (e.g. the phase-timing build of tools/README.md)
+LIB_PATH = os.environ.get("MKWS_LIB") or os.path.join(_HERE, "lib", "libmkws_hip.so")
 
 MKWS_OK = 0
 

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace mkws {
@@ -582,6 +583,9 @@ struct FrontArgs {
   const float* Wd; const float* scD; const float* shD;
   float* Y; float* sums;
   int B, H, W, Ho, Wo, pt, pl, Cexp, G;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbg_t;
+#endif
 };
 
 // Template: KS/S depthwise kernel & stride; CC channels per block; KCT > 0: big-image mode with exactly KCT
@@ -604,6 +608,10 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   const int rows = gvalid * HW;
   const int ch0 = blockIdx.y * CC;             // first expanded channel of this block
   if (tid < LDE / 4) *reinterpret_cast<f32x4*>(s_front + (size_t)a.G * HW * LDE + 4 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbgp = a.dbg_t + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+  if (tid == 0) dbgp[0] = wall_clock64();
+#endif
   // nt_valid: n-tiles of this block that exist (the last chunk of a layer may be partial)
   const int nt_valid = ((a.Cexp - ch0) / 16 < NT) ? (a.Cexp - ch0) / 16 : NT;
   // ---- phase 1: expand into LDS ----
@@ -755,7 +763,13 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
       }
     }
   }
+#ifdef MKWS_FRONT_TIMING
+  if (tid == 0) dbgp[1] = wall_clock64();
+#endif
   __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+  if (tid == 0) dbgp[2] = wall_clock64();
+#endif
   // ---- phase 2: depthwise from LDS ----
   if constexpr (PIXEL_LANES) {
     constexpr int PL = 256 / Q;
@@ -910,6 +924,10 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
       }
     }
   }
+#ifdef MKWS_FRONT_TIMING
+  __syncthreads();
+  if (tid == 0) dbgp[3] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -932,13 +950,34 @@ struct BlockArgs {
   float* Y; int Cout; int residual;
   float* dbg_dw; float* dbg_gate;
   int B, Cexp, se;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbg_t;
+#endif
 };
 
-// acc[q] += sum_j W(j, tile0 + tstride*q) . xfrag(j) for j in [0, KC): weight fragments via a DEPTH-deep
-// register ring (prologue / branch-free steady state / drain, so hipcc emits counted vmcnt waits).
-template <int NTW, int DEPTH, typename XF>
-__device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW], const float* __restrict__ wlane, size_t chunk_stride, int tile0, int tstride,
-                                            int ntiles, int KC, XF xfrag) {
+// acc[q][m] += sum_j W(j, tile0 + tstride*q) . xfrag(j, m) for j in [0, KC): weight fragments via a
+// DEPTH-deep register ring (prologue / branch-free steady state / drain, so hipcc emits counted vmcnt
+// waits); every weight fragment feeds MT activation tiles.
+template <int NTWR, int DEPTH>
+__device__ __forceinline__ void stream_mfma_prefetch(f32x4 (&wq)[DEPTH][NTWR], const float* __restrict__ wlane, size_t chunk_stride, int tile0,
+                                                     int tstride, int ntiles, int KC) {
+  if (KC >= DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int q = 0; q < NTWR; ++q) {
+        int t = tile0 + tstride * q;
+        if (t >= ntiles) t = ntiles - 1;
+        wq[d][q] = *reinterpret_cast<const f32x4*>(wlane + (size_t)t * 256 + (size_t)d * chunk_stride);
+      }
+  }
+}
+
+// PRE: the first DEPTH chunks were already requested by stream_mfma_prefetch (issued a phase earlier, so
+// their latency hides behind other work); wq is the caller's ring (NTWR >= NTW columns).
+template <int NTW, int DEPTH, int MT, bool PRE, int NTWR, typename XF>
+__device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[DEPTH][NTWR], const float* __restrict__ wlane, size_t chunk_stride,
+                                            int tile0, int tstride, int ntiles, int KC, XF xfrag) {
   const float* wp[NTW];
 #pragma unroll
   for (int q = 0; q < NTW; ++q) {
@@ -946,21 +985,26 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW], const float* __re
     if (t >= ntiles) t = ntiles - 1;             // clamped: result unused
     wp[q] = wlane + (size_t)t * 256;
   }
-  f32x4 wq[DEPTH][NTW];
-  auto load = [&](int j, f32x4 (&wv)[NTW]) {
+  auto load = [&](int j, f32x4 (&wv)[NTWR]) {
 #pragma unroll
     for (int q = 0; q < NTW; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wp[q] + (size_t)j * chunk_stride);
   };
-  auto compute = [&](int j, const f32x4 (&wv)[NTW]) {
-    const f32x4 x = xfrag(j);
+  auto compute = [&](int j, const f32x4 (&wv)[NTWR]) {
+    f32x4 x[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) x[m] = xfrag(j, m);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int q = 0; q < NTW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[s], acc[q], 0, 0, 0);
+      for (int q = 0; q < NTW; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[m][s], acc[q][m], 0, 0, 0);
   };
   if (KC >= DEPTH) {
+    if (!PRE) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load(d, wq[d]);
+      for (int d = 0; d < DEPTH; ++d) load(d, wq[d]);
+    }
     int j = 0;
     for (; j + 2 * DEPTH <= KC; j += DEPTH) {
 #pragma unroll
@@ -990,13 +1034,32 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW], const float* __re
 // [tile_of(r), +NTW), each KC chunks long.  The weight ring keeps DEPTH chunks in flight ACROSS runs, so a
 // run's first loads are already issued while the previous run computes (no per-run latency bubble).  The
 // epilogue must not issue global loads (they would drain the in-order vmcnt ring): constants come from LDS.
-template <int NTW, int DEPTH, typename XF, typename TOF, typename EPI>
-__device__ __forceinline__ void stream_mfma_runs(const float* __restrict__ wlane, size_t chunk_stride, int ntiles, int nruns, int KC,
-                                                 TOF tile_of, XF xfrag, EPI epilogue) {
+template <int NTW, int DEPTH, typename TOF>
+__device__ __forceinline__ void stream_mfma_runs_prefetch(f32x4 (&wq)[DEPTH][NTW], const float* __restrict__ wlane, size_t chunk_stride, int ntiles,
+                                                          int nruns, int KC, TOF tile_of) {
+  if (nruns * KC >= DEPTH) {
+    int lr = 0, lj = 0;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int t0 = tile_of(lr);
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        int t = t0 + q;
+        if (t >= ntiles) t = ntiles - 1;
+        wq[d][q] = *reinterpret_cast<const f32x4*>(wlane + (size_t)t * 256 + (size_t)lj * chunk_stride);
+      }
+      if (++lj == KC) { lj = 0; ++lr; }
+    }
+  }
+}
+
+template <int NTW, int DEPTH, int MT, bool PRE, typename XF, typename TOF, typename EPI>
+__device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const float* __restrict__ wlane, size_t chunk_stride, int ntiles, int nruns,
+                                                 int KC, TOF tile_of, XF xfrag, EPI epilogue) {
   const int T = nruns * KC;
   if (T <= 0) return;
-  f32x4 wq[DEPTH][NTW];
   int lr = 0, lj = 0;                                  // load cursor (run, chunk)
+  if (PRE && T >= DEPTH) { lr = DEPTH / KC; lj = DEPTH - lr * KC; }
   auto load = [&](f32x4 (&wv)[NTW]) {
     const int t0 = tile_of(lr);
 #pragma unroll
@@ -1007,26 +1070,36 @@ __device__ __forceinline__ void stream_mfma_runs(const float* __restrict__ wlane
     }
     if (++lj == KC) { lj = 0; ++lr; }
   };
-  f32x4 acc[NTW];
+  f32x4 acc[NTW][MT];
 #pragma unroll
-  for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < NTW; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int cr = 0, cj = 0;                                  // compute cursor
   auto compute = [&](const f32x4 (&wv)[NTW]) {
-    const f32x4 x = xfrag(cj);
+    f32x4 x[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) x[m] = xfrag(cj, m);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int q = 0; q < NTW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[s], acc[q], 0, 0, 0);
+      for (int q = 0; q < NTW; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[m][s], acc[q][m], 0, 0, 0);
     if (++cj == KC) {
       epilogue(tile_of(cr), acc);
 #pragma unroll
-      for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < NTW; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
       cj = 0; ++cr;
     }
   };
   if (T >= DEPTH) {
+    if (!PRE) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load(wq[d]);
+      for (int d = 0; d < DEPTH; ++d) load(wq[d]);
+    }
     int it = 0;
     for (; it + 2 * DEPTH <= T; it += DEPTH) {
 #pragma unroll
@@ -1052,28 +1125,50 @@ __device__ __forceinline__ void stream_mfma_runs(const float* __restrict__ wlane
   }
 }
 
-template <int KS, int S, int HT, int WT, int NWAVES>
+// LDS carve of mbconv_block_kernel (floats), shared by the kernel and its launcher.
+//   U: phase A: block input as B-operand fragments [KCe][MT][256];  later: SE means [G][Cexp] + gate [G][Cexp]
+//      (the SE-reduce partials [NWAVES][48][G] borrow the gate space)
+//   E: expanded activations [MT*16][Cexp + 4]
+//   Z: phase A: expand BN scale/shift [2][Cexp];  later: r [16][52] + SE expand bias [Cexp]
+struct BlockLds { int U, E, Z; };
+__host__ __device__ inline BlockLds block_lds(int KCe, int Cexp, int MT, int G, int nwaves) {
+  BlockLds l;
+  const int xf = KCe * MT * 256;
+  const int gp = (G * Cexp > nwaves * 48 * G) ? G * Cexp : nwaves * 48 * G;
+  const int sg = G * Cexp + gp;
+  l.U = xf > sg ? xf : sg;
+  l.E = MT * 16 * (Cexp + 4);
+  const int z2 = 16 * 52 + Cexp;
+  l.Z = (2 * Cexp > z2) ? 2 * Cexp : z2;
+  return l;
+}
+
+// MT = 16-row activation tiles per workgroup: 1 for 2x2 images (4 clips), 3 for 4x3 images (4 clips = 48 rows;
+// every streamed weight fragment then feeds 3 MFMAs per n-tile instead of 1).
+template <int KS, int S, int HT, int WT, int MT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_blk[];
   constexpr int NTHR = NWAVES * 64;
   constexpr int HW = HT * WT;
-  constexpr int G = 16 / HW;                                   // clips per workgroup (4 for 2x2, 1 for 4x3)
+  constexpr int G = MT * 16 / HW;                              // clips per workgroup
+  static_assert(G * HW == MT * 16, "clips must fill the row tiles exactly");
   constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1);
   constexpr int HoWo = HoT * WoT;
+  constexpr int MTO = (G * HoWo + 15) / 16;                    // output row tiles (stride 2 shrinks them)
   constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
   const int Cexp = a.Cexp, LDE = Cexp + 4;
   const int KCx = Cexp / 16;                                   // K chunks of the SE-reduce and project GEMMs
   constexpr int LDR = 52;                                      // r rows: up to 48 SE units + pad
-  float* s_X = s_blk;                                          // [KCe][64][4]   block input as B-operand fragments
-  float* s_E = s_X + (size_t)a.KCe * 256;                      // [16][LDE]
-  float* s_S = s_E + 16 * LDE;                                 // [G][Cexp]  SE means
-  float* s_G = s_S + G * Cexp;                                 // [G][Cexp]  SE gate  (phase C2 onwards)
-  float* s_P = s_G;                                            // [NWAVES][48][16] SE-reduce partials (phase C1 only: same space)
-  const int gp = (G * Cexp > NWAVES * 48 * 16) ? G * Cexp : NWAVES * 48 * 16;
-  float* s_R = s_G + gp;                                       // [16][LDR]
-  float* s_scE = s_R + 16 * LDR;                               // [Cexp] expand BN scale, shift; SE expand bias
+  const BlockLds L = block_lds(a.KCe, Cexp, MT, G, NWAVES);
+  float* s_X = s_blk;                                          // U, phase A
+  float* s_S = s_blk;                                          // U, phase B onwards: [G][Cexp] SE means
+  float* s_G = s_S + G * Cexp;                                 //                     [G][Cexp] SE gate (phase C2 onwards)
+  float* s_P = s_G;                                            //                     [NWAVES][48][G] SE-reduce partials (C1 only)
+  float* s_E = s_blk + L.U;                                    // [MT*16][LDE]
+  float* s_scE = s_E + L.E;                                    // Z, phase A: [Cexp] expand BN scale, shift
   float* s_shE = s_scE + Cexp;
-  float* s_be = s_shE + Cexp;
+  float* s_R = s_scE;                                          // Z, phase B onwards: [16][LDR], then SE expand bias [Cexp]
+  float* s_be = s_R + 16 * LDR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * G;
@@ -1081,39 +1176,65 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   const int rows_in = gvalid * HW, rows_out = gvalid * HoWo;
   const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
 
-  // ---- stage the input tile as fragments: s_X[j][lane] = X[row = c][16j + 4g .. +3]; epilogue constants ----
-  for (int j = wave; j < a.KCe; j += NWAVES) {
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
+#endif
+  // ---- stage the input tiles as fragments: s_X[j][m][lane] = X[row = 16m + c][16j + 4g .. +3]; epilogue constants ----
+  for (int jm = wave; jm < a.KCe * MT; jm += NWAVES) {
+    const int j = jm / MT, m = jm - j * MT;
+    const int r = m * 16 + c;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (c < rows_in && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
-    *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = v;
+    if (r < rows_in && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + 16 * j + 4 * g);
+    *reinterpret_cast<f32x4*>(s_X + ((size_t)jm * 64 + lane) * 4) = v;
   }
-  for (int i = tid; i < Cexp; i += NTHR) { s_scE[i] = a.scE[i]; s_shE[i] = a.shE[i]; s_be[i] = a.be[i]; }
+  for (int i = tid; i < Cexp; i += NTHR) { s_scE[i] = a.scE[i]; s_shE[i] = a.shE[i]; }
   __syncthreads();
 
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
+#endif
   // ---- phase A: expand ----
   {
-    constexpr int NTW = 2;
+    constexpr int NTW = (MT >= 3) ? 1 : 2;        // one weight fragment already feeds 4*MT MFMAs; finer runs balance the waves
     const int ngroups = (a.NTe + NTW - 1) / NTW;
     const int nruns = (ngroups > wave) ? (ngroups - wave + NWAVES - 1) / NWAVES : 0;
     auto tile_of = [&](int r) { return (wave + NWAVES * r) * NTW; };
-    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)j * 64 + lane) * 4); };
-    auto epi = [&](int t0, const f32x4 (&acc)[NTW]) {
+    auto xfrag = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTW][MT]) {
 #pragma unroll
       for (int q = 0; q < NTW; ++q) {
         const int n = (t0 + q) * 16 + 4 * g;
         if (t0 + q < a.NTe) {
-          f32x4 y = acc[q] * *reinterpret_cast<const f32x4*>(s_scE + n) + *reinterpret_cast<const f32x4*>(s_shE + n);
-          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
-          if (c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(s_E + (size_t)c * LDE + n) = y;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(s_scE + n), sh = *reinterpret_cast<const f32x4*>(s_shE + n);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 y = acc[q][m] * sc + sh;
+            y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+            if (m * 16 + c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(s_E + (size_t)(m * 16 + c) * LDE + n) = y;
+          }
         }
       }
     };
-    stream_mfma_runs<NTW, 4>(a.WpE + (size_t)g * 64 + c * 4, (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xfrag, epi);
+    f32x4 wqa[4][NTW];
+    stream_mfma_runs<NTW, 4, MT, false>(wqa, a.WpE + (size_t)g * 64 + c * 4, (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xfrag, epi);
   }
   __syncthreads();
 
-  // ---- phase B: depthwise in place + SE sums ----
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 2] = wall_clock64();
+#endif
+  // ---- phase B: depthwise (+BN+swish) + SE means.  Outputs overwrite the clip's own rows: row gi*HW + o
+  //      (in place for stride 1; for stride 2 phase D maps output row r -> (r / HoWo)*HW + r % HoWo) ----
+  for (int i = tid; i < Cexp; i += NTHR) s_be[i] = a.be[i];
+  // the weight streams of the next phases are requested one phase early (their first fragments arrive while
+  // this phase computes): C1's K slice of the SE-reduce weights here
+  const int c1_per = (KCx + NWAVES - 1) / NWAVES;
+  const int c1_j0 = wave * c1_per;
+  const int c1_kc = (c1_j0 + c1_per <= KCx) ? c1_per : (KCx > c1_j0 ? KCx - c1_j0 : 0);
+  const float* c1_w = a.WrP + (size_t)g * 64 + c * 4 + (size_t)c1_j0 * a.NTR * 256;
+  f32x4 wq1[3][3];
+  stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   {
     const int Q = Cexp / 4;
     for (int task = tid; task < G * Q; task += NTHR) {
@@ -1151,13 +1272,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + q4);
       const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + q4);
       f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
-      float* Eo = s_E + (size_t)gi * HoWo * LDE + q4;        // output rows: clip gi's HoWo pixels (== input rows when S == 1)
 #pragma unroll
       for (int o = 0; o < HoWo; ++o) {
         f32x4 y = acc[o] * sc + sh;
         y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
         if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(Eo + (size_t)o * LDE) = y;
+        *reinterpret_cast<f32x4*>(Eg + (size_t)o * LDE) = y;
         ssum += y;
         if (a.dbg_dw && gi < gvalid) *reinterpret_cast<f32x4*>(a.dbg_dw + (row0_out + gi * HoWo + o) * Cexp + q4) = y;
       }
@@ -1165,96 +1285,125 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
     }
   }
   __syncthreads();
-  // rows [rows_out, 16) of E must read as zero in phase D (stride-2 block: rows HoWo..HW-1 still hold phase-A data)
-  if (S != 1) {
-    for (int i = tid; i < (16 - G * HoWo) * (Cexp / 4); i += NTHR) {
-      const int r = G * HoWo + i / (Cexp / 4), q4 = (i % (Cexp / 4)) * 4;
-      *reinterpret_cast<f32x4*>(s_E + (size_t)r * LDE + q4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  }
 
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 3] = wall_clock64();
+#endif
   // ---- phase C1: r^T[se, clips] = Wr^T . mean^T, K = Cexp split over the waves ----
+  constexpr int NTW2 = 3;                                      // C2: gate tiles per run
+  const int c2_groups = (KCx + NTW2 - 1) / NTW2;
+  const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto c2_tile_of = [&](int r) { return (wave + NWAVES * r) * NTW2; };
+  f32x4 wq2[3][NTW2];
   {
-    const float* wlane = a.WrP + (size_t)g * 64 + c * 4;
-    const size_t cstride = (size_t)a.NTR * 256;
-    f32x4 acc[3];
+    f32x4 acc[3][1];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int per = (KCx + NWAVES - 1) / NWAVES;
-    const int j0 = wave * per;
-    const int kc = (j0 + per <= KCx) ? per : (KCx > j0 ? KCx - j0 : 0);
-    auto xfrag = [&](int j) {
+    for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto xfrag = [&](int j, int) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c < G) v = *reinterpret_cast<const f32x4*>(s_S + (size_t)c * Cexp + 16 * (j0 + j) + 4 * g);
+      if (c < G) v = *reinterpret_cast<const f32x4*>(s_S + (size_t)c * Cexp + 16 * (c1_j0 + j) + 4 * g);
       return v;
     };
-    if (kc > 0) stream_mfma<3, 3>(acc, wlane + (size_t)j0 * cstride, cstride, 0, 1, a.NTR, kc, xfrag);
+    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xfrag);
+    stream_mfma_runs_prefetch<NTW2, 3>(wq2, a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);   // C2's stream
+    if (c < G) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * 16 + c] = acc[q][r];
+        for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+    }
   }
   __syncthreads();
-  for (int t = tid; t < 48 * 16; t += NTHR) {
-    const int n = t >> 4, clip = t & 15;
+  for (int t = tid; t < 48 * G; t += NTHR) {
+    const int n = t / G, clip = t - n * G;
     float v = 0.0f;
-    if (n < a.se && clip < G) {
+    if (n < a.se) {
 #pragma unroll
-      for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * 16 + clip];
+      for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * G + clip];
       v = swishf_(v + a.br[n]);
     }
     s_R[clip * LDR + n] = v;
   }
   __syncthreads();
-  // ---- phase C2: gate^T[Cexp, clips] = We2^T . r^T, tiles over waves ----
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+#endif
+  // ---- phase C2: gate^T[Cexp, clips] = We2^T . r^T, tiles over waves (columns c >= G are don't-care) ----
+  // phase D's weight stream is requested first: this wave owns project tiles wave, wave + NWAVES, ...
+  const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0;
+  const float* d_w = a.WpP + (size_t)g * 64 + c * 4;
+  f32x4 wqd[4][3];
+  if (d_ntw > 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);
   {
-    constexpr int NTW = 3;
-    const int ngroups = (KCx + NTW - 1) / NTW;
-    const int nruns = (ngroups > wave) ? (ngroups - wave + NWAVES - 1) / NWAVES : 0;
-    auto tile_of = [&](int r) { return (wave + NWAVES * r) * NTW; };
-    auto xfrag = [&](int j) { return *reinterpret_cast<const f32x4*>(s_R + c * LDR + 16 * j + 4 * g); };
-    auto epi = [&](int t0, const f32x4 (&acc)[NTW]) {
+    const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
+    auto xfrag = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
 #pragma unroll
-      for (int q = 0; q < NTW; ++q) {
+      for (int q = 0; q < NTW2; ++q) {
         const int n = (t0 + q) * 16 + 4 * g;
         if (t0 + q < KCx && c < G) {
-          f32x4 y = acc[q] + *reinterpret_cast<const f32x4*>(s_be + n);
+          f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
           y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
           *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
           if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + n) = y;
         }
       }
     };
-    stream_mfma_runs<NTW, 3>(a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, nruns, a.NTR, tile_of, xfrag, epi);
+    stream_mfma_runs<NTW2, 3, 1, true>(wq2, a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xfrag, epi);
   }
   __syncthreads();
 
-  // ---- phase D: gated project (+ residual) ----
+  // ---- phase D: gated project (+ residual): output row r = 16m + c lives in E row (r / HoWo)*HW + r % HoWo ----
   {
-    const float* wlane = a.WpP + (size_t)g * 64 + c * 4;
     const size_t cstride = (size_t)a.NTp * 256;
-    const int clip = (c < rows_out) ? c / HoWo : 0;
-    const float* erow = s_E + (size_t)c * LDE + 4 * g;
-    const float* grow = s_G + (size_t)clip * Cexp + 4 * g;
-    auto xfrag = [&](int j) {
-      return *reinterpret_cast<const f32x4*>(erow + 16 * j) * *reinterpret_cast<const f32x4*>(grow + 16 * j);
-    };
-    constexpr int NTW = (20 + NWAVES - 1) / NWAVES;           // Cout/16 <= 20 tiles
-    f32x4 acc[NTW];
+    const float* erow[MTO];
+    const float* grow[MTO];
 #pragma unroll
-    for (int q = 0; q < NTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    stream_mfma<NTW, 4>(acc, wlane, cstride, wave, NWAVES, a.NTp, KCx, xfrag);
-#pragma unroll
-    for (int q = 0; q < NTW; ++q) {
-      const int t = wave + NWAVES * q;
-      const int n = t * 16 + 4 * g;
-      if (t < a.NTp && c < rows_out) {
-        f32x4 y = acc[q] * *reinterpret_cast<const f32x4*>(a.scP + n) + *reinterpret_cast<const f32x4*>(a.shP + n);
-        if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + n);
-        *reinterpret_cast<f32x4*>(a.Y + (row0_out + c) * a.Cout + n) = y;
-      }
+    for (int m = 0; m < MTO; ++m) {
+      int r = m * 16 + c;
+      if (r >= G * HoWo) r = G * HoWo - 1;                   // padding rows of the last tile: any finite row
+      const int clip = r / HoWo;
+      erow[m] = s_E + (size_t)(clip * HW + (r - clip * HoWo)) * LDE + 4 * g;
+      grow[m] = s_G + (size_t)clip * Cexp + 4 * g;
     }
+    auto xfrag = [&](int j, int m) {
+      return *reinterpret_cast<const f32x4*>(erow[m] + 16 * j) * *reinterpret_cast<const f32x4*>(grow[m] + 16 * j);
+    };
+    auto run = [&](auto ntw_tag) {
+      constexpr int NTW = decltype(ntw_tag)::value;
+      f32x4 acc[NTW][MTO];
+#pragma unroll
+      for (int q = 0; q < NTW; ++q)
+#pragma unroll
+        for (int m = 0; m < MTO; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      stream_mfma<NTW, 4, MTO, true>(acc, wqd, d_w, cstride, wave, NWAVES, a.NTp, KCx, xfrag);
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        const int t = wave + NWAVES * q;
+        const int n = t * 16 + 4 * g;
+        if (t < a.NTp) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scP + n), sh = *reinterpret_cast<const f32x4*>(a.shP + n);
+#pragma unroll
+          for (int m = 0; m < MTO; ++m) {
+            const int r = m * 16 + c;
+            if (r < rows_out) {
+              f32x4 y = acc[q][m] * sc + sh;
+              if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + n);
+              *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+            }
+          }
+        }
+      }
+    };
+    // Cout/16 <= 20 tiles over NWAVES waves: each wave runs exactly the 0..3 tiles it owns
+    if (d_ntw == 1) run(std::integral_constant<int, 1>{});
+    else if (d_ntw == 2) run(std::integral_constant<int, 2>{});
+    else if (d_ntw >= 3) run(std::integral_constant<int, 3>{});
   }
+#ifdef MKWS_FRONT_TIMING
+  __syncthreads();
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1430,7 +1579,7 @@ struct mkws_embed {
   bool fuse_se = false;            // SE squeeze -> reduce-FC partials inside the producing kernel (saves the se_reduce launch, but the
                                    // serial tails cost more than the launch on MI355X: 624k vs 643k clips/s; kept for A/B)
   bool fuse_stem = true;           // stem conv + block-1a depthwise in one kernel (stem_dw_kernel)
-  int fuse_block = 1;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images, 2 = also 4x3
+  int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
   int topH = 0, topW = 0;
@@ -1726,6 +1875,12 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   const int ks = b.spec.kernel, st = b.spec.stride, kc = b.expand.KC;
   ProfScope ps(stage, std::string("mbconv_front_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(CC) + "," +
                           (tiny ? "0," + std::to_string(b.H) + "," + std::to_string(b.W) : std::to_string(kc) + ",0,0") + ">");
+#ifdef MKWS_FRONT_TIMING
+  static unsigned long long* d_t = nullptr;
+  const size_t nblk = (size_t)grid.x * grid.y;
+  if (!d_t) (void)hipMalloc(&d_t, sizeof(unsigned long long) * 4 * 65536);
+  a.dbg_t = d_t;
+#endif
 #define MKWS_FRONT(KS, S, C_, KC_, H_, W_) \
   hipLaunchKernelGGL((mbconv_front_kernel<KS, S, C_, KC_, H_, W_>), grid, dim3((KC_) > 0 ? 256 : 512), lds, s, a)
   if (!tiny) {
@@ -1743,17 +1898,38 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
     else if (ks == 3 && st == 1) MKWS_FRONT(3, 1, 128, 0, 2, 2);             // 7a
   }
 #undef MKWS_FRONT
+#ifdef MKWS_FRONT_TIMING
+  {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(nblk * 4);
+    (void)hipMemcpy(h.data(), d_t, h.size() * 8, hipMemcpyDeviceToHost);
+    double p1 = 0, bar = 0, p2 = 0; unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t i = 0; i < nblk; ++i) {
+      p1 += (double)(h[4 * i + 1] - h[4 * i]); bar += (double)(h[4 * i + 2] - h[4 * i + 1]); p2 += (double)(h[4 * i + 3] - h[4 * i + 2]);
+      if (h[4 * i] < t0) t0 = h[4 * i];
+      if (h[4 * i + 3] > t1) t1 = h[4 * i + 3];
+    }
+    // wall_clock64 ticks at 100 MHz
+    fprintf(stderr, "[front-timing] %s ks%d s%d blocks %zu: phase1 %.2f us  barrier %.2f us  phase2 %.2f us  kernel span %.2f us\n", stage, ks, st, nblk,
+            p1 / nblk / 100.0, bar / nblk / 100.0, p2 / nblk / 100.0, (double)(t1 - t0) / 100.0);
+  }
+#endif
 }
 
-// Whole-block kernel for 4x3 / 2x2 images (blocks 4b..7a).
+// Whole-block kernel for 4x3 / 2x2 images (blocks 4b..7a): 4 clips per workgroup either way.
+static constexpr int kBlockWaves = 8;
+static size_t block_lds_bytes(const BlockPlan& b) {
+  const int HW = b.H * b.W, MT = (HW == 4) ? 1 : 3, G = MT * 16 / HW;
+  const BlockLds L = block_lds(b.expand.KC, b.ce, MT, G, kBlockWaves);
+  return ((size_t)L.U + L.E + L.Z) * sizeof(float);
+}
 bool block_supported(const BlockPlan& b, int mode) {
   const int ks = b.spec.kernel, st = b.spec.stride;
   if (!b.has_expand || b.ce % 16 != 0 || b.spec.out_ch % 16 != 0 || b.spec.out_ch > 320 || b.se.NTR > 3) return false;
-  // 4x3 images are implemented (and tested through fuse_block = 2) but lose to the multi-kernel path on
-  // MI355X: one clip per workgroup re-streams the block's weights 1024 times (profiles/r01_notes.md).
+  if (!((b.H == 4 && b.W == 3) || (b.H == 2 && b.W == 2))) return false;
+  if (block_lds_bytes(b) > 160 * 1024) return false;
   if (b.H == 4 && b.W == 3) return mode >= 2 && ((ks == 3 && st == 1) || (ks == 5 && st == 1) || (ks == 5 && st == 2));
-  if (b.H == 2 && b.W == 2) return (ks == 5 && st == 1) || (ks == 3 && st == 1);
-  return false;
+  return (ks == 5 && st == 1) || (ks == 3 && st == 1);
 }
 
 void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
@@ -1766,23 +1942,46 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
-  const int HW = b.H * b.W, G = 16 / HW;
-  const int nwaves = (HW == 4) ? 8 : 4;
-  const size_t gp = ((size_t)G * b.ce > (size_t)nwaves * 48 * 16) ? (size_t)G * b.ce : (size_t)nwaves * 48 * 16;
-  const size_t lds = ((size_t)b.expand.KC * 256 + 16 * (b.ce + 4) + (size_t)G * b.ce + gp + 16 * 52 + 3 * (size_t)b.ce) * sizeof(float);
+  const int HW = b.H * b.W, MT = (HW == 4) ? 1 : 3, G = MT * 16 / HW;
+  const size_t lds = block_lds_bytes(b);
   const dim3 grid((B + G - 1) / G);
   const int ks = b.spec.kernel, st = b.spec.stride;
-  ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + "," + std::to_string(nwaves) + ">");
-#define MKWS_BLOCK(KS, S, H_, W_, NW) hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_, NW>), grid, dim3(NW * 64), lds, s, a)
+#ifdef MKWS_FRONT_TIMING
+  static unsigned long long* d_bt = nullptr;
+  if (!d_bt) (void)hipMalloc(&d_bt, sizeof(unsigned long long) * 8 * 4096);
+  a.dbg_t = d_bt;
+#endif
+  ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," +
+                          std::to_string(b.W) + "," + std::to_string(MT) + "," + std::to_string(kBlockWaves) + ">");
+#define MKWS_BLOCK(KS, S, H_, W_, MT_) do { \
+    static bool attr_done = false; \
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+    hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, a); } while (0)
   if (b.H == 4 && b.W == 3) {
-    if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 4);
-    else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 4);
-    else MKWS_BLOCK(5, 2, 4, 3, 4);
+    if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 3);
+    else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 3);
+    else MKWS_BLOCK(5, 2, 4, 3, 3);
   } else {
-    if (ks == 5) MKWS_BLOCK(5, 1, 2, 2, 8);
-    else MKWS_BLOCK(3, 1, 2, 2, 8);
+    if (ks == 5) MKWS_BLOCK(5, 1, 2, 2, 1);
+    else MKWS_BLOCK(3, 1, 2, 2, 1);
   }
 #undef MKWS_BLOCK
+#ifdef MKWS_FRONT_TIMING
+  {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)grid.x * 8);
+    (void)hipMemcpy(h.data(), d_bt, h.size() * 8, hipMemcpyDeviceToHost);
+    double ph[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t i = 0; i < grid.x; ++i) {
+      for (int k = 0; k < 6; ++k) ph[k] += (double)(h[8 * i + k + 1] - h[8 * i + k]);
+      if (h[8 * i] < t0) t0 = h[8 * i];
+      if (h[8 * i + 6] > t1) t1 = h[8 * i + 6];
+    }
+    fprintf(stderr, "[block-timing] %s blocks %u: stage %.2f  A %.2f  B %.2f  C1 %.2f  C2 %.2f  D %.2f us; span %.2f us\n", stage, grid.x,
+            ph[0] / grid.x / 100.0, ph[1] / grid.x / 100.0, ph[2] / grid.x / 100.0, ph[3] / grid.x / 100.0, ph[4] / grid.x / 100.0,
+            ph[5] / grid.x / 100.0, (double)(t1 - t0) / 100.0);
+  }
+#endif
 }
 
 void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B, int se_chunks) {

@@ -60,7 +60,7 @@ def test_execution_options_agree(ctx):
             ctx["em"].set_option("gemm_lds", block % 2)
             ctx["em"].set_option("fuse_se", 1 - block % 2)
             assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block)
-            for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a"):
+            for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a"):
                 taps = {}
                 ctx["oracle"].forward(spec[:3], taps)
                 got = ctx["em"].tap(x[:3], name).cpu().numpy().reshape(taps[name].shape)
