@@ -598,9 +598,11 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   constexpr int LDE = CC + 4;
   constexpr int NT = CC / 16;
   constexpr int Q = CC / 4;
-  const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+  const int HW = a.H * a.W;
   float* s_E = s_front;                        // [G*HW][LDE]
   f32x4* s_red = reinterpret_cast<f32x4*>(s_front + ((size_t)a.G * HW + 1) * LDE);   // [256], after the zero row
+  float* s_sumc = reinterpret_cast<float*>(s_red + 256);                              // [G][CC] channel sums (SE squeeze)
+  float* s_wd = s_sumc + (size_t)a.G * CC;                                           // [KS*KS][CC] depthwise taps (big-image mode)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * a.G;
@@ -614,6 +616,13 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #endif
   // nt_valid: n-tiles of this block that exist (the last chunk of a layer may be partial)
   const int nt_valid = ((a.Cexp - ch0) / 16 < NT) ? (a.Cexp - ch0) / 16 : NT;
+  if constexpr (PIXEL_LANES) {                 // depthwise taps of this channel chunk -> LDS (consumed after phase 1)
+    for (int i = tid; i < KS * KS * Q; i += NTHREADS) {
+      const int t = i / Q, q4 = (i - t * Q) * 4;
+      const int cq = (q4 < nt_valid * 16) ? ch0 + q4 : ch0;
+      *reinterpret_cast<f32x4*>(s_wd + t * CC + q4) = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)t * a.Cexp + cq);
+    }
+  }
   // ---- phase 1: expand into LDS ----
   // Operand fragments go global -> registers through the vector L1 (64 B/clk/CU), which is what bounds
   // small MFMA tiles; so weights are fetched as rarely as possible:
@@ -772,78 +781,96 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #endif
   // ---- phase 2: depthwise from LDS ----
   if constexpr (PIXEL_LANES) {
-    constexpr int PL = 256 / Q;
-    const int tq = tid % Q, tp = tid / Q;
-    const bool qok = tq < nt_valid * 4;
-    const int cq = qok ? ch0 + 4 * tq : ch0;
-    f32x4 wk[KS * KS];
-#pragma unroll
-    for (int t = 0; t < KS * KS; ++t) wk[t] = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)t * a.Cexp + cq);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
-    const int dh = PL / a.Wo, dwo = PL % a.Wo;
-    const int zrow = a.G * HW;                 // LDS row of zeros: out-of-image taps read it (no branches, so
-                                               // all KS*KS ds_reads of a pixel are in flight together)
-    for (int gi = 0; gi < gvalid; ++gi) {
-      const float* E = s_E + 4 * tq;
-      const int ebase = gi * HW;
-      float* yout = a.Y + (size_t)(b0 + gi) * HoWo * a.Cexp + cq;
+    // Row strips: item = (clip, output row, column segment, channel quad) computes SEG adjacent outputs of one
+    // row.  The image size is a template constant, so a strip reads each of its KS x ((SEG-1)*S + KS) inputs
+    // once (instead of KS*KS per output), column offsets are immediates, out-of-image taps read the LDS zero
+    // row (no branches: all ds_reads of a row are in flight together), and the taps come from LDS.
+    constexpr int HoT = (S == 1) ? HT : (HT + 1) / 2, WoT = (S == 1) ? WT : (WT + 1) / 2;
+    constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+    constexpr int SEG = (WoT % 5 == 0) ? 5 : WoT;
+    constexpr int NSEG = WoT / SEG;
+    constexpr int NC = (SEG - 1) * S + KS;
+    static_assert(NSEG * SEG == WoT, "segments tile the output row");
+    const int zrow = a.G * HW;
+    const int nitems = gvalid * HoT * NSEG * Q;
+    for (int item = tid; item < nitems; item += NTHREADS) {
+      const int tq = item % Q;
+      int r = item / Q;
+      const int sg = r % NSEG; r /= NSEG;
+      const int oh = r % HoT, gi = r / HoT;
       f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
-      int oh = tp / a.Wo, ow = tp % a.Wo;
-      for (int p = tp; qok && p < HoWo; p += PL) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int ih0 = oh * S - a.pt, iw0 = ow * S - a.pl;
-        int colv[KS];
+      if (tq < nt_valid * 4) {
+        const int cq = ch0 + 4 * tq;
+        const float* E0 = s_E + 4 * tq;
+        const int ih0 = oh * S - PT, iw0 = sg * SEG * S - PLF;
+        int coff[NC];
 #pragma unroll
-        for (int jx = 0; jx < KS; ++jx) colv[jx] = ((unsigned)(iw0 + jx) < (unsigned)a.W) ? ebase + iw0 + jx : -1;
+        for (int ci = 0; ci < NC; ++ci) coff[ci] = ((unsigned)(iw0 + ci) < (unsigned)WT) ? iw0 + ci : -1;
+        f32x4 acc[SEG];
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
           const int ih = ih0 + i;
-          const bool rok = (unsigned)ih < (unsigned)a.H;
-          const int rbase = ih * a.W;
+          const bool rok = (unsigned)ih < (unsigned)HT;
+          const int rbase = gi * HW + ih * WT;
+          f32x4 v[NC], w[KS];
 #pragma unroll
-          for (int jx = 0; jx < KS; ++jx) {
-            const int r = (rok && colv[jx] >= 0) ? rbase + colv[jx] : zrow;
-            acc += *reinterpret_cast<const f32x4*>(E + (size_t)r * LDE) * wk[i * KS + jx];
+          for (int ci = 0; ci < NC; ++ci) {
+            const int row = (rok && coff[ci] >= 0) ? rbase + coff[ci] : zrow;
+            v[ci] = *reinterpret_cast<const f32x4*>(E0 + (size_t)row * LDE);
           }
-        }
-        f32x4 y = acc * sc + sh;
-        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
-        *reinterpret_cast<f32x4*>(yout + (size_t)p * a.Cexp) = y;
-        ssum += y;
-        oh += dh; ow += dwo;
-        if (ow >= a.Wo) { ow -= a.Wo; ++oh; }
-      }
-      // channel sums of this clip: lanes of a wave that share tq (lane % Q) fold with shuffles, then the
-      // NW wave partials are added in fixed order (deterministic, batch-size independent)
 #pragma unroll
-      for (int m = Q; m < 64; m <<= 1) {
-        ssum.x += __shfl_xor(ssum.x, m); ssum.y += __shfl_xor(ssum.y, m);
-        ssum.z += __shfl_xor(ssum.z, m); ssum.w += __shfl_xor(ssum.w, m);
+          for (int jx = 0; jx < KS; ++jx) w[jx] = *reinterpret_cast<const f32x4*>(s_wd + (i * KS + jx) * CC + 4 * tq);
+#pragma unroll
+          for (int o = 0; o < SEG; ++o)
+#pragma unroll
+            for (int jx = 0; jx < KS; ++jx) acc[o] += v[o * S + jx] * w[jx];
+        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
+        float* yout = a.Y + ((size_t)(b0 + gi) * (HoT * WoT) + oh * WoT + sg * SEG) * a.Cexp + cq;
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
+          f32x4 y = acc[o] * sc + sh;
+          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+          *reinterpret_cast<f32x4*>(yout + (size_t)o * a.Cexp) = y;
+          ssum += y;
+        }
       }
-      if (lane < Q) s_red[wave * Q + lane] = ssum;
-      __syncthreads();
-      float* s_sumc = reinterpret_cast<float*>(s_red + 256);         // [CC] channel sums of this clip
-      if (tid < nt_valid * 4) {
-        f32x4 t = s_red[tid];
-        for (int k = 1; k < NTHREADS / 64; ++k) t += s_red[k * Q + tid];
-        *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + ch0 + 4 * tid) = t;
-        *reinterpret_cast<f32x4*>(s_sumc + 4 * tid) = t;
+      s_red[item] = ssum;
+    }
+    __syncthreads();
+    // channel sums per clip: the strips' partial sums are added in fixed (row, segment) order
+    if (tid < gvalid * Q) {
+      const int gi = tid / Q, tq = tid - gi * Q;
+      if (tq < nt_valid * 4) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < HoT * NSEG; ++k) t += s_red[(gi * HoT * NSEG + k) * Q + tq];
+        *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + ch0 + 4 * tq) = t;
+        *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = t;
       }
+    }
+    if (a.separt) {
       __syncthreads();
-      if (a.separt && tid < 48) {
+      const int nc = nt_valid * 16;
+      for (int o = tid; o < gvalid * 48; o += NTHREADS) {
+        const int gi = o / 48, n = o - gi * 48;
         float v = 0.0f;
-        if (tid < a.se) {
-          const int nc = nt_valid * 16;
-        {
-          const float* wr = a.Wr + (size_t)ch0 * a.se + tid;
-#pragma unroll 16
-          for (int cc = 0; cc < nc; ++cc) v += s_sumc[cc] * a.inv_hw * wr[(size_t)cc * a.se];
+        if (n < a.se) {
+          const float* wr = a.Wr + (size_t)ch0 * a.se + n;
+          float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll 8
+          for (int cc = 0; cc < nc; cc += 4) {
+            v0 += s_sumc[gi * CC + cc] * wr[(size_t)cc * a.se];
+            v1 += s_sumc[gi * CC + cc + 1] * wr[(size_t)(cc + 1) * a.se];
+            v2 += s_sumc[gi * CC + cc + 2] * wr[(size_t)(cc + 2) * a.se];
+            v3 += s_sumc[gi * CC + cc + 3] * wr[(size_t)(cc + 3) * a.se];
+          }
+          v = ((v0 + v1) + (v2 + v3)) * a.inv_hw;
         }
-        }
-        a.separt[((size_t)blockIdx.y * a.B + (b0 + gi)) * 48 + tid] = v;
+        a.separt[((size_t)blockIdx.y * a.B + (b0 + gi)) * 48 + n] = v;
       }
-      __syncthreads();
     }
   } else {
     // image size is a template constant here: the tap loops unroll completely and taps that fall outside
@@ -899,10 +926,9 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
         ssum += y;
       }
       *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + cq) = ssum;
-      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(s_red + 256) + (size_t)gi * CC + 4 * tq) = ssum;
+      *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = ssum;
     }
     if (a.separt) {
-      float* s_sumc = reinterpret_cast<float*>(s_red + 256);        // [G][CC]
       __syncthreads();
       const int nc = nt_valid * 16;
       for (int o = tid; o < gvalid * 48; o += NTHREADS) {
@@ -975,9 +1001,11 @@ __device__ __forceinline__ void stream_mfma_prefetch(f32x4 (&wq)[DEPTH][NTWR], c
 
 // PRE: the first DEPTH chunks were already requested by stream_mfma_prefetch (issued a phase earlier, so
 // their latency hides behind other work); wq is the caller's ring (NTWR >= NTW columns).
-template <int NTW, int DEPTH, int MT, bool PRE, int NTWR, typename XF>
+// Activation fragments come from LDS in two steps so that they can be software-pipelined: xload(j, m) issues the
+// ds_reads of chunk j (called one chunk ahead), xmake(raw) turns them into the MFMA operand at use.
+template <int NTW, int DEPTH, int MT, bool PRE, int NTWR, typename XL, typename XM>
 __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[DEPTH][NTWR], const float* __restrict__ wlane, size_t chunk_stride,
-                                            int tile0, int tstride, int ntiles, int KC, XF xfrag) {
+                                            int tile0, int tstride, int ntiles, int KC, XL xload, XM xmake) {
   const float* wp[NTW];
 #pragma unroll
   for (int q = 0; q < NTW; ++q) {
@@ -989,10 +1017,21 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
 #pragma unroll
     for (int q = 0; q < NTW; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wp[q] + (size_t)j * chunk_stride);
   };
-  auto compute = [&](int j, const f32x4 (&wv)[NTWR]) {
+  // fragment buffers alternate with the ring slot (distinct registers, so the next chunk's ds_reads really
+  // issue before this chunk's MFMAs instead of waiting for their operands to die)
+  constexpr int XB = (DEPTH % 2 == 0) ? 2 : DEPTH;
+  decltype(xload(0, 0)) xr[XB][MT];
+  if (KC > 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xr[0][m] = xload(0, m);
+  }
+  auto compute = [&](int d, int j, const f32x4 (&wv)[NTWR]) {
+    const int nj = (j + 1 < KC) ? j + 1 : j;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xr[((d + 1) % DEPTH) % XB][m] = xload(nj, m);
     f32x4 x[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) x[m] = xfrag(j, m);
+    for (int m = 0; m < MT; ++m) x[m] = xmake(xr[d % XB][m]);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1009,24 +1048,24 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
     for (; j + 2 * DEPTH <= KC; j += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
-        compute(j + d, wq[d]);
+        compute(d, j + d, wq[d]);
         load(j + DEPTH + d, wq[d]);
       }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      compute(j + d, wq[d]);
+      compute(d, j + d, wq[d]);
       if (j + DEPTH + d < KC) load(j + DEPTH + d, wq[d]);
     }
     j += DEPTH;
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-      if (j + d < KC) compute(j + d, wq[d]);
+      if (j + d < KC) compute(d, j + d, wq[d]);
   } else {
-    for (int j = 0; j < KC; ++j) {
-      load(j, wq[0]);
-      compute(j, wq[0]);
-    }
+    // short stream (KC < DEPTH): chunk j uses ring slot j, so the fragment buffers still alternate
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < KC) { load(d, wq[d]); compute(d, d, wq[d]); }
   }
 }
 
@@ -1053,9 +1092,9 @@ __device__ __forceinline__ void stream_mfma_runs_prefetch(f32x4 (&wq)[DEPTH][NTW
   }
 }
 
-template <int NTW, int DEPTH, int MT, bool PRE, typename XF, typename TOF, typename EPI>
+template <int NTW, int DEPTH, int MT, bool PRE, typename XL, typename XM, typename TOF, typename EPI>
 __device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const float* __restrict__ wlane, size_t chunk_stride, int ntiles, int nruns,
-                                                 int KC, TOF tile_of, XF xfrag, EPI epilogue) {
+                                                 int KC, TOF tile_of, XL xload, XM xmake, EPI epilogue) {
   const int T = nruns * KC;
   if (T <= 0) return;
   int lr = 0, lj = 0;                                  // load cursor (run, chunk)
@@ -1076,10 +1115,17 @@ __device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const 
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int cr = 0, cj = 0;                                  // compute cursor
-  auto compute = [&](const f32x4 (&wv)[NTW]) {
+  constexpr int XB = (DEPTH % 2 == 0) ? 2 : DEPTH;
+  decltype(xload(0, 0)) xr[XB][MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) xr[0][m] = xload(0, m);
+  auto compute = [&](int d, const f32x4 (&wv)[NTW]) {
+    const int nj = (cj + 1 == KC) ? 0 : cj + 1;        // every run walks the same K chunks
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xr[((d + 1) % DEPTH) % XB][m] = xload(nj, m);
     f32x4 x[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) x[m] = xfrag(cj, m);
+    for (int m = 0; m < MT; ++m) x[m] = xmake(xr[d % XB][m]);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1104,24 +1150,23 @@ __device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const 
     for (; it + 2 * DEPTH <= T; it += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
-        compute(wq[d]);
+        compute(d, wq[d]);
         load(wq[d]);
       }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      compute(wq[d]);
+      compute(d, wq[d]);
       if (it + DEPTH + d < T) load(wq[d]);
     }
     it += DEPTH;
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-      if (it + d < T) compute(wq[d]);
+      if (it + d < T) compute(d, wq[d]);
   } else {
-    for (int it = 0; it < T; ++it) {
-      load(wq[0]);
-      compute(wq[0]);
-    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < T) { load(wq[d]); compute(d, wq[d]); }
   }
 }
 
@@ -1177,6 +1222,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
 
 #ifdef MKWS_FRONT_TIMING
+  const long long dbg_c0 = clock64();
   if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
 #endif
   // ---- stage the input tiles as fragments: s_X[j][m][lane] = X[row = 16m + c][16j + 4g .. +3]; epilogue constants ----
@@ -1199,7 +1245,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
     const int ngroups = (a.NTe + NTW - 1) / NTW;
     const int nruns = (ngroups > wave) ? (ngroups - wave + NWAVES - 1) / NWAVES : 0;
     auto tile_of = [&](int r) { return (wave + NWAVES * r) * NTW; };
-    auto xfrag = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
+    auto xmake = [](const f32x4& v) { return v; };
     auto epi = [&](int t0, const f32x4 (&acc)[NTW][MT]) {
 #pragma unroll
       for (int q = 0; q < NTW; ++q) {
@@ -1217,7 +1264,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
       }
     };
     f32x4 wqa[4][NTW];
-    stream_mfma_runs<NTW, 4, MT, false>(wqa, a.WpE + (size_t)g * 64 + c * 4, (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xfrag, epi);
+    stream_mfma_runs<NTW, 4, MT, false>(wqa, a.WpE + (size_t)g * 64 + c * 4, (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
   }
   __syncthreads();
 
@@ -1299,12 +1346,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
     f32x4 acc[3][1];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto xfrag = [&](int j, int) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c < G) v = *reinterpret_cast<const f32x4*>(s_S + (size_t)c * Cexp + 16 * (c1_j0 + j) + 4 * g);
-      return v;
-    };
-    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xfrag);
+    const float* srow = s_S + (size_t)(c < G ? c : 0) * Cexp + 16 * c1_j0 + 4 * g;      // columns c >= G are don't-care
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
     stream_mfma_runs_prefetch<NTW2, 3>(wq2, a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);   // C2's stream
     if (c < G) {
 #pragma unroll
@@ -1336,7 +1381,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   if (d_ntw > 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);
   {
     const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
-    auto xfrag = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
     auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
 #pragma unroll
       for (int q = 0; q < NTW2; ++q) {
@@ -1349,10 +1395,13 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
         }
       }
     };
-    stream_mfma_runs<NTW2, 3, 1, true>(wq2, a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xfrag, epi);
+    stream_mfma_runs<NTW2, 3, 1, true>(wq2, a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
   }
   __syncthreads();
 
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
+#endif
   // ---- phase D: gated project (+ residual): output row r = 16m + c lives in E row (r / HoWo)*HW + r % HoWo ----
   {
     const size_t cstride = (size_t)a.NTp * 256;
@@ -1366,9 +1415,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
       erow[m] = s_E + (size_t)(clip * HW + (r - clip * HoWo)) * LDE + 4 * g;
       grow[m] = s_G + (size_t)clip * Cexp + 4 * g;
     }
-    auto xfrag = [&](int j, int m) {
-      return *reinterpret_cast<const f32x4*>(erow[m] + 16 * j) * *reinterpret_cast<const f32x4*>(grow[m] + 16 * j);
+    struct EG { f32x4 e, g; };
+    auto xload = [&](int j, int m) {
+      return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow[m] + 16 * j)};
     };
+    auto xmake = [](const EG& v) { return v.e * v.g; };
     auto run = [&](auto ntw_tag) {
       constexpr int NTW = decltype(ntw_tag)::value;
       f32x4 acc[NTW][MTO];
@@ -1376,7 +1427,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
       for (int q = 0; q < NTW; ++q)
 #pragma unroll
         for (int m = 0; m < MTO; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      stream_mfma<NTW, 4, MTO, true>(acc, wqd, d_w, cstride, wave, NWAVES, a.NTp, KCx, xfrag);
+      stream_mfma<NTW, 4, MTO, true>(acc, wqd, d_w, cstride, wave, NWAVES, a.NTp, KCx, xload, xmake);
 #pragma unroll
       for (int q = 0; q < NTW; ++q) {
         const int t = wave + NWAVES * q;
@@ -1402,7 +1453,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   }
 #ifdef MKWS_FRONT_TIMING
   __syncthreads();
-  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
+  if (threadIdx.x == 0) { a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64(); a.dbg_t[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - dbg_c0); }
 #endif
 }
 
@@ -1840,10 +1891,10 @@ void launch_dw(hipStream_t s, const char* stage, const BlockPlan& b, const float
 bool front_supported(const BlockPlan& b) {
   const int ks = b.spec.kernel, st = b.spec.stride, kc = (b.spec.in_ch + 15) / 16;
   const int HW = b.H * b.W;
-  if (HW > 16) {
-    if ((size_t)HW * 36 * 4 > 76 * 1024) return false;
-    return (ks == 3 && st == 2 && kc == 1) || (ks == 3 && st == 1 && kc == 2) || (ks == 5 && st == 2 && kc == 2) ||
-           (ks == 5 && st == 1 && kc == 3) || (ks == 3 && st == 2 && kc == 3);
+  if (HW > 16) {       // one instance per layer geometry of the 49x40 network (image size is a template constant)
+    return (b.H == 25 && b.W == 20 && ks == 3 && st == 2 && kc == 1) || (b.H == 13 && b.W == 10 && ks == 3 && st == 1 && kc == 2) ||
+           (b.H == 13 && b.W == 10 && ks == 5 && st == 2 && kc == 2) || (b.H == 7 && b.W == 5 && ks == 5 && st == 1 && kc == 3) ||
+           (b.H == 7 && b.W == 5 && ks == 3 && st == 2 && kc == 3);
   }
   if (b.H == 4 && b.W == 3) return (ks == 3 && st == 1) || (ks == 5 && st == 1) || (ks == 5 && st == 2);
   if (b.H == 2 && b.W == 2) return (ks == 5 && st == 1) || (ks == 3 && st == 1);
@@ -1859,22 +1910,21 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   a.B = B; a.H = b.H; a.W = b.W; a.Ho = b.Ho; a.Wo = b.Wo; a.pt = b.pt; a.pl = b.pl; a.Cexp = b.ce;
   const int HW = b.H * b.W;
   const bool tiny = HW <= 16;
+  const int ks = b.spec.kernel, st = b.spec.stride, kc = b.expand.KC;
   int CC, G;
   if (tiny) {                       // 4x3 and 2x2 images: wide channel chunks, 128 LDS rows per block
     CC = 128;
     G = 128 / HW;
-  } else {                          // big images: 32 channels, as many clips as give ~256 rows / <= 44 KB
+  } else {                          // big images: 32 channels; clips per block so that the row strips fill 256 threads
     CC = 32;
-    G = 256 / HW; if (G < 1) G = 1; if (G > 8) G = 8;
-    while (G > 1 && (size_t)G * HW * (CC + 4) * 4 > 44 * 1024) --G;
+    G = (b.H == 25) ? 1 : (b.H == 13 ? (st == 1 ? 1 : 3) : (st == 1 ? 4 : 8));    // 2a | 2b, 3a | 3b, 4a (LDS: 2+ blocks per CU)
   }
   if (G > B) G = B;
   a.G = G;
-  const size_t lds = (((size_t)G * HW + 1) * (CC + 4) + 256 * 4 + (tiny ? (size_t)G * CC : CC)) * sizeof(float);
+  const size_t lds = (((size_t)G * HW + 1) * (CC + 4) + 256 * 4 + (size_t)G * CC + (tiny ? 0 : (size_t)ks * ks * CC)) * sizeof(float);
   const dim3 grid((B + G - 1) / G, (b.ce + CC - 1) / CC);
-  const int ks = b.spec.kernel, st = b.spec.stride, kc = b.expand.KC;
   ProfScope ps(stage, std::string("mbconv_front_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(CC) + "," +
-                          (tiny ? "0," + std::to_string(b.H) + "," + std::to_string(b.W) : std::to_string(kc) + ",0,0") + ">");
+                          (tiny ? "0," : std::to_string(kc) + ",") + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
 #ifdef MKWS_FRONT_TIMING
   static unsigned long long* d_t = nullptr;
   const size_t nblk = (size_t)grid.x * grid.y;
@@ -1884,11 +1934,11 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
 #define MKWS_FRONT(KS, S, C_, KC_, H_, W_) \
   hipLaunchKernelGGL((mbconv_front_kernel<KS, S, C_, KC_, H_, W_>), grid, dim3((KC_) > 0 ? 256 : 512), lds, s, a)
   if (!tiny) {
-    if (ks == 3 && st == 2 && kc == 1) MKWS_FRONT(3, 2, 32, 1, 0, 0);        // 2a
-    else if (ks == 3 && st == 1 && kc == 2) MKWS_FRONT(3, 1, 32, 2, 0, 0);   // 2b
-    else if (ks == 5 && st == 2 && kc == 2) MKWS_FRONT(5, 2, 32, 2, 0, 0);   // 3a
-    else if (ks == 5 && st == 1 && kc == 3) MKWS_FRONT(5, 1, 32, 3, 0, 0);   // 3b
-    else if (ks == 3 && st == 2 && kc == 3) MKWS_FRONT(3, 2, 32, 3, 0, 0);   // 4a
+    if (ks == 3 && st == 2 && kc == 1) MKWS_FRONT(3, 2, 32, 1, 25, 20);        // 2a
+    else if (ks == 3 && st == 1 && kc == 2) MKWS_FRONT(3, 1, 32, 2, 13, 10);   // 2b
+    else if (ks == 5 && st == 2 && kc == 2) MKWS_FRONT(5, 2, 32, 2, 13, 10);   // 3a
+    else if (ks == 5 && st == 1 && kc == 3) MKWS_FRONT(5, 1, 32, 3, 7, 5);     // 3b
+    else if (ks == 3 && st == 2 && kc == 3) MKWS_FRONT(3, 2, 32, 3, 7, 5);     // 4a
   } else if (b.H == 4 && b.W == 3) {
     if (ks == 3 && st == 1) MKWS_FRONT(3, 1, 128, 0, 4, 3);                  // 4b, 4c
     else if (ks == 5 && st == 1) MKWS_FRONT(5, 1, 128, 0, 4, 3);             // 5a, 5b, 5c
@@ -1977,6 +2027,8 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
       if (h[8 * i] < t0) t0 = h[8 * i];
       if (h[8 * i + 6] > t1) t1 = h[8 * i + 6];
     }
+    double clk = 0; for (size_t i = 0; i < grid.x; ++i) clk += (double)h[8 * i + 7] / ((double)(h[8 * i + 6] - h[8 * i]) / 100.0);
+    fprintf(stderr, "[block-timing] shader clock %.0f MHz\n", clk / grid.x);
     fprintf(stderr, "[block-timing] %s blocks %u: stage %.2f  A %.2f  B %.2f  C1 %.2f  C2 %.2f  D %.2f us; span %.2f us\n", stage, grid.x,
             ph[0] / grid.x / 100.0, ph[1] / grid.x / 100.0, ph[2] / grid.x / 100.0, ph[3] / grid.x / 100.0, ph[4] / grid.x / 100.0,
             ph[5] / grid.x / 100.0, (double)(t1 - t0) / 100.0);
