@@ -171,6 +171,8 @@ def main():
             else:
                 if kernel == "stem_dw_kernel":
                     cost = costs["stem_dw"]
+                elif kernel == "stem_block1a_kernel":
+                    cost = costs["stem_block1a"]
                 elif kernel.startswith("mbconv_front"):
                     cost = costs[stage.replace("_dw", "_front")]
                 elif kernel.startswith("mbconv_block"):

@@ -30,6 +30,9 @@ def stage_costs(B):
     c["stem"] = (2 * B * h * w * 9 * 32, 4 * (B * 49 * 40 + B * h * w * 32 + 9 * 32))
     # fused stem + block-1a depthwise launch: spectrogram in, depthwise output out
     c["stem_dw"] = (c["stem"][0] + 2 * B * h * w * 9 * 32, 4 * (B * 49 * 40 + B * h * w * 32 + 2 * 9 * 32 + B * 32))
+    # stem + whole block 1a in one launch: spectrogram in, block-1a output [25,20,16] out
+    c["stem_block1a"] = (c["stem_dw"][0] + 2 * B * 2 * 32 * 8 + 2 * B * h * w * 32 * 16,
+                         4 * (B * 49 * 40 + B * h * w * 16 + 2 * 9 * 32 + 2 * 32 * 8 + 32 * 16))
     for name, cin, cout, k, s, e in BLOCKS:
         p = "block" + name
         ce, se = cin * e, max(1, int(cin * 0.25))

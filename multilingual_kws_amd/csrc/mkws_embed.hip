@@ -183,6 +183,160 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem + the whole of block 1a (no expand conv: depthwise 3x3 -> SE -> gated 32->16 projection) for one clip
+// per workgroup.  Spectrogram [49,40] in, block-1a output [25,20,16] out; the 64 KB stem output and the 64 KB
+// depthwise output stay in LDS, so the network's two largest activations never reach HBM.
+//   1. input tile (+Rescaling/Normalization) -> LDS;  2. stem 3x3 s2 conv + BN + swish -> s_E (zero halo)
+//   3. depthwise 3x3 + BN + swish -> s_D [500][36], channel sums by shuffles
+//   4. SE: r = swish(mean.Wr + br) (8 units), gate = sigmoid(r.We + be)                    (VALU, tiny)
+//   5. projection on the fp32 MFMA: weights (A operand, 2 K chunks) in registers, (D * gate) rows from LDS
+__global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restrict__ spec, const float* __restrict__ w /*[9][32]*/,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, float norm_mean,
+                                                           float norm_std, const float* __restrict__ Wd /*[9][32]*/, const float* __restrict__ scD,
+                                                           const float* __restrict__ shD, const float* __restrict__ Wr /*[32][se]*/,
+                                                           const float* __restrict__ br, const float* __restrict__ We /*[se][32]*/,
+                                                           const float* __restrict__ be, int se, const float* __restrict__ WpP,
+                                                           const float* __restrict__ scP, const float* __restrict__ shP, float* __restrict__ Y) {
+  constexpr int H = kInH, W = kInW, Ho = 25, Wo = 20, C = 32, CO = 16, NTHR = 512;
+  constexpr int TH = H + 2, TW = W + 1;                 // input tile with halo: rows -1..49, cols 0..40
+  constexpr int EH = Ho + 2, EW = Wo + 2;               // stem-output tile with a 1-pixel zero halo
+  constexpr int LDD = C + 4;                            // depthwise-output row stride (conflict-free MFMA operand reads)
+  extern __shared__ __attribute__((aligned(16))) float s_sb[];
+  float* s_in = s_sb;                                   // [TH][TW]
+  float* s_E = s_in + ((TH * TW + 3) & ~3);             // [EH][EW][C]
+  float* s_D = s_E + EH * EW * C;                       // [Ho*Wo][LDD]
+  f32x4* s_red = reinterpret_cast<f32x4*>(s_D + Ho * Wo * LDD);   // [8 waves][8 quads]
+  float* s_mean = reinterpret_cast<float*>(s_red + 64);  // [32] means, [16] r, [32] gate
+  float* s_r = s_mean + C;
+  float* s_gate = s_r + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t b = blockIdx.x;
+  const float* img = spec + b * H * W;
+  for (int i = tid; i < TH * TW; i += NTHR) {
+    const int r = i / TW - 1, cc = i % TW;
+    float v = 0.0f;
+    if (r >= 0 && r < H && cc < W) v = __fdiv_rn(img[r * W + cc] * (1.0f / 255.0f) - norm_mean, norm_std);
+    s_in[i] = v;
+  }
+  for (int i = tid; i < EH * EW * C / 4; i += NTHR) {    // zero the halo (interior is overwritten below)
+    const int pix = i / (C / 4);
+    const int r = pix / EW, cc = pix % EW;
+    if (r == 0 || r == EH - 1 || cc == 0 || cc == EW - 1) reinterpret_cast<f32x4*>(s_E)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // SE and projection constants are requested now and consumed after the convolutions
+  const int q = tid & 7;                                 // channel quad of this thread
+  const int g = lane >> 4, c = lane & 15;
+  const float wr_pre = (tid < C * 8 && (tid & 7) < se) ? Wr[(tid >> 3) * se + (tid & 7)] : 0.0f;    // thread (ch = tid>>3, n = tid&7)
+  const float we_pre = (tid < 8 * C && (tid >> 5) < se) ? We[tid] : 0.0f;                            // thread (n = tid>>5, ch = tid&31)
+  const float br_pre = (tid < se) ? br[tid] : 0.0f;
+  const float be_pre = (tid < C) ? be[tid] : 0.0f;
+  f32x4 wp[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wp[j] = *reinterpret_cast<const f32x4*>(WpP + ((size_t)j * 4 + g) * 64 + c * 4);
+  const f32x4 scp = *reinterpret_cast<const f32x4*>(scP + 4 * g), shp = *reinterpret_cast<const f32x4*>(shP + 4 * g);
+  __syncthreads();
+  {
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(w + t * C + q * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+    for (int pix = tid >> 3; pix < Ho * Wo; pix += NTHR / 8) {
+      const int oh = pix / Wo, ow = pix % Wo;
+      const float* in0 = s_in + (2 * oh) * TW + 2 * ow;   // tile row 2*oh == image row 2*oh - 1
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += wk[i * 3 + j] * in0[i * TW + j];
+      f32x4 y = acc * sc + sh;
+      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+      *reinterpret_cast<f32x4*>(s_E + ((size_t)(oh + 1) * EW + (ow + 1)) * C + q * 4) = y;
+    }
+  }
+  __syncthreads();
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+  {
+    f32x4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(Wd + t * C + q * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scD + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shD + q * 4);
+    for (int pix = tid >> 3; pix < Ho * Wo; pix += NTHR / 8) {
+      const int oh = pix / Wo, ow = pix % Wo;
+      const float* e0 = s_E + ((size_t)oh * EW + ow) * C + q * 4;     // top-left tap (halo offset cancels the -1)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + j) * C) * wk[i * 3 + j];
+      f32x4 y = acc * sc + sh;
+      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+      *reinterpret_cast<f32x4*>(s_D + (size_t)pix * LDD + q * 4) = y;
+      ssum += y;
+    }
+  }
+  // channel sums: lanes of a wave that share the quad fold by shuffles, the 8 wave partials in fixed order
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) {
+    ssum.x += __shfl_xor(ssum.x, m); ssum.y += __shfl_xor(ssum.y, m);
+    ssum.z += __shfl_xor(ssum.z, m); ssum.w += __shfl_xor(ssum.w, m);
+  }
+  if (lane < 8) s_red[wave * 8 + lane] = ssum;
+  __syncthreads();
+  if (tid < 8) {
+    f32x4 t = s_red[tid];
+    for (int k = 1; k < NTHR / 64; ++k) t += s_red[k * 8 + tid];
+    *reinterpret_cast<f32x4*>(s_mean + tid * 4) = t * (1.0f / (Ho * Wo));
+  }
+  __syncthreads();
+  // SE reduce: thread (ch, n) contributes mean[ch]*Wr[ch][n]; the 32 channels of a unit fold by shuffles
+  if (tid < C * 8) {
+    float v = s_mean[tid >> 3] * wr_pre;
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) v += __shfl_xor(v, m);                 // 8 channels per wave
+    if (lane < 8) reinterpret_cast<float*>(s_red)[wave * 8 + lane] = v;      // waves 0..3 hold channels 8w..8w+7
+  }
+  __syncthreads();
+  if (tid < 8) {
+    const float* pr = reinterpret_cast<const float*>(s_red);
+    const float v = ((pr[tid] + pr[8 + tid]) + (pr[16 + tid] + pr[24 + tid])) + br_pre;
+    s_r[tid] = (tid < se) ? swishf_(v) : 0.0f;
+  }
+  __syncthreads();
+  // SE expand: thread (n, ch) -> r[n]*We[n][ch]; the 8 units of a channel live in 8 different half-waves
+  if (tid < 8 * C) reinterpret_cast<float*>(s_red)[tid] = s_r[tid >> 5] * we_pre;
+  __syncthreads();
+  if (tid < C) {
+    const float* pe = reinterpret_cast<const float*>(s_red);
+    float v = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v += pe[n * C + tid];
+    s_gate[tid] = sigmoidf_(v + be_pre);
+  }
+  __syncthreads();
+  // projection: Y[500, 16] = BN((D * gate)[500, 32] . Wp[32, 16])
+  {
+    f32x4 gq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gq[j] = *reinterpret_cast<const f32x4*>(s_gate + 16 * j + 4 * g);
+    float* yout = Y + b * Ho * Wo * CO;
+    for (int t = wave; t < (Ho * Wo + 15) / 16; t += NTHR / 64) {
+      const int row = t * 16 + c;
+      const int rr = row < Ho * Wo ? row : Ho * Wo - 1;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(s_D + (size_t)rr * LDD + 16 * j + 4 * g) * gq[j];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][s4], x[s4], acc, 0, 0, 0);
+      }
+      if (row < Ho * Wo) *reinterpret_cast<f32x4*>(yout + (size_t)row * CO + 4 * g) = acc * scp + shp;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1x1 conv / dense GEMM.  Y[m, n] = act((sum_k X[m,k] * gate[m/HW, k] * W[k,n]) * scale[n] + shift[n]) + R[m,n]
 // Packed weights (chunk-major): Wp[((j*NTtot + nt)*4 + g)*64 + c*4 + s] = W[16j + 4g + s][16nt + c], zero
 // padded -- the NT tiles a wave needs for one K chunk are contiguous, consecutive n-blocks read consecutive
@@ -340,6 +494,137 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
       if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
       *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = y;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gated projection conv of the big-image MBConv blocks (1a .. 4a): K = Cexp <= 240, N = Cout <= 80, M = B*H*W
+// up to 512 000.  The activation matrix is the only large operand, so it must cross HBM exactly once:
+//   * the whole packed weight matrix (<= 75 KB) is staged in LDS once per workgroup;
+//   * a wave owns ALL n-tiles of its rows (pw_gemm_kernel splits N over waves and re-reads X per split);
+//   * waves grid-stride over groups of MT row tiles; the (group, K chunk) sequence is flattened into one
+//     stream with a D-deep register ring (X and SE-gate fragments), so the next group's first chunks are in
+//     flight while this group finishes -- K is only 2..15 chunks, a per-group prologue would dominate;
+//   * residual rows ride the same stream (requested D chunks into their group, consumed at its epilogue),
+//     so the epilogue issues no loads and the ring never drains.
+// Same accumulation order per output row as pw_gemm_kernel (K chunks ascending): results are bit-identical.
+template <int NT, int MT>
+__global__ __launch_bounds__(512) void pw_proj_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_pw[];
+  constexpr int NWAVES = 8, D = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int KC = a.KC;
+  float* s_sc = s_pw + (size_t)KC * NT * 256;                  // [NT*16] scale, [NT*16] shift
+  float* s_sh = s_sc + NT * 16;
+  for (int i = tid; i < KC * NT * 64; i += NWAVES * 64)
+    reinterpret_cast<f32x4*>(s_pw)[i] = reinterpret_cast<const f32x4*>(a.Wp)[i];
+  if (tid < NT * 16) { s_sc[tid] = a.scale[tid]; s_sh[tid] = a.shift[tid]; }
+  __syncthreads();
+
+  const int ngroups = (a.M + 16 * MT - 1) / (16 * MT);
+  const int wid = blockIdx.x * NWAVES + wave, nw = gridDim.x * NWAVES;
+  const int nmy = (ngroups > wid) ? (ngroups - wid + nw - 1) / nw : 0;
+  const int T = nmy * KC;
+  if (T == 0) return;
+  const bool hasR = a.R != nullptr;
+
+  struct Slot { f32x4 x[MT], gt[MT]; };
+  Slot ring[D];
+  f32x4 rq[MT][NT];                                            // residual fragments of the group being computed
+  // load cursor
+  int lgi = 0, lj = 0;
+  const float* xp[MT]; const float* gp[MT]; const float* rp[MT];
+  auto set_ptrs = [&](int gi) {
+    int grp = wid + nw * gi;
+    if (grp >= ngroups) grp = ngroups - 1;                     // past the end: harmless re-read, never consumed
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      int row = (grp * MT + m) * 16 + c;
+      if (row >= a.M) row = a.M - 1;
+      xp[m] = a.X + (size_t)row * a.ldx + 4 * g;
+      gp[m] = a.gate + (size_t)(row / a.HW) * a.K + 4 * g;
+      rp[m] = hasR ? a.R + (size_t)row * a.ldr + 4 * g : nullptr;
+    }
+  };
+  set_ptrs(0);
+  const int jr = (KC > D) ? D : KC - 1;                        // chunk at which a group's residual rows are requested
+  auto load = [&](Slot& sl) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      sl.x[m] = *reinterpret_cast<const f32x4*>(xp[m] + 16 * lj);
+      sl.gt[m] = *reinterpret_cast<const f32x4*>(gp[m] + 16 * lj);
+    }
+    if (hasR && lj == jr && KC > D) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) rq[m][nt] = *reinterpret_cast<const f32x4*>(rp[m] + (nt * 16 < a.N ? nt * 16 : 0));
+    }
+    if (++lj == KC) { lj = 0; ++lgi; set_ptrs(lgi); }
+  };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int cgi = 0, cj = 0;
+  auto compute = [&](const Slot& sl) {
+    f32x4 w[NT], xv[MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4*>(s_pw + (((size_t)cj * NT + nt) * 4 + g) * 64 + c * 4);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xv[m] = sl.x[m] * sl.gt[m];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt][s], xv[m][s], acc[m][nt], 0, 0, 0);
+    if (++cj == KC) {
+      const int grp = wid + nw * cgi;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row = (grp * MT + m) * 16 + c;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = nt * 16 + 4 * g;
+          f32x4 y = acc[m][nt] * *reinterpret_cast<const f32x4*>(s_sc + n) + *reinterpret_cast<const f32x4*>(s_sh + n);
+          if (hasR) {
+            if (KC > D) y += rq[m][nt];
+            else if (row < a.M && n < a.N) y += *reinterpret_cast<const f32x4*>(a.R + (size_t)row * a.ldr + n);
+          }
+          if (row < a.M && n < a.N) *reinterpret_cast<f32x4*>(a.Y + (size_t)row * a.ldy + n) = y;
+          acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      cj = 0; ++cgi;
+    }
+  };
+  if (T >= D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(ring[d]);
+    int it = 0;
+    for (; it + 2 * D <= T; it += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        compute(ring[d]);
+        load(ring[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      compute(ring[d]);
+      if (it + D + d < T) load(ring[d]);
+    }
+    it += D;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (it + d < T) compute(ring[d]);
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < T) { load(ring[d]); compute(ring[d]); }
   }
 }
 
@@ -1594,7 +1879,7 @@ struct GemmLayer {   // device pointers into the weight blob
   int K = 0, N = 0, KC = 0, NTtot = 0;
 };
 struct DwLayer { const float* Wd = nullptr; const float* scale = nullptr; const float* shift = nullptr; };
-struct SeLayer { const float* Wr = nullptr; const float* WrP = nullptr; const float* br = nullptr; const float* WeP = nullptr; const float* be = nullptr; int se = 0, KCr = 0, NTR = 0, NTe = 0; };
+struct SeLayer { const float* Wr = nullptr; const float* We = nullptr; const float* WrP = nullptr; const float* br = nullptr; const float* WeP = nullptr; const float* be = nullptr; int se = 0, KCr = 0, NTR = 0, NTe = 0; };
 
 struct BlockPlan {
   MBConvSpec spec;
@@ -1626,10 +1911,11 @@ struct mkws_embed {
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
+  int proj_stream = 1;             // gated projection convs of blocks 1a..4a: 1 = pw_proj_kernel (X streamed once, weights in LDS), 0 = pw_gemm_kernel
   int gemm_lds = 0;                // 1x1-conv/dense GEMM: 0 = direct-to-register kernel (faster on MI355X, profiles/r01_notes.md), 1 = planner may pick the LDS-staged kernel
   bool fuse_se = false;            // SE squeeze -> reduce-FC partials inside the producing kernel (saves the se_reduce launch, but the
                                    // serial tails cost more than the launch on MI355X: 624k vs 643k clips/s; kept for A/B)
-  bool fuse_stem = true;           // stem conv + block-1a depthwise in one kernel (stem_dw_kernel)
+  int fuse_stem = 2;               // 2: stem + whole block 1a in one kernel (stem_block1a_kernel); 1: stem + block-1a depthwise (stem_dw_kernel); 0: separate
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
@@ -1770,6 +2056,7 @@ static const LdsCfg kLdsCfgs[] = {
     {7, 1, 4, 4, 3},   //  64 x 192
 };
 constexpr int kNumLdsCfgs = sizeof(kLdsCfgs) / sizeof(kLdsCfgs[0]);
+static thread_local int g_proj_stream = 1;        // gated projections through pw_proj_kernel (option proj_stream)
 static thread_local int g_gemm_lds_mode = 0;      // 0: never, 1: planner decides, >= 100: force config (mode - 100)
 
 template <bool GATE>
@@ -1822,6 +2109,27 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
   if (const char* f = getenv("MKWS_GEMM_FORCE")) {       // experiment hook: "Mmax,MT,NT,SK" applies to layers with Mplan <= Mmax
     int mmax = 0, fmt = 0, fnt = 0, fsk = 0;
     if (sscanf(f, "%d,%d,%d,%d", &mmax, &fmt, &fnt, &fsk) == 4 && Mplan <= mmax && fnt <= L.NTtot) tc = {fmt, fnt, fsk};
+  }
+  // gated projection of a big-image block: stream X once, weights in LDS (pw_proj_kernel)
+  if (g_proj_stream && gate && L.NTtot <= 5 && (L.K & 15) == 0 && (size_t)L.KC * L.NTtot * 1024 <= 80 * 1024) {
+    const int groups2 = (Mplan + 31) / 32;
+    const int MT = (groups2 >= 2048) ? 2 : 1;                  // planned on max_batch: same choice for every batch size
+    const int ngroups = (M + 16 * MT - 1) / (16 * MT);
+    const size_t lds = ((size_t)L.KC * L.NTtot * 256 + 2 * L.NTtot * 16) * sizeof(float);
+    int per_cu = (int)((150 * 1024) / (lds + 1024)); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
+    int nblk = (ngroups + 7) / 8; if (nblk > 256 * per_cu) nblk = 256 * per_cu;
+    ProfScope ps(stage, std::string("pw_proj_kernel<") + std::to_string(L.NTtot) + "," + std::to_string(MT) + ">");
+#define MKWS_PJ(NT_, MT_) do { \
+      static bool attr_done = false; \
+      if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_proj_kernel<NT_, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_done = true; } \
+      hipLaunchKernelGGL((pw_proj_kernel<NT_, MT_>), dim3(nblk), dim3(512), lds, s, a); } while (0)
+    if (MT == 2) {
+      switch (L.NTtot) { case 1: MKWS_PJ(1, 2); break; case 2: MKWS_PJ(2, 2); break; case 3: MKWS_PJ(3, 2); break; case 4: MKWS_PJ(4, 2); break; default: MKWS_PJ(5, 2); break; }
+    } else {
+      switch (L.NTtot) { case 1: MKWS_PJ(1, 1); break; case 2: MKWS_PJ(2, 1); break; case 3: MKWS_PJ(3, 1); break; case 4: MKWS_PJ(4, 1); break; default: MKWS_PJ(5, 1); break; }
+    }
+#undef MKWS_PJ
+    return;
   }
   // LDS-staged kernel?
   int lds_sk = 1;
@@ -2081,13 +2389,26 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
                 const float** tap_src, size_t* tap_count) {
   g_splitk_ws = em->splitk_ws; g_splitk_ws_floats = em->splitk_floats;
   g_gemm_lds_mode = em->gemm_lds;
+  g_proj_stream = em->proj_stream;
   auto hit = [&](const std::string& name, const float* p, size_t n) {
     if (stop && name == stop) { *tap_src = p; *tap_count = n; return true; }
     return false;
   };
   const bool want_stem_tap = stop && strcmp(stop, "stem") == 0;
   const bool fused_stem = em->fuse_stem && !want_stem_tap;
-  if (fused_stem) {
+  const BlockPlan& blk1a = em->blocks[0];
+  // whole block 1a with the stem (its inner taps come from the two-kernel path); SE is at most 8 units wide there
+  const bool fused_1a = fused_stem && em->fuse_stem >= 2 && blk1a.se.se <= 8 && !blk1a.has_expand && blk1a.spec.out_ch == 16 &&
+                        !(stop && (strcmp(stop, "block1a_dw") == 0 || strcmp(stop, "block1a_gate") == 0));
+  if (fused_1a) {
+    ProfScope ps("block1a", "stem_block1a_kernel");
+    const size_t lds = ((size_t)((51 * 41 + 3) & ~3) + 27 * 22 * 32 + 500 * 36 + 64 * 4 + 32 + 16 + 32) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_block1a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    hipLaunchKernelGGL(stem_block1a_kernel, dim3(B), dim3(512), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
+                       em->norm_std, blk1a.dw.Wd, blk1a.dw.scale, blk1a.dw.shift, blk1a.se.Wr, blk1a.se.br, blk1a.se.We, blk1a.se.be,
+                       blk1a.se.se, blk1a.project.Wp, blk1a.project.scale, blk1a.project.shift, em->bufB);
+  } else if (fused_stem) {
     // stem + block-1a depthwise in one launch: bufD <- dw output, sums <- SE sums (bufA is not produced)
     const BlockPlan& b1 = em->blocks[0];
     ProfScope ps("block1a_dw", "stem_dw_kernel");
@@ -2110,6 +2431,11 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     const BlockPlan& b = em->blocks[i];
     const std::string p = std::string("block") + b.spec.name;
     const int Min = B * b.H * b.W, Mout = B * b.Ho * b.Wo;
+    if (i == 0 && fused_1a) {          // already computed into nxt (= bufB) by stem_block1a_kernel
+      if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
+      float* t = cur; cur = nxt; nxt = t;
+      continue;
+    }
     const bool want_expand_tap = stop && (p + "_expand") == stop;
     int se_chunks = 0;            // > 0: SE reduce partials were already produced by the upstream kernel
     if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
@@ -2226,7 +2552,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   fold_bn(T("stem_bn/gamma"), T("stem_bn/beta"), T("stem_bn/moving_mean"), T("stem_bn/moving_variance"), kStemCh, &sc, &sh);
   const size_t o_stem_sc = pk.add(sc.data(), kStemCh), o_stem_sh = pk.add(sh.data(), kStemCh);
 
-  struct BlockOff { GemmOff expand, project, se_r, se_e; size_t dw_w, dw_sc, dw_sh, se_wr; } bo[kNumBlocks];
+  struct BlockOff { GemmOff expand, project, se_r, se_e; size_t dw_w, dw_sc, dw_sh, se_wr, se_we; } bo[kNumBlocks];
   int H = 25, W = 20;
   for (int i = 0; i < kNumBlocks; ++i) {
     BlockPlan& b = em->blocks[i];
@@ -2260,6 +2586,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
       std::vector<float> one_r(se, 1.0f), bias_r(T(p + "_se_reduce/bias"), T(p + "_se_reduce/bias") + se);
       bo[i].se_r = pack_gemm(pk, T(p + "_se_reduce/kernel"), b.ce, se, one_r, bias_r);
       bo[i].se_wr = pk.add(T(p + "_se_reduce/kernel"), (size_t)b.ce * se);     // plain [C][se] for the fused partials
+      bo[i].se_we = pk.add(T(p + "_se_expand/kernel"), (size_t)se * b.ce);     // plain [se][C] (stem_block1a_kernel)
       std::vector<float> one_e(b.ce, 1.0f), bias_e(T(p + "_se_expand/bias"), T(p + "_se_expand/bias") + b.ce);
       bo[i].se_e = pack_gemm(pk, T(p + "_se_expand/kernel"), se, b.ce, one_e, bias_e);
       if (bo[i].se_r.NTtot > 3) { delete em; return fail(MKWS_ERR_UNSUPPORTED, "SE width %d > 48", se); }
@@ -2293,7 +2620,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     if (b.has_expand) b.expand = G(bo[i].expand);
     b.project = G(bo[i].project);
     b.dw.Wd = d + bo[i].dw_w; b.dw.scale = d + bo[i].dw_sc; b.dw.shift = d + bo[i].dw_sh;
-    b.se.Wr = d + bo[i].se_wr; b.se.WrP = d + bo[i].se_r.Wp; b.se.br = d + bo[i].se_r.shift; b.se.WeP = d + bo[i].se_e.Wp; b.se.be = d + bo[i].se_e.shift;
+    b.se.Wr = d + bo[i].se_wr; b.se.We = d + bo[i].se_we; b.se.WrP = d + bo[i].se_r.Wp; b.se.br = d + bo[i].se_r.shift; b.se.WeP = d + bo[i].se_e.Wp; b.se.be = d + bo[i].se_e.shift;
     b.se.KCr = bo[i].se_r.KC; b.se.NTR = bo[i].se_r.NTtot; b.se.NTe = bo[i].se_e.NTtot;
     // the expand FC's K (= se) is padded to NTR*16 by pack_gemm: KC of se_e == NTR by construction
   }
@@ -2338,8 +2665,9 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (!em || !name) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
   if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
-  if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value != 0; return MKWS_OK; }
+  if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "gemm_lds") == 0) { em->gemm_lds = value; return MKWS_OK; }
+  if (strcmp(name, "proj_stream") == 0) { em->proj_stream = value; return MKWS_OK; }
   if (strcmp(name, "fuse_se") == 0) { em->fuse_se = value != 0; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }

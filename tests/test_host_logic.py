@@ -104,7 +104,7 @@ def test_synthetic_clip_generator_is_pinned():
 
 def test_stage_costs_match_survey_totals():
     c = arch.stage_costs(1)
-    fused = lambda k: k.endswith("_front") or k.endswith("_block") or k == "stem_dw"      # fused launches re-book their stages
+    fused = lambda k: k.endswith("_front") or k.endswith("_block") or k in ("stem_dw", "stem_block1a")      # fused launches re-book their stages
     assert sum(f for k, (f, _) in c.items() if not fused(k)) - c["gap"][0] == 2 * 32974496
     assert c["block5b_block"][0] == sum(c["block5b" + sfx][0] for sfx in ("_expand", "_dw", "_gate", ""))
     assert c["block2a_front"][0] == c["block2a_expand"][0] + c["block2a_dw"][0]        # fused launch = both stages' flops
