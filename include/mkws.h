@@ -150,12 +150,14 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 loads; measured slower on MI355X for these shapes); 100+i forces LDS configuration i.
  *   "fuse_se" (default 0): 1 = the partial sums of the SE reduce FC are produced by the depthwise kernels
  *                 themselves (one SE launch per block instead of two; measured slower on MI355X).
- *   "fuse_stem" (default 1): stem conv + block-1a depthwise in one kernel (stem output stays in LDS).
  *   "fuse_block" (default 2): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
  *                 ONE kernel, 4 clips per workgroup, activations resident in LDS; 1 = only the 2x2 blocks
  *                 (6b..7a); 0 = the multi-kernel path everywhere.
- *   "proj_stream" (default 1): gated projection convs of the big-image blocks (1a..4a) use the streaming kernel
- *                 (activations cross HBM once, packed weights in LDS); 0 = the generic GEMM kernel. */
+ *   "proj_stream" (default 0): 1 = gated projection convs of the big-image blocks (2a..4a) use the streaming
+ *                 kernel (activations cross HBM once, packed weights in LDS; measured equal on MI355X);
+ *                 0 = the generic GEMM kernel.
+ *   "fuse_stem" (default 2): 2 = stem conv + the whole of block 1a in one kernel (one clip per workgroup, both
+ *                 25x20x32 activations stay in LDS); 1 = stem conv + block-1a depthwise; 0 = separate kernels. */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
 
 /* Measurement aid (NOT capturable: it records a hipEvent pair around every kernel launch and

@@ -27,6 +27,10 @@
 #include <type_traits>
 #include <vector>
 
+// fp32 multiply-adds of the convolution / epilogue code may fuse (v_pk_fma_f32): one rounding instead of two,
+// like the MFMA accumulation itself; the build's default (-ffp-contract=off) stays in force for the other files.
+#pragma clang fp contract(fast)
+
 namespace mkws {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -1911,7 +1915,7 @@ struct mkws_embed {
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
-  int proj_stream = 1;             // gated projection convs of blocks 1a..4a: 1 = pw_proj_kernel (X streamed once, weights in LDS), 0 = pw_gemm_kernel
+  int proj_stream = 0;             // gated projection convs of blocks 2a..4a: 1 = pw_proj_kernel (X streamed once, weights in LDS; measured equal), 0 = pw_gemm_kernel
   int gemm_lds = 0;                // 1x1-conv/dense GEMM: 0 = direct-to-register kernel (faster on MI355X, profiles/r01_notes.md), 1 = planner may pick the LDS-staged kernel
   bool fuse_se = false;            // SE squeeze -> reduce-FC partials inside the producing kernel (saves the se_reduce launch, but the
                                    // serial tails cost more than the launch on MI355X: 624k vs 643k clips/s; kept for A/B)
@@ -2056,7 +2060,7 @@ static const LdsCfg kLdsCfgs[] = {
     {7, 1, 4, 4, 3},   //  64 x 192
 };
 constexpr int kNumLdsCfgs = sizeof(kLdsCfgs) / sizeof(kLdsCfgs[0]);
-static thread_local int g_proj_stream = 1;        // gated projections through pw_proj_kernel (option proj_stream)
+static thread_local int g_proj_stream = 0;        // gated projections through pw_proj_kernel (option proj_stream)
 static thread_local int g_gemm_lds_mode = 0;      // 0: never, 1: planner decides, >= 100: force config (mode - 100)
 
 template <bool GATE>
