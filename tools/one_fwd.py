@@ -1,14 +1,18 @@
-import sys, os
+"""Four identical passes of the hot path (frontend + embedding forward, B = 1024) -- the workload the PMC and
+phase-timing runs wrap (tools/pmc_traffic.sh, tools/gpu_round.sh, MKWS_LIB=...timing.so)."""
+import os
+import sys
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
-from multilingual_kws_amd import weights
+import torch
+from multilingual_kws_amd import synth, weights
 from multilingual_kws_amd.embedding_model import EmbeddingModel
+from multilingual_kws_amd.frontend import Frontend
+
 dev = torch.device("cuda:0")
-blob = weights.synthetic_blob()
 B = 1024
-em = EmbeddingModel(blob, max_batch=B)
-rng = np.random.default_rng(0)
-x = torch.from_numpy((rng.integers(0, 670, size=(B, 49, 40)).astype(np.float32) * np.float32(10/256))).to(dev)
-for _ in range(3):
-    em.forward(x)
+em = EmbeddingModel(weights.synthetic_blob(), max_batch=B)
+fe = Frontend(max_samples=16000)
+audio = torch.from_numpy(synth.clips_float32(B)).to(dev)
+for _ in range(4):
+    em.forward(fe.forward(audio))
 torch.cuda.synchronize()
