@@ -106,6 +106,28 @@ def _read_wav(path, desired_samples=-1):
         return decode_wav(f.read(), desired_samples)[0]
 
 
+def load_unknown_files(unknown_words_dir, listing="unknown_files.txt"):
+    """The unknown-words bank layout the reference's few-shot CLI consumes (run.py:272-278): a directory holding
+    `unknown_files.txt`, one WAV path per line relative to that directory.  Returns absolute-ish path strings."""
+    import os
+    root = str(unknown_words_dir)
+    lst = os.path.join(root, listing)
+    if not os.path.isfile(lst):
+        raise FileNotFoundError(f"{lst} not found")
+    with open(lst, "r") as fh:
+        return [os.path.join(root, w) for w in fh.read().splitlines() if w.strip()]
+
+
+def check_one_second_16k(filepath):
+    """What run.py:259-268 asks `soxi` (absent here) about every training sample: a 16 kHz, 1 s, PCM16 WAV.
+    Raises ValueError otherwise."""
+    with open(filepath, "rb") as f:
+        audio, rate = decode_wav(f.read(), -1)
+    if rate != 16000 or audio.shape[0] != 16000:
+        raise ValueError(f"{filepath} appears to not be a 16KHz 1-second wav file ({rate} Hz, {audio.shape[0]} samples)")
+    return True
+
+
 def file2spec(model_settings, filepath):
     """WAV file -> spectrogram [frames, channels] (numpy); background-noise variant: AudioDataset.file2spec_w_bg."""
     audio = _read_wav(filepath, model_settings["desired_samples"])

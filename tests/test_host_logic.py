@@ -111,3 +111,25 @@ def test_stage_costs_match_survey_totals():
     assert c["block2a_front"][1] < c["block2a_expand"][1]                               # ...without the expanded tensor's bytes
     assert arch.FRONTEND_BYTES_PER_CLIP_F32 == 71840
     assert c["block2a_expand"][0] == 2 * 768000 and c["block7a"][0] == 2 * 1474560
+
+
+def test_unknown_files_bank_and_sample_check(tmp_path):
+    """run.py:259-278 on-disk conventions: unknown_files.txt listing, 1 s @ 16 kHz samples."""
+    import util_data
+    from multilingual_kws_amd.embedding import input_data
+    bank = tmp_path / "unknown_words"
+    rng = np.random.default_rng(0)
+    for rel in ("en/clips/a/x.wav", "es/clips/b/y.wav"):
+        util_data.write_wav(str(bank / rel), util_data.tone_clip(440, rng))
+    (bank / "unknown_files.txt").write_text("en/clips/a/x.wav\nes/clips/b/y.wav\n")
+    files = input_data.load_unknown_files(bank)
+    assert files == [str(bank / "en/clips/a/x.wav"), str(bank / "es/clips/b/y.wav")]
+    assert input_data.check_one_second_16k(files[0])
+    util_data.write_wav(str(bank / "short.wav"), util_data.tone_clip(440, rng, n=8000))
+    with pytest.raises(ValueError):
+        input_data.check_one_second_16k(str(bank / "short.wav"))
+    util_data.write_wav(str(bank / "r8k.wav"), util_data.tone_clip(440, rng, n=16000), rate=8000)
+    with pytest.raises(ValueError):
+        input_data.check_one_second_16k(str(bank / "r8k.wav"))
+    with pytest.raises(FileNotFoundError):
+        input_data.load_unknown_files(tmp_path)
