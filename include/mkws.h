@@ -192,6 +192,10 @@ int mkws_head_set_params(mkws_head* hd, const float* h_params, int n);   /* also
 int mkws_head_get_params(mkws_head* hd, float* h_params, int n, void* stream);
 /* d_emb [B,in] -> d_probs [B,classes] (softmax probabilities, what model.predict returns). */
 int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, void* stream);
+/* Multi-keyword serving (batch_streaming_analysis.py runs one full model per keyword; here N keywords share one
+ * embedding pass): n_heads heads of equal dimensions over the same d_emb [B,in] in ONE launch (per 64 heads)
+ * -> d_probs [n_heads, B, classes].  `heads` is a host array of handles. */
+int mkws_heads_forward(mkws_head* const* heads, int n_heads, const float* d_emb, int B, float* d_probs, void* stream);
 /* Forward + mean sparse-CE loss + backward into the handle's grad buffer (gradient of the MEAN loss
  * over these B rows).  d_labels int32 [B].  d_stats float32[2] receives {sum of per-row loss,
  * number of correct argmax predictions} for these B rows. */

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("mkws_head_set_params", _I, [_P, _P, _I]),
     ("mkws_head_get_params", _I, [_P, _P, _I, _P]),
     ("mkws_head_forward", _I, [_P, _P, _I, _P, _P]),
+    ("mkws_heads_forward", _I, [ctypes.POINTER(_P), _I, _P, _I, _P, _P]),
     ("mkws_head_loss_grad", _I, [_P, _P, _P, _I, _P, _P]),
     ("mkws_head_adam_step", _I, [_P, _F, _F, _F, _F, _I, _F, _P]),
 ]
@@ -77,6 +78,13 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C multilingual_kws_amd/csrc`).  multilingual_kws_amd has no CPU fallback.")
+        try:
+            # Load order matters: PyTorch brings its own HIP runtime.  If this library (linked against
+            # /opt/rocm's libamdhip64) is loaded first, the process ends up with a runtime that sees no device
+            # on the GPU box; with torch first both share torch's.  torch is required anyway (device memory).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)       # AttributeError if the .so does not export it

@@ -22,14 +22,23 @@ struct HeadDims { int in, hid, cls; };
 
 // one wave per row: h = tanh(x W1 + b1); z = h W2 + b2; p = softmax(z).
 // TRAIN: also per-row loss, correctness, dz = (p - onehot)/B and dpre = (dz W2^T) * (1 - h^2).
-template <bool TRAIN>
+// Parameter blocks of up to kHeadsPerLaunch heads, passed by value (multi-keyword serving: blockIdx.y = head).
+constexpr int kHeadsPerLaunch = 64;
+struct HeadTable { const float* p[kHeadsPerLaunch]; };
+
+template <bool TRAIN, bool MULTI = false>
 __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float* __restrict__ params, const float* __restrict__ x,
                                                         const int32_t* __restrict__ labels, int B, float* __restrict__ probs,
                                                         float* __restrict__ hbuf /*[B,hid]*/, float* __restrict__ dz /*[B,cls]*/,
-                                                        float* __restrict__ dpre /*[B,hid]*/, float* __restrict__ rowstat /*[B,2]*/) {
+                                                        float* __restrict__ dpre /*[B,hid]*/, float* __restrict__ rowstat /*[B,2]*/,
+                                                        HeadTable table = HeadTable()) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
+  if (MULTI) {                      // head blockIdx.y: its own parameters, its own [B, cls] slab of the output
+    params = table.p[blockIdx.y];
+    probs += (size_t)blockIdx.y * B * d.cls;
+  }
   const float* W1 = params;
   const float* b1 = W1 + (size_t)d.in * d.hid;
   const float* W2 = b1 + d.hid;
@@ -278,6 +287,28 @@ int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, 
   if (!d_emb || !d_probs) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
   hipLaunchKernelGGL((head_rows_kernel<false>), dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb,
                      nullptr, B, d_probs, nullptr, nullptr, nullptr, nullptr);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_heads_forward(mkws_head* const* heads, int n_heads, const float* d_emb, int B, float* d_probs, void* stream) {
+  if (!heads || n_heads < 0) return fail(MKWS_ERR_INVALID_ARG, "heads is NULL or n_heads < 0");
+  if (B < 0) return fail(MKWS_ERR_INVALID_ARG, "negative batch");
+  if (n_heads == 0 || B == 0) return MKWS_OK;
+  if (!d_emb || !d_probs) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
+  for (int i = 0; i < n_heads; ++i) {
+    if (!heads[i]) return fail(MKWS_ERR_INVALID_ARG, "head %d is NULL", i);
+    if (heads[i]->d.in != heads[0]->d.in || heads[i]->d.hid != heads[0]->d.hid || heads[i]->d.cls != heads[0]->d.cls)
+      return fail(MKWS_ERR_INVALID_ARG, "head %d has different dimensions than head 0", i);
+  }
+  const HeadDims d = heads[0]->d;
+  for (int h0 = 0; h0 < n_heads; h0 += kHeadsPerLaunch) {
+    const int n = (n_heads - h0 < kHeadsPerLaunch) ? n_heads - h0 : kHeadsPerLaunch;
+    HeadTable t;
+    for (int i = 0; i < kHeadsPerLaunch; ++i) t.p[i] = heads[h0 + (i < n ? i : 0)]->params;
+    hipLaunchKernelGGL((head_rows_kernel<false, true>), dim3((B + 3) / 4, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb,
+                       nullptr, B, d_probs + (size_t)h0 * B * d.cls, nullptr, nullptr, nullptr, nullptr, t);
+  }
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

@@ -71,10 +71,12 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
     specs = stream_spectrograms(model_settings, audio, clip, stride)
     outs = [[] for _ in mlist]
     emb_model = mlist[0].embedding
+    from ..head import Head
     for s in range(0, specs.shape[0], batch_windows):
         emb = emb_model.forward(specs[s:s + batch_windows])
-        for k, m in enumerate(mlist):
-            outs[k].append(m.head.forward(emb))
+        probs = Head.forward_many([m.head for m in mlist], emb)          # [N, windows, 3] in one launch
+        for k in range(len(mlist)):
+            outs[k].append(probs[k])
     res = [torch.cat(o).cpu().numpy() if o else np.zeros((0, 3), np.float32) for o in outs]
     return res[0] if single else res
 

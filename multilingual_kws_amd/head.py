@@ -88,6 +88,22 @@ class Head:
                                                 _lib.current_stream_ptr()))
         return probs
 
+    @staticmethod
+    def forward_many(heads, emb):
+        """N heads of equal dimensions over the same embeddings in one launch: emb CUDA [B,in] -> CUDA [N,B,classes]
+        (multi-keyword serving on a shared embedding pass)."""
+        import torch
+        heads = list(heads)
+        emb = emb.contiguous()
+        B = emb.shape[0]
+        h0 = heads[0]
+        probs = torch.empty((len(heads), B, h0.classes), dtype=torch.float32, device=h0.device)
+        table = (ctypes.c_void_p * len(heads))(*[h.h.value for h in heads])
+        with torch.cuda.device(h0.device):
+            _lib.check(h0.L.mkws_heads_forward(table, len(heads), ctypes.c_void_p(emb.data_ptr()), B,
+                                               ctypes.c_void_p(probs.data_ptr()), _lib.current_stream_ptr()))
+        return probs
+
     def loss_grad(self, emb, labels):
         """Fills the grad buffer with d(mean CE over these rows)/d(params); returns a CUDA tensor
         [2] = {sum of row losses, number correct} (asynchronous; .tolist() syncs)."""

@@ -57,6 +57,7 @@ def test_cluster_and_sort_contract(monkeypatch):
 
 
 def test_export_keyword_embeddings_layout(monkeypatch, tmp_path):
+    pytest.importorskip("pyarrow")
     import pandas as pd
     from multilingual_kws_amd.embedding import distance_filtering as dfl
     monkeypatch.setattr(dfl, "_specs_for_files", _stub_specs)
@@ -93,6 +94,10 @@ def test_consumers_on_device(tmp_path):
     assert np.allclose(vec[7], one[0], rtol=1e-5, atol=1e-6)                        # batching does not change a clip's vector
     r = dfl.cluster_and_sort(np.array(files), emb, seed=1, n_train=15, n_clusters=3)
     assert len(r["sorted_clips"]) == 9 and np.all(np.diff(r["distances"]) >= 0)
+    try:
+        import pyarrow  # noqa: F401  (absent on some GPU boxes: the parquet layout itself is covered by the CPU test)
+    except ImportError:
+        return
     written = dfl.export_keyword_embeddings(tmp_path / "clips", tmp_path / "out", emb)
     df = pd.read_parquet(written[0])
     assert len(df) == 24 and np.allclose(np.stack(df["mswc_embedding_vector"].to_numpy()), vec, rtol=1e-6)

@@ -84,3 +84,16 @@ def test_error_contract(dev):
     with pytest.raises(MkwsError):
         Head(hidden=64)                          # beyond the kernels' register tiling
     assert hd.forward(x[:0]).shape == (0, 3)
+
+
+def test_many_heads_one_launch(dev):
+    """Multi-keyword serving: N heads over one embedding batch == N separate forwards, bit for bit
+    (70 heads also crosses the 64-heads-per-launch chunking)."""
+    from multilingual_kws_amd.head import Head
+    x, _ = _mk(dev, 37, seed=9)
+    heads = [Head(max_batch=64, seed=2000 + k) for k in range(70)]
+    many = Head.forward_many(heads, x)
+    assert many.shape == (70, 37, 3)
+    for k in (0, 1, 63, 64, 69):
+        assert torch.equal(many[k], heads[k].forward(x)), k
+    assert Head.forward_many(heads[:1], x[:0]).shape == (1, 0, 3)
