@@ -220,7 +220,7 @@ def main():
             "whole_step": {"tflops": round(B * arch.EMBED_FLOPS_PER_CLIP / (ms_per_step * 1e-3) / 1e12, 2),
                            "frontend_ms": round(fe_ms, 4), "embedding_ms": round(sum(ms for _, _, ms in prof), 4)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             spec_np = spec[:512].cpu().numpy()
             result["cpu_baseline"] = cpu_baseline(spec_np, audio_np[:512], blob, args.cpu_seconds)
         else:
