@@ -46,14 +46,6 @@ struct cpx { int r, i; };
 
 __device__ __forceinline__ int sext16(int v) { return (int)(short)v; }
 __device__ __forceinline__ int sround(int v) { return sext16((v + 16384) >> 15); }
-__device__ __forceinline__ int fixdiv4(int v) { return sround(v * 8191); }    // kissfft DIVSCALAR(x,4)
-__device__ __forceinline__ int fixdiv2(int v) { return sround(v * 16383); }   // DIVSCALAR(x,2)
-__device__ __forceinline__ cpx cmul(cpx a, cpx b) {
-  cpx m;
-  m.r = sround(a.r * b.r - a.i * b.i);
-  m.i = sround(a.r * b.i + a.i * b.r);
-  return m;
-}
 __device__ __forceinline__ uint32_t pack(int r, int i) { return ((uint32_t)r & 0xFFFFu) | ((uint32_t)i << 16); }
 __device__ __forceinline__ cpx unpack(uint32_t u) { cpx c; c.r = sext16((int)u); c.i = ((int)u) >> 16; return c; }
 
@@ -65,22 +57,30 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// kissfft kf_bfly4 (forward), one butterfly.  Inputs/outputs are sign-extended int16 values; the
-// int16 wrap of the C code is applied when results are packed (adds commute with the wrap).
-__device__ __forceinline__ void bfly4(cpx& F0, cpx& F1, cpx& F2, cpx& F3, cpx t1, cpx t2, cpx t3) {
-  F0.r = fixdiv4(F0.r); F0.i = fixdiv4(F0.i);
-  F1.r = fixdiv4(F1.r); F1.i = fixdiv4(F1.i);
-  F2.r = fixdiv4(F2.r); F2.i = fixdiv4(F2.i);
-  F3.r = fixdiv4(F3.r); F3.i = fixdiv4(F3.i);
-  const cpx s0 = cmul(F1, t1), s1 = cmul(F2, t2), s2 = cmul(F3, t3);
-  const cpx s5 = {F0.r - s1.r, F0.i - s1.i};
-  const cpx a0 = {F0.r + s1.r, F0.i + s1.i};
-  const cpx s3 = {s0.r + s2.r, s0.i + s2.i};
-  const cpx s4 = {s0.r - s2.r, s0.i - s2.i};
-  F2.r = a0.r - s3.r; F2.i = a0.i - s3.i;
-  F0.r = a0.r + s3.r; F0.i = a0.i + s3.i;
-  F1.r = s5.r + s4.i; F1.i = s5.i - s4.r;
-  F3.r = s5.r - s4.i; F3.i = s5.i + s4.r;
+// Packed int16 complex (x = re, y = im; the same bits as the LDS word pack() builds).  kissfft's FIXED_POINT=16
+// arithmetic stores every intermediate to int16, i.e. wraps mod 2^16 at every add -- exactly what the packed
+// 16-bit VALU ops do (v_pk_add/sub_i16); the rounded products are 32-bit dot products (v_dot2c_i32_i16).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 mk2(int r, int i) { s16x2 v; v.x = (short)r; v.y = (short)i; return v; }
+__device__ __forceinline__ uint32_t bits2(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 from2(uint32_t u) { return __builtin_bit_cast(s16x2, u); }
+// C_FIXDIV: sround(v * (32767/div)) on both components (|result| <= |v|/div: no wrap)
+__device__ __forceinline__ s16x2 fixdiv_pk(s16x2 v, int k) { return mk2(((int)v.x * k + 16384) >> 15, ((int)v.y * k + 16384) >> 15); }
+// twiddle t as the two dot-product operands of C_MUL: (t.r, -t.i) and (t.i, t.r)   (|t| <= 32767: negation is exact)
+struct tw2 { s16x2 a, b; };
+__device__ __forceinline__ tw2 mktw(cpx t) { tw2 w; w.a = mk2(t.r, -t.i); w.b = mk2(t.i, t.r); return w; }
+__device__ __forceinline__ s16x2 cmul_pk(s16x2 a, tw2 t) {
+  return mk2(__builtin_amdgcn_sdot2(a, t.a, 16384, false) >> 15, __builtin_amdgcn_sdot2(a, t.b, 16384, false) >> 15);
+}
+
+// kissfft kf_bfly4 (forward), one butterfly, on packed values.
+__device__ __forceinline__ void bfly4(s16x2& F0, s16x2& F1, s16x2& F2, s16x2& F3, tw2 t1, tw2 t2, tw2 t3) {
+  F0 = fixdiv_pk(F0, 8191); F1 = fixdiv_pk(F1, 8191); F2 = fixdiv_pk(F2, 8191); F3 = fixdiv_pk(F3, 8191);
+  const s16x2 s0 = cmul_pk(F1, t1), s1 = cmul_pk(F2, t2), s2 = cmul_pk(F3, t3);
+  const s16x2 s5 = F0 - s1, a0 = F0 + s1, s3 = s0 + s2, s4 = s0 - s2;
+  const s16x2 rot = mk2(s4.y, -(int)s4.x);             // -j * s4
+  F2 = a0 - s3; F0 = a0 + s3;
+  F1 = s5 + rot; F3 = s5 - rot;
 }
 
 // bits.h Sqrt64/Sqrt32: floor sqrt, then +1 when the remainder exceeds the root (round to nearest),
@@ -128,9 +128,11 @@ __device__ __forceinline__ uint32_t log_scale(uint32_t x, int scale_shift, const
 // Per-lane constants that do not change across the frames of a clip.
 struct LaneConst {
   int coef[8];        // window coefficients of this lane's 8 samples
-  cpx twB[3], twC[3], twD[3];
-  cpx st1, st2;       // super twiddles for k = lane+1 and k = lane+65
+  tw2 twB[3], twC[3], twD[3];
+  tw2 st1, st2;       // super twiddles for k = lane+1 and k = lane+65
   int n0;             // base-4 digit reversal of the lane id (3 digits)
+  int toff[4];        // sample offset of pair j inside the frame, clamped into the window (loads are unconditional)
+  int tsel[4];        // 2: both samples inside the window, 1: only the first (odd window), 0: none (zero padding)
 };
 
 __device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lane, LaneConst& L) {
@@ -146,13 +148,19 @@ __device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lan
     const int kB = lane & 3, kC = lane & 15, kD = lane;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      L.twB[q] = unpack(p.tw[kB * 16 * (q + 1)]);
-      L.twC[q] = unpack(p.tw[kC * 4 * (q + 1)]);
-      L.twD[q] = unpack(p.tw[kD * (q + 1)]);
+      L.twB[q] = mktw(unpack(p.tw[kB * 16 * (q + 1)]));
+      L.twC[q] = mktw(unpack(p.tw[kC * 4 * (q + 1)]));
+      L.twD[q] = mktw(unpack(p.tw[kD * (q + 1)]));
     }
   }
-  L.st1 = unpack(p.stw[lane]);
-  L.st2 = unpack(p.stw[lane + 64]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = 2 * (L.n0 + 64 * j);
+    L.tsel[j] = (t + 1 < p.window_size) ? 2 : (t < p.window_size ? 1 : 0);
+    L.toff[j] = (L.tsel[j] == 2) ? t : p.window_size - 2;     // the clamped pair ends at the window's last sample
+  }
+  L.st1 = mktw(unpack(p.stw[lane]));
+  L.st2 = mktw(unpack(p.stw[lane + 64]));
 }
 
 // window.c + fft.c + kiss_fftr + filterbank.c for ONE frame by ONE wave.
@@ -180,58 +188,56 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
   // ---- stage A (m = 1): butterflies on z[n0 + 64 j], twiddle (32767, 0) ----
   // fft.c FftCompute: (int16)((uint16)w << shift)
   auto shl = [shift](int v) { return sext16((int)((uint32_t)v << shift)); };
-  cpx F0 = {shl(w[0]), shl(w[1])};
-  cpx F1 = {shl(w[2]), shl(w[3])};
-  cpx F2 = {shl(w[4]), shl(w[5])};
-  cpx F3 = {shl(w[6]), shl(w[7])};
-  const cpx one = {32767, 0};
+  s16x2 F0 = mk2(shl(w[0]), shl(w[1]));
+  s16x2 F1 = mk2(shl(w[2]), shl(w[3]));
+  s16x2 F2 = mk2(shl(w[4]), shl(w[5]));
+  s16x2 F3 = mk2(shl(w[6]), shl(w[7]));
+  const tw2 one = mktw(cpx{32767, 0});
   bfly4(F0, F1, F2, F3, one, one, one);
-  fftbuf[4 * lane + 0] = pack(F0.r, F0.i);
-  fftbuf[4 * lane + 1] = pack(F1.r, F1.i);
-  fftbuf[4 * lane + 2] = pack(F2.r, F2.i);
-  fftbuf[4 * lane + 3] = pack(F3.r, F3.i);
+  fftbuf[4 * lane + 0] = bits2(F0);
+  fftbuf[4 * lane + 1] = bits2(F1);
+  fftbuf[4 * lane + 2] = bits2(F2);
+  fftbuf[4 * lane + 3] = bits2(F3);
   wave_lds_sync();
   // ---- stage B (m = 4) ----
   {
     const int base = (lane >> 2) * 16 + (lane & 3);
-    F0 = unpack(fftbuf[base]); F1 = unpack(fftbuf[base + 4]); F2 = unpack(fftbuf[base + 8]); F3 = unpack(fftbuf[base + 12]);
+    F0 = from2(fftbuf[base]); F1 = from2(fftbuf[base + 4]); F2 = from2(fftbuf[base + 8]); F3 = from2(fftbuf[base + 12]);
     bfly4(F0, F1, F2, F3, L.twB[0], L.twB[1], L.twB[2]);
-    fftbuf[base] = pack(F0.r, F0.i); fftbuf[base + 4] = pack(F1.r, F1.i);
-    fftbuf[base + 8] = pack(F2.r, F2.i); fftbuf[base + 12] = pack(F3.r, F3.i);
+    fftbuf[base] = bits2(F0); fftbuf[base + 4] = bits2(F1);
+    fftbuf[base + 8] = bits2(F2); fftbuf[base + 12] = bits2(F3);
     wave_lds_sync();
   }
   // ---- stage C (m = 16) ----
   {
     const int base = (lane >> 4) * 64 + (lane & 15);
-    F0 = unpack(fftbuf[base]); F1 = unpack(fftbuf[base + 16]); F2 = unpack(fftbuf[base + 32]); F3 = unpack(fftbuf[base + 48]);
+    F0 = from2(fftbuf[base]); F1 = from2(fftbuf[base + 16]); F2 = from2(fftbuf[base + 32]); F3 = from2(fftbuf[base + 48]);
     bfly4(F0, F1, F2, F3, L.twC[0], L.twC[1], L.twC[2]);
-    fftbuf[base] = pack(F0.r, F0.i); fftbuf[base + 16] = pack(F1.r, F1.i);
-    fftbuf[base + 32] = pack(F2.r, F2.i); fftbuf[base + 48] = pack(F3.r, F3.i);
+    fftbuf[base] = bits2(F0); fftbuf[base + 16] = bits2(F1);
+    fftbuf[base + 32] = bits2(F2); fftbuf[base + 48] = bits2(F3);
     wave_lds_sync();
   }
   // ---- stage D (m = 64) ----
   {
-    F0 = unpack(fftbuf[lane]); F1 = unpack(fftbuf[lane + 64]); F2 = unpack(fftbuf[lane + 128]); F3 = unpack(fftbuf[lane + 192]);
+    F0 = from2(fftbuf[lane]); F1 = from2(fftbuf[lane + 64]); F2 = from2(fftbuf[lane + 128]); F3 = from2(fftbuf[lane + 192]);
     bfly4(F0, F1, F2, F3, L.twD[0], L.twD[1], L.twD[2]);
-    fftbuf[lane] = pack(F0.r, F0.i); fftbuf[lane + 64] = pack(F1.r, F1.i);
-    fftbuf[lane + 128] = pack(F2.r, F2.i); fftbuf[lane + 192] = pack(F3.r, F3.i);
+    fftbuf[lane] = bits2(F0); fftbuf[lane + 64] = bits2(F1);
+    fftbuf[lane + 128] = bits2(F2); fftbuf[lane + 192] = bits2(F3);
     wave_lds_sync();
   }
   // ---- real-FFT post-pass (kiss_fftr) + energy, bins k and 256-k for k = lane+1, lane+65 ----
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int k = lane + 1 + 64 * h;
-    const cpx st = h ? L.st2 : L.st1;
-    cpx fpk = unpack(fftbuf[k]);
-    cpx t = unpack(fftbuf[256 - k]);
-    cpx fpnk = {t.r, sext16(-t.i)};
-    fpk.r = fixdiv2(fpk.r); fpk.i = fixdiv2(fpk.i);
-    fpnk.r = fixdiv2(fpnk.r); fpnk.i = fixdiv2(fpnk.i);
-    const cpx f1 = {sext16(fpk.r + fpnk.r), sext16(fpk.i + fpnk.i)};
-    const cpx f2 = {sext16(fpk.r - fpnk.r), sext16(fpk.i - fpnk.i)};
-    const cpx tw = cmul(f2, st);
-    const int ar = sext16((f1.r + tw.r) >> 1), ai = sext16((f1.i + tw.i) >> 1);
-    const int br = sext16((f1.r - tw.r) >> 1), bi = sext16((tw.i - f1.i) >> 1);
+    const tw2 st = h ? L.st2 : L.st1;
+    const s16x2 t = from2(fftbuf[256 - k]);
+    const s16x2 fpk = fixdiv_pk(from2(fftbuf[k]), 16383);
+    const s16x2 fpnk = fixdiv_pk(mk2(t.x, -(int)t.y), 16383);
+    const s16x2 f1 = fpk + fpnk, f2 = fpk - fpnk;
+    const s16x2 tw = cmul_pk(f2, st);
+    // the halving adds are done in int (no int16 wrap before the shift), as in kiss_fftr
+    const int ar = ((int)f1.x + (int)tw.x) >> 1, ai = ((int)f1.y + (int)tw.y) >> 1;
+    const int br = ((int)f1.x - (int)tw.x) >> 1, bi = ((int)tw.y - (int)f1.y) >> 1;
     // FilterbankConvertFftComplexToEnergy: uint32 r*r + i*i (can reach exactly 2^31)
     if (k != 128) ebuf[k] = (uint32_t)(ar * ar) + (uint32_t)(ai * ai);
     ebuf[256 - k] = (uint32_t)(br * br) + (uint32_t)(bi * bi);   // k == 128: the second write wins upstream
@@ -274,12 +280,15 @@ template <> struct AudioLoad<int16_t> {
 // Loads this lane's 8 samples of the frame starting at `frame` (window_size valid samples).
 template <typename T>
 __device__ __forceinline__ void load_frame(const T* frame, int window_size, bool aligned, const LaneConst& L, int (&x)[8]) {
+  // branch-free: every lane issues its 4 pair loads (clamped into the window), the zero padding of the
+  // 512-point FFT frame is applied by selects (window_size >= 2; host sets `aligned` only for even windows)
+  (void)window_size;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int t = 2 * (L.n0 + 64 * j);
-    if (t + 1 < window_size) AudioLoad<T>::pair(frame + t, aligned, x[2 * j], x[2 * j + 1]);
-    else if (t < window_size) { x[2 * j] = AudioLoad<T>::one(frame + t); x[2 * j + 1] = 0; }
-    else { x[2 * j] = 0; x[2 * j + 1] = 0; }
+    int a, b;
+    AudioLoad<T>::pair(frame + L.toff[j], aligned, a, b);
+    x[2 * j] = (L.tsel[j] == 2) ? a : (L.tsel[j] == 1 ? b : 0);
+    x[2 * j + 1] = (L.tsel[j] == 2) ? b : 0;
   }
 }
 
@@ -588,7 +597,8 @@ int frontend_forward_impl(mkws_frontend* fe, const T* d_audio, int B, int n_samp
   const size_t lds = clip_lds_bytes(fe, frames);
   if (lds > 64 * 1024)
     return fail(MKWS_ERR_UNSUPPORTED, "%d frames per clip need %zu B of LDS; use mkws_frontend_stream_f32 for long audio", frames, lds);
-  const int aligned = ((n_samples % 2) == 0 && (fe->prm.window_step % 2) == 0 && (reinterpret_cast<uintptr_t>(d_audio) % (2 * sizeof(T))) == 0) ? 1 : 0;
+  const int aligned = ((n_samples % 2) == 0 && (fe->prm.window_step % 2) == 0 && (fe->prm.window_size % 2) == 0 &&
+                       (reinterpret_cast<uintptr_t>(d_audio) % (2 * sizeof(T))) == 0) ? 1 : 0;
   hipLaunchKernelGGL((frontend_clip_kernel<T, kClipWaves>), dim3(B), dim3(kClipWaves * 64), lds, static_cast<hipStream_t>(stream),
                      fe->prm, d_audio, n_samples, frames, aligned, d_spec, d_raw);
   MKWS_HIP(hipGetLastError());
@@ -628,7 +638,7 @@ int mkws_frontend_stream_f32(mkws_frontend* fe, const float* d_audio, int n_samp
     const size_t n = (size_t)(fe->max_frames > 0 ? fe->max_frames : 1) * p.num_channels * 4;
     if (hipMalloc(reinterpret_cast<void**>(&fe->d_stream_sig), n) != hipSuccess) return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) failed", n);
   }
-  const int aligned = ((p.window_step % 2) == 0 && (reinterpret_cast<uintptr_t>(d_audio) % 8) == 0) ? 1 : 0;
+  const int aligned = ((p.window_step % 2) == 0 && (p.window_size % 2) == 0 && (reinterpret_cast<uintptr_t>(d_audio) % 8) == 0) ? 1 : 0;
   const size_t lds1 = 4 * 512 * 4 + ((p.ncoef + 7) & ~7) * 2 + 16;
   int grid1 = (total_frames + 3) / 4;
   if (grid1 > 4096) grid1 = 4096;
