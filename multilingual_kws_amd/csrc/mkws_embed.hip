@@ -1647,6 +1647,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
         for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
     }
   }
+  const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;     // requested before the barrier (48*G <= NTHR)
   __syncthreads();
   for (int t = tid; t < 48 * G; t += NTHR) {
     const int n = t / G, clip = t - n * G;
@@ -1654,7 +1655,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
     if (n < a.se) {
 #pragma unroll
       for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * G + clip];
-      v = swishf_(v + a.br[n]);
+      v = swishf_(v + br_pre);
     }
     s_R[clip * LDR + n] = v;
   }
