@@ -156,6 +156,7 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "proj_stream" (default 0): 1 = gated projection convs of the big-image blocks (2a..4a) use the streaming
  *                 kernel (activations cross HBM once, packed weights in LDS; measured equal on MI355X);
  *                 0 = the generic GEMM kernel.
+ *   "fuse_gap" (default 1): global average pool fused into the top conv epilogue (its [B*4,1280] output is never stored).
  *   "fuse_stem" (default 2): 2 = stem conv + the whole of block 1a in one kernel (one clip per workgroup, both
  *                 25x20x32 activations stay in LDS); 1 = stem conv + block-1a depthwise; 0 = separate kernels. */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);

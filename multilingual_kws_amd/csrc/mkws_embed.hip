@@ -355,6 +355,7 @@ struct GemmArgs {
   const float* R; int ldr;
   float* Y; int ldy;
   int M, K, N, KC, NTtot, act;
+  int pool4;       // 1: global average pool fused into the epilogue: the 4 rows of a clip (2x2 image) are averaged, Y is [M/4, N]
   int splitk;      // > 1: blockIdx.z owns a slice of the K chunks and writes raw sums to part[z][M][ldp]
   float* part; int ldp;
 };
@@ -496,7 +497,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
         y.x = apply_act(y.x, a.act); y.y = apply_act(y.y, a.act); y.z = apply_act(y.z, a.act); y.w = apply_act(y.w, a.act);
       }
       if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
-      *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = y;
+      if (a.pool4) {
+        // rows 4i..4i+3 of the tile sit in lanes c = 4i..4i+3 of the same lane group: two xor-shuffles fold them
+        // (M is a multiple of 4, so a clip's rows are valid together; shuffles run on all lanes of the wave)
+        y.x += __shfl_xor(y.x, 1); y.y += __shfl_xor(y.y, 1); y.z += __shfl_xor(y.z, 1); y.w += __shfl_xor(y.w, 1);
+        y.x += __shfl_xor(y.x, 2); y.y += __shfl_xor(y.y, 2); y.z += __shfl_xor(y.z, 2); y.w += __shfl_xor(y.w, 2);
+        if ((c & 3) == 0) *reinterpret_cast<f32x4*>(a.Y + (m >> 2) * a.ldy + n) = y * 0.25f;
+      } else {
+        *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = y;
+      }
     }
   }
 }
@@ -1916,6 +1925,7 @@ struct mkws_embed {
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
+  int fuse_gap = 1;                // global average pool fused into the top conv's epilogue (2x2 image: 4 rows per clip)
   int proj_stream = 0;             // gated projection convs of blocks 2a..4a: 1 = pw_proj_kernel (X streamed once, weights in LDS; measured equal), 0 = pw_gemm_kernel
   int gemm_lds = 0;                // 1x1-conv/dense GEMM: 0 = direct-to-register kernel (faster on MI355X, profiles/r01_notes.md), 1 = planner may pick the LDS-staged kernel
   bool fuse_se = false;            // SE squeeze -> reduce-FC partials inside the producing kernel (saves the se_reduce launch, but the
@@ -2106,11 +2116,13 @@ int pick_lds(int M, int NTtot, int KC, int* splitk) {
 }
 
 void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const float* X, int ldx, int M, int Mplan, int act, const float* gate, int HW,
-                 const float* R, int ldr, float* Y, int ldy) {
+                 const float* R, int ldr, float* Y, int ldy, int pool4 = 0) {
   GemmArgs a;
+  a.pool4 = pool4;
   a.X = X; a.ldx = ldx; a.Wp = L.Wp; a.scale = L.scale; a.shift = L.shift; a.gate = gate; a.HW = HW > 0 ? HW : 1;
   a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy; a.M = M; a.K = L.K; a.N = L.N; a.KC = L.KC; a.NTtot = L.NTtot; a.act = act;
   TileChoice tc = pick_tile(Mplan, L.NTtot, L.KC);
+  if (pool4) tc.splitk = 1;                 // the fused average pool lives in the direct epilogue only
   if (const char* f = getenv("MKWS_GEMM_FORCE")) {       // experiment hook: "Mmax,MT,NT,SK" applies to layers with Mplan <= Mmax
     int mmax = 0, fmt = 0, fnt = 0, fsk = 0;
     if (sscanf(f, "%d,%d,%d,%d", &mmax, &fmt, &fnt, &fsk) == 4 && Mplan <= mmax && fnt <= L.NTtot) tc = {fmt, fnt, fsk};
@@ -2478,9 +2490,15 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     float* t = cur; cur = nxt; nxt = t;
   }
   const int HWt = em->topH * em->topW;
-  launch_gemm(s, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, kTopCh);
-  if (hit("top", em->bufE, (size_t)B * HWt * kTopCh)) return MKWS_OK;
-  {
+  const bool fuse_gap = em->fuse_gap && HWt == 4 && em->gemm_lds == 0 && !(stop && strcmp(stop, "top") == 0);
+  if (fuse_gap) {
+    // top conv + BN + swish + global average pool in one launch: the [B*4, 1280] tensor never reaches HBM
+    launch_gemm(s, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->gap, kTopCh, 1);
+  } else {
+    launch_gemm(s, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, kTopCh);
+    if (hit("top", em->bufE, (size_t)B * HWt * kTopCh)) return MKWS_OK;
+  }
+  if (!fuse_gap) {
     const long total = (long)B * (kTopCh / 4);
     ProfScope ps("gap", "mean_hw_kernel");
     hipLaunchKernelGGL(mean_hw_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, em->bufE, em->gap, B, HWt, kTopCh);
@@ -2673,6 +2691,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "gemm_lds") == 0) { em->gemm_lds = value; return MKWS_OK; }
   if (strcmp(name, "proj_stream") == 0) { em->proj_stream = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
   if (strcmp(name, "fuse_se") == 0) { em->fuse_se = value != 0; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }

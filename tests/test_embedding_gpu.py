@@ -60,19 +60,21 @@ def test_execution_options_agree(ctx):
             ctx["em"].set_option("gemm_lds", block % 2)
             ctx["em"].set_option("fuse_se", 1 - block % 2)
             ctx["em"].set_option("proj_stream", front)
+            ctx["em"].set_option("fuse_gap", front)
             assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block)
-            for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block2b", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a"):
+            for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block2b", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a", "top", "gap"):
                 taps = {}
                 ctx["oracle"].forward(spec[:3], taps)
                 got = ctx["em"].tap(x[:3], name).cpu().numpy().reshape(taps[name].shape)
                 assert _rel(got, taps[name]) < REL_TOL, (front, block, name)
     finally:
         ctx["em"].set_option("fuse_front", 1)
-        ctx["em"].set_option("fuse_block", 1)
+        ctx["em"].set_option("fuse_block", 2)
         ctx["em"].set_option("fuse_stem", 2)
         ctx["em"].set_option("gemm_lds", 0)
         ctx["em"].set_option("fuse_se", 0)
-        ctx["em"].set_option("proj_stream", 1)
+        ctx["em"].set_option("proj_stream", 0)
+        ctx["em"].set_option("fuse_gap", 1)
 
 
 def test_golden_embedding_on_device(ctx, golden_dir):
