@@ -150,7 +150,7 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 loads; measured slower on MI355X for these shapes); 100+i forces LDS configuration i.
  *   "fuse_se" (default 0): 1 = the partial sums of the SE reduce FC are produced by the depthwise kernels
  *                 themselves (one SE launch per block instead of two; measured slower on MI355X).
- *   "fuse_block" (default 2): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
+ *   "fuse_block" (default 2 for handles with max_batch >= 384, else 0): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
  *                 ONE kernel, 4 clips per workgroup, activations resident in LDS; 1 = only the 2x2 blocks
  *                 (6b..7a); 0 = the multi-kernel path everywhere.
  *   "proj_stream" (default 0): 1 = gated projection convs of the big-image blocks (2a..4a) use the streaming

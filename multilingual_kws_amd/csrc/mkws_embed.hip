@@ -2561,6 +2561,11 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   mkws_embed* em = new (std::nothrow) mkws_embed();
   if (!em) return fail(MKWS_ERR_ALLOC, "out of host memory");
   em->max_batch = max_batch;
+  // Whole-block kernels re-stream a block's weights once per 4 clips: that pays from a few hundred clips up
+  // (measured crossover between 256 and 512, tools/latency_sweep.py); small-batch (serving) handles use the
+  // multi-kernel path, which spreads the weights of a layer over the chip.  Per handle, so results stay
+  // bit-identical across the batch sizes one handle sees.
+  em->fuse_block = (max_batch >= 384) ? 2 : 0;
   (void)hipGetDevice(&em->device);
   Packer pk;
   std::vector<float> sc, sh;
