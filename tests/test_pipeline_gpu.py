@@ -131,3 +131,39 @@ def test_transfer_learn_contract_and_learning(data, tmp_path):
 def test_smoke_entry_point():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_hot_path_is_graph_capturable():
+    """include/mkws.h promises: asynchronous on the caller's stream, no allocation and no synchronisation after
+    create.  Capture frontend + embedding + 3 heads into one HIP graph and replay it on new input."""
+    import torch
+    from multilingual_kws_amd import synth, weights
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    from multilingual_kws_amd.frontend import Frontend
+    from multilingual_kws_amd.head import Head
+    dev = torch.device("cuda:0")
+    fe, em = Frontend(max_samples=16000), EmbeddingModel(weights.synthetic_blob(), max_batch=8)
+    heads = [Head(max_batch=8, seed=s) for s in (1, 2, 3)]
+    a0 = torch.from_numpy(synth.clips_float32(8)).to(dev)
+    a1 = torch.from_numpy(synth.clips_float32(8, first_clip=100)).to(dev)
+
+    def run(x):
+        return Head.forward_many(heads, em.forward(fe.forward(x)))
+
+    ref0, ref1 = run(a0).clone(), run(a1).clone()
+    static_in = a0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run(static_in)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref0)
+    static_in.copy_(a1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref1) and not torch.equal(ref0, ref1)
