@@ -238,13 +238,15 @@ __global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 2; ++j) wp[j] = *reinterpret_cast<const f32x4*>(WpP + ((size_t)j * 4 + g) * 64 + c * 4);
   const f32x4 scp = *reinterpret_cast<const f32x4*>(scP + 4 * g), shp = *reinterpret_cast<const f32x4*>(shP + 4 * g);
+  // both convolutions' taps and BN constants too (requested before the barriers they would otherwise wait behind)
+  f32x4 wk[9], wkd[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { wk[t] = *reinterpret_cast<const f32x4*>(w + t * C + q * 4); wkd[t] = *reinterpret_cast<const f32x4*>(Wd + t * C + q * 4); }
+  const f32x4 sc_s = *reinterpret_cast<const f32x4*>(scale + q * 4), sh_s = *reinterpret_cast<const f32x4*>(shift + q * 4);
+  const f32x4 sc_d = *reinterpret_cast<const f32x4*>(scD + q * 4), sh_d = *reinterpret_cast<const f32x4*>(shD + q * 4);
   __syncthreads();
   {
-    f32x4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(w + t * C + q * 4);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+    const f32x4 sc = sc_s, sh = sh_s;
     for (int pix = tid >> 3; pix < Ho * Wo; pix += NTHR / 8) {
       const int oh = pix / Wo, ow = pix % Wo;
       const float* in0 = s_in + (2 * oh) * TW + 2 * ow;   // tile row 2*oh == image row 2*oh - 1
@@ -261,11 +263,7 @@ __global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restri
   __syncthreads();
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
   {
-    f32x4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(Wd + t * C + q * 4);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scD + q * 4);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shD + q * 4);
+    const f32x4 sc = sc_d, sh = sh_d;
     for (int pix = tid >> 3; pix < Ho * Wo; pix += NTHR / 8) {
       const int oh = pix / Wo, ow = pix % Wo;
       const float* e0 = s_E + ((size_t)oh * EW + ow) * C + q * 4;     // top-left tap (halo offset cancels the -1)
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc += *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + j) * C) * wk[i * 3 + j];
+        for (int j = 0; j < 3; ++j) acc += *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + j) * C) * wkd[i * 3 + j];
       f32x4 y = acc * sc + sh;
       y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
       *reinterpret_cast<f32x4*>(s_D + (size_t)pix * LDD + q * 4) = y;
@@ -914,6 +912,15 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #endif
   // nt_valid: n-tiles of this block that exist (the last chunk of a layer may be partial)
   const int nt_valid = ((a.Cexp - ch0) / 16 < NT) ? (a.Cexp - ch0) / 16 : NT;
+  // depthwise BN constants of this thread's channel quad (item % Q == tid % Q for every item of the thread):
+  // requested now, used after the barrier
+  f32x4 scd_pre = {0.f, 0.f, 0.f, 0.f}, shd_pre = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (PIXEL_LANES) {
+    const int tq0 = tid % Q;
+    const int cq0 = (tq0 < nt_valid * 4) ? ch0 + 4 * tq0 : ch0;
+    scd_pre = *reinterpret_cast<const f32x4*>(a.scD + cq0);
+    shd_pre = *reinterpret_cast<const f32x4*>(a.shD + cq0);
+  }
   if constexpr (PIXEL_LANES) {                 // depthwise taps of this channel chunk -> LDS (consumed after phase 1)
     for (int i = tid; i < KS * KS * Q; i += NTHREADS) {
       const int t = i / Q, q4 = (i - t * Q) * 4;
@@ -1125,8 +1132,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #pragma unroll
             for (int jx = 0; jx < KS; ++jx) acc[o] += v[o * S + jx] * w[jx];
         }
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
+        const f32x4 sc = scd_pre, sh = shd_pre;
         float* yout = a.Y + ((size_t)(b0 + gi) * (HoT * WoT) + oh * WoT + sg * SEG) * a.Cexp + cq;
 #pragma unroll
         for (int o = 0; o < SEG; ++o) {
