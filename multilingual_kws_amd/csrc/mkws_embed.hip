@@ -1926,7 +1926,7 @@ struct mkws_embed {
   float *sums = nullptr, *gate = nullptr;   // (1152 each)
   float *gap = nullptr, *d0 = nullptr, *d1 = nullptr;   // (1280, 2048, 2048)
   float* se_part = nullptr;                              // SE reduce partials (8 slices x 48 = 384, + tile padding)
-  float* splitk_ws = nullptr; size_t splitk_floats = 0;  // (4 slices x 4 rows x 320 cols = 5120)
+  float* splitk_ws = nullptr; size_t splitk_floats = 0;  // per clip: 4 K slices x (4 rows x 1280 cols: the widest layer a small-batch plan may split) = 20480 floats
   // plan
   const float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
   float norm_mean = 0.f, norm_std = 1.f;
@@ -2163,7 +2163,7 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
     const int bnt = c.WN * c.NT, bm = c.WM * c.MT * 16;
     a.splitk = lds_sk; a.part = nullptr; a.ldp = L.NTtot * 16;
     if (a.splitk > 1) {
-      if (!g_splitk_ws || (size_t)a.splitk * M * a.ldp > g_splitk_ws_floats) a.splitk = 1;
+      if (!g_splitk_ws || (size_t)a.splitk * Mplan * a.ldp > g_splitk_ws_floats) a.splitk = 1;   // decided on the planned M: same path for every batch size
       else a.part = g_splitk_ws;
     }
     const size_t lds = (size_t)(2 * 2 * c.WM * c.MT * 256 + 2 * 2 * bnt * 256) * sizeof(float);
@@ -2184,7 +2184,7 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
   const int MT = tc.MT, NT = tc.NT;
   a.splitk = tc.splitk; a.part = nullptr; a.ldp = L.NTtot * 16;
   if (tc.splitk > 1) {
-    if (!g_splitk_ws || (size_t)tc.splitk * M * a.ldp > g_splitk_ws_floats) a.splitk = 1;   // no workspace: plain path
+    if (!g_splitk_ws || (size_t)tc.splitk * Mplan * a.ldp > g_splitk_ws_floats) a.splitk = 1;   // no workspace: plain path (decided on the planned M, so every batch size of a handle takes the same path)
     else a.part = g_splitk_ws;
   }
   dim3 grid((M + 64 * MT - 1) / (64 * MT), (L.NTtot + NT - 1) / NT, a.splitk);
@@ -2661,7 +2661,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->top = G(o_top); em->dense0 = G(o_d0); em->dense1 = G(o_d1); em->dense2 = G(o_d2);
 
   // workspace
-  const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 5120 + 9 * 48;
+  const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 20480 + 9 * 48;
   const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
@@ -2670,7 +2670,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   const size_t mb = (size_t)max_batch;
   em->bufA = w; w += 16000 * mb; em->bufB = w; w += 16000 * mb; em->bufE = w; w += 48000 * mb; em->bufD = w; w += 18720 * mb;
   em->sums = w; w += 1152 * mb; em->gate = w; w += 1152 * mb; em->gap = w; w += 1280 * mb; em->d0 = w; w += 2048 * mb; em->d1 = w; w += 2048 * mb;
-  em->splitk_ws = w; em->splitk_floats = 5120 * mb; w += 5120 * mb;
+  em->splitk_ws = w; em->splitk_floats = 20480 * mb; w += 20480 * mb;
   em->se_part = w;      // 8 slices x ceil(mb/16) groups x 768 floats <= 384*mb + 6144
   *out = em;
   return MKWS_OK;

@@ -142,3 +142,17 @@ def test_weight_container_roundtrip(ctx, tmp_path):
     assert np.array_equal(weights.load(str(tmp_path / "w")), ctx["blob"])
     named = {t["name"]: ctx["blob"][t["offset"]:t["offset"] + t["count"]].reshape(t["shape"]) for t in weights.manifest()}
     assert np.array_equal(weights.from_named_tensors(named), ctx["blob"])
+
+
+def test_small_batch_handle_plan(ctx):
+    """Handles created for small batches plan the multi-kernel path (mkws_embed_create: fuse_block follows
+    max_batch); same numbers within fp32 rounding, still bit-identical across the batch sizes of that handle."""
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    spec = _spec(np.random.default_rng(21), 8)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    small = EmbeddingModel(ctx["blob"], max_batch=8)
+    out = small.forward(x)
+    assert _rel(out.cpu().numpy(), ctx["oracle"].forward(spec).numpy()) < REL_TOL
+    assert _rel(out.cpu().numpy(), ctx["em"].forward(x).cpu().numpy()) < REL_TOL
+    for b in (1, 3, 5):
+        assert torch.equal(small.forward(x[:b]), out[:b]), b
