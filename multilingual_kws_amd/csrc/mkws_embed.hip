@@ -441,6 +441,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
       for (int d = 0; d < D; ++d) {
         compute(xq[d], wq[d]);
         load(j + D + d, xq[d], wq[d]);
+        // without this hipcc sinks all D reloads to the end of the loop body: every iteration then starts by
+        // waiting a full memory latency for slot 0 (the ring keeps nothing in flight across iterations)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // here D <= jpipe_end - j < 2D: one more group with partial reloads, then the drain
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
     for (int d = 0; d < D; ++d) {
       compute(xq[d], wq[d]);
       if (j + D + d < jpipe_end) load(j + D + d, xq[d], wq[d]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     j += D;
 #pragma unroll
@@ -1354,12 +1358,14 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
       for (int d = 0; d < DEPTH; ++d) {
         compute(d, j + d, wq[d]);
         load(j + DEPTH + d, wq[d]);
+        __builtin_amdgcn_sched_barrier(0);     // keep each reload behind its slot's MFMAs (hipcc otherwise sinks them all to the loop end)
       }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       compute(d, j + d, wq[d]);
       if (j + DEPTH + d < KC) load(j + DEPTH + d, wq[d]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     j += DEPTH;
 #pragma unroll
@@ -1456,12 +1462,14 @@ __device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const 
       for (int d = 0; d < DEPTH; ++d) {
         compute(d, wq[d]);
         load(wq[d]);
+        __builtin_amdgcn_sched_barrier(0);     // see stream_mfma
       }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       compute(d, wq[d]);
       if (it + DEPTH + d < T) load(wq[d]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     it += DEPTH;
 #pragma unroll
