@@ -625,12 +625,14 @@ __global__ __launch_bounds__(512) void pw_proj_kernel(GemmArgs a) {
       for (int d = 0; d < D; ++d) {
         compute(ring[d]);
         load(ring[d]);
+        __builtin_amdgcn_sched_barrier(0);     // keep the reload behind its slot's MFMAs (see pw_gemm_kernel)
       }
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       compute(ring[d]);
       if (it + D + d < T) load(ring[d]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     it += D;
 #pragma unroll
