@@ -1335,10 +1335,15 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
 #pragma unroll
     for (int m = 0; m < MT; ++m) xr[0][m] = xload(0, m);
   }
+  // a wave with a single accumulator (one tile, one row tile) would issue 4 dependent MFMAs per chunk (40-cycle dependent
+  // latency vs 32-cycle issue): its odd k-steps go to a second accumulator, folded in once at the end
+  constexpr bool SPLIT = (NTW * MT == 1);
+  f32x4 acc_odd = {0.f, 0.f, 0.f, 0.f};
   auto compute = [&](int d, int j, const f32x4 (&wv)[NTWR]) {
     const int nj = (j + 1 < KC) ? j + 1 : j;
 #pragma unroll
     for (int m = 0; m < MT; ++m) xr[((d + 1) % DEPTH) % XB][m] = xload(nj, m);
+    __builtin_amdgcn_sched_barrier(0);           // the next chunk's ds_reads go out BEFORE this chunk's MFMAs, not after them
     f32x4 x[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) x[m] = xmake(xr[d % XB][m]);
@@ -1347,7 +1352,10 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
 #pragma unroll
       for (int q = 0; q < NTW; ++q)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[m][s], acc[q][m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) {
+          if (SPLIT && (s & 1)) acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[m][s], acc_odd, 0, 0, 0);
+          else acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], x[m][s], acc[q][m], 0, 0, 0);
+        }
   };
   if (KC >= DEPTH) {
     if (!PRE) {
@@ -1379,6 +1387,7 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
     for (int d = 0; d < DEPTH; ++d)
       if (d < KC) { load(d, wq[d]); compute(d, d, wq[d]); }
   }
+  if (SPLIT) acc[0][0] += acc_odd;
 }
 
 // Flattened variant of stream_mfma for MANY short accumulation runs (phase A, SE expand): run r = tiles
@@ -1435,6 +1444,7 @@ __device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const 
     const int nj = (cj + 1 == KC) ? 0 : cj + 1;        // every run walks the same K chunks
 #pragma unroll
     for (int m = 0; m < MT; ++m) xr[((d + 1) % DEPTH) % XB][m] = xload(nj, m);
+    __builtin_amdgcn_sched_barrier(0);                 // next chunk's ds_reads before this chunk's MFMAs (see stream_mfma)
     f32x4 x[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) x[m] = xmake(xr[d % XB][m]);
