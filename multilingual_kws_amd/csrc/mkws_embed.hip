@@ -411,25 +411,28 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   // exactly "MFMAs, then reload" (the compiler then emits counted vmcnt(N) and D-1 chunks stay in flight),
   // and a drain.
   constexpr int D = (MT * NT >= 10) ? 3 : 4;
-  f32x4 xq[D][MT], wq[D][NT];
-  auto load = [&](int j, f32x4 (&xv)[MT], f32x4 (&wv)[NT]) {
+  constexpr int XW = GATE ? 2 * MT : MT;        // the SE gate rides the ring as raw fragments next to X: multiplying it in at
+  f32x4 xq[D][XW], wq[D][NT];                   // load time would touch the fresh registers and force an immediate wait
+  auto load = [&](int j, f32x4 (&xv)[XW], f32x4 (&wv)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(xrow[mt] + 16 * j);
-      if (GATE) v *= *reinterpret_cast<const f32x4*>(grow[mt] + 16 * j);
-      xv[mt] = v;
+      xv[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + 16 * j);
+      if (GATE) xv[MT + mt] = *reinterpret_cast<const f32x4*>(grow[mt] + 16 * j);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const f32x4*>(wrow[nt] + (size_t)j * a.NTtot * 256);
   };
-  auto compute = [&](const f32x4 (&xv)[MT], const f32x4 (&wv)[NT]) {
+  auto compute = [&](const f32x4 (&xv)[XW], const f32x4 (&wv)[NT]) {
+    f32x4 x[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) x[mt] = GATE ? xv[mt] * xv[MT + (GATE ? mt : 0)] : xv[mt];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][s], xv[mt][s], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][s], x[mt][s], acc[mt][nt], 0, 0, 0);
   };
   const int n = jpipe_end - jbeg;
   if (n >= D) {
