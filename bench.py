@@ -1,20 +1,35 @@
 #!/usr/bin/env python
-"""bench.py -- clips/sec of the hot path: micro-frontend + EfficientNet-B0 embedding forward, batch 1024
-per GPU, 1 s @ 16 kHz synthetic clips resident in HBM (BASELINE.json metric; the workload shape of
-notebooks/dataperf_experiments.py:324-338,385-415 in the reference).
+"""bench.py -- the hot path of multilingual_kws on MI355X, one JSON line per run.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; clips are sharded across ranks with no
-   data-path collective -> "scaling": "weak", 1024 clips per GPU per step.)
+  python bench.py [--config embed|frontend|finetune|stream] --gpus N --steps K --warmup W
 
-A step = frontend kernel + ~70 embedding kernels over one batch.  Rank 0 prints ONE JSON line with
-the whole-job clips/s plus `roofline` (dominant kernel, hipEvent-timed live) and `cpu_baseline`
-(the CPU oracle timed on this box's host cores, bounded sample).
+--config selects the BASELINE.json configuration (default `embed` = configs[2], the one the headline metric
+is quoted on):
+  frontend  configs[1]  batch 1024 synthetic 1 s @ 16 kHz clips -> micro-frontend only            (HBM roofline)
+  embed     configs[2]  batch 1024 -> micro-frontend + EfficientNet-B0 embedding forward          (fp32 MFMA roofline)
+  finetune  configs[3]  512 clips/GPU: augmentation -> frontend -> SpecAugment -> embedding ->
+                        head loss/gradient -> ONE RCCL all-reduce (N > 1) -> Keras Adam
+  stream    configs[4]  60 s stream = 2950 windows, 50 keyword heads on one shared embedding,
+                        throughput at batch 256 (+ batch-1 latency reported beside it)
+(workload shapes: notebooks/dataperf_experiments.py:324-338,385-415 and
+ multilingual_kws/embedding/batch_streaming_analysis.py:99-117 in the reference).
+
+N > 1: one rank per GPU.  Under torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the env) this process is
+one rank; started plainly with --gpus N it re-launches itself under torch.distributed.run with N ranks and
+relays rank 0's JSON line.  Clips are sharded across ranks ("scaling": "weak"); the only collective is the
+fine-tune step's gradient all-reduce.
+
+Rank 0 prints ONE JSON line: whole-job throughput + `roofline` (dominant kernel, hipEvent-timed live on the
+launch stream) + `cpu_baseline` (the CPU oracle on this box's host cores, bounded sample, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak
+CONFIGS = ("embed", "frontend", "finetune", "stream")
 
 
 def parse():
@@ -29,7 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU per step")
+    ap.add_argument("--config", choices=CONFIGS, default="embed", help="BASELINE.json configuration (default: configs[2])")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default: the config's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--profile-reps", type=int, default=5)
@@ -38,83 +55,236 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(spec_batch_np, audio_np, blob, budget_s):
-    """Times the CPU oracle (C frontend with OpenMP over clips + PyTorch-CPU fp32 embedding) on a
-    bounded sample of the same workload.  kind = "port": TensorFlow (the reference's runtime) is not
-    installable in this image, so this is the restatement, not the reference itself."""
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU over RCCL)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to report an N-GPU number from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (kind "port" -- TensorFlow, the reference's runtime, is not installable in this image) on a
+# bounded sample of the same workload, on ALL host cores as `procs` worker processes x `threads` threads each.
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_worker(kind, idx, threads, n_clips, first_clip, budget_s, q, go):
     import numpy as np
     import torch
+    torch.set_num_threads(threads)
+    from multilingual_kws_amd import synth, weights
     from oracle.frontend_oracle import FrontendOracle
-    from oracle.efficientnet_oracle import EmbeddingOracle
-    ncpu = os.cpu_count() or 1
     fo = FrontendOracle()
-    eo = EmbeddingOracle(blob)
-    chunk = 64
-    # PyTorch-CPU convolutions on 49x40 inputs stop scaling (and collapse) well before 256 threads:
-    # pick the best of a few thread counts on a tiny sample, then use it for both legs.
-    best, cores = None, 1
+    audio = synth.clips_float32(n_clips, first_clip=first_clip)
+    eo = heads = None
+    if kind != "frontend":
+        from oracle.efficientnet_oracle import EmbeddingOracle
+        from oracle import head_oracle as ho
+        eo = EmbeddingOracle(weights.synthetic_blob())
+        heads = [ho.glorot_uniform_params(seed=2000 + k) for k in range(50 if kind == "stream" else 1)]
+        labels = np.arange(n_clips) % 3
+    chunk = 32 if kind != "frontend" else 64
     with torch.no_grad():
-        for t in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
-            torch.set_num_threads(t)
-            eo.forward(spec_batch_np[:4])
-            t0 = time.perf_counter()
-            eo.forward(spec_batch_np[:16])
-            dt = time.perf_counter() - t0
-            if best is None or dt < best:
-                best, cores = dt, t
-    torch.set_num_threads(cores)
-    done, t_fe, t_em = 0, 0.0, 0.0
-    t_start = time.perf_counter()
-    with torch.no_grad():
-        fo.run_batch_f32(audio_np[:8], nthreads=cores)      # warm-up
-        eo.forward(spec_batch_np[:8])
-        while done + chunk <= audio_np.shape[0]:
-            t0 = time.perf_counter()
-            spec = fo.run_batch_f32(audio_np[done:done + chunk], nthreads=cores)
-            t1 = time.perf_counter()
+        spec = fo.run_batch_f32(audio[:4], nthreads=threads)          # warm-up
+        if eo is not None:
             eo.forward(spec)
-            t2 = time.perf_counter()
-            t_fe += t1 - t0
-            t_em += t2 - t1
+        q.put(("ready", idx))
+        go.wait()
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            a = audio[(done % n_clips):(done % n_clips) + chunk]
+            if a.shape[0] < chunk:
+                a = audio[:chunk]
+            spec = fo.run_batch_f32(a, nthreads=threads)
+            if eo is not None:
+                emb = eo.forward(spec).numpy()
+                if kind == "finetune":
+                    _, g, _, _ = ho.loss_and_grad(heads[0], emb, labels[:chunk])
+                    heads[0] = (heads[0] - 1e-3 * g).astype(np.float32)
+                elif kind == "stream":
+                    for p in heads:
+                        ho.forward(p, emb)
             done += chunk
-            if time.perf_counter() - t_start > budget_s:
-                break
-    total = t_fe + t_em
-    return {
-        "value": round(done / total, 2), "unit": "clips/s", "cores": cores, "host_cores": ncpu, "kind": "port",
-        "sample": f"{done} clips of the same synthetic batch: oracle C micro-frontend (OpenMP, {cores} threads) "
-                  f"+ PyTorch-CPU fp32 EfficientNet-B0 embedding ({cores} threads); TensorFlow not installable here",
-        "frontend_clips_per_s": round(done / t_fe, 1), "embedding_clips_per_s": round(done / t_em, 1),
-    }
+        q.put(("done", idx, done, time.perf_counter() - t0))
+
+
+def cpu_baseline(kind, budget_s):
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    threads = 1 if kind == "frontend" else min(8, ncpu)           # PyTorch-CPU convs on 49x40 images stop scaling near 8 threads
+    procs = max(1, min(ncpu // threads, 64))
+    ctx = mp.get_context("spawn")
+    q, go = ctx.Queue(), ctx.Event()
+    ps = [ctx.Process(target=_cpu_worker, args=(kind, i, threads, 128, 1024 + 128 * i, budget_s, q, go)) for i in range(procs)]
+    for p in ps:
+        p.start()
+    import queue as _queue
+
+    def get(deadline):
+        while True:
+            try:
+                return q.get(timeout=2)
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in ps) or time.time() > deadline:
+                    for p in ps:
+                        p.kill()
+                    raise RuntimeError("cpu_baseline: a worker process died or timed out")
+    ready = 0
+    while ready < procs:
+        ready += get(time.time() + 300)[0] == "ready"
+    go.set()
+    t0 = time.perf_counter()
+    total, longest = 0, 0.0
+    for _ in range(procs):
+        m = get(time.time() + budget_s + 120)
+        total += m[2]
+        longest = max(longest, m[3])
+    wall = max(time.perf_counter() - t0, longest)
+    for p in ps:
+        p.join(30)
+    what = {"frontend": "oracle C micro-frontend", "embed": "oracle C micro-frontend + PyTorch-CPU fp32 EfficientNet-B0 embedding",
+            "finetune": "oracle C micro-frontend + PyTorch-CPU fp32 embedding + numpy head loss/gradient/update (augmentation not included)",
+            "stream": "oracle C micro-frontend per 1 s window (no frame sharing, as the reference) + PyTorch-CPU fp32 embedding + 50 numpy heads"}[kind]
+    unit = "windows/s" if kind == "stream" else "clips/s"
+    return {"value": round(total / wall, 2), "unit": unit, "cores": procs * threads, "host_cores": ncpu, "procs": procs,
+            "threads_per_proc": threads, "kind": "port",
+            "sample": f"{total} synthetic clips in {wall:.1f} s: {what}; {procs} processes x {threads} threads; TensorFlow not installable here"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def source_hash():
+    """sha256 over the device sources: ties profiles/pmc_traffic.json to the build it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "multilingual_kws_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes (tools/pmc_to_json.py) -- only if they were collected on THIS
+    build of the kernels (source hash match); a stale file yields null, never an old number."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if d.get("_source_hash") != source_hash():
+        return None, f"profiles/pmc_traffic.json is from build {d.get('_source_hash')}, this is {source_hash()}"
+    e = d.get(kernel)
+    return (e.get("hbm_bytes_per_launch"), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same build") if e else (None, "kernel not in pmc_traffic.json")
+
+
+def embed_roofline(em, spec, B, reps, arch, extra=None):
+    """Dominant kernel of the embedding forward: per-launch hipEvent timing inside the library, on the launch stream."""
+    costs = arch.stage_costs(B)
+    prof = em.profile(spec, reps=reps)
+    per_kernel = dict(extra or {})
+    for stage, kernel, ms in prof:
+        k = per_kernel.setdefault(kernel, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+        k["ms"] += ms
+        k["launches"] += 1
+        if stage.endswith("#reduce"):
+            cost = (0.0, 0.0)          # helper launch (split-K / SE partial): its work is booked on the main stage
+        elif kernel == "stem_dw_kernel":
+            cost = costs["stem_dw"]
+        elif kernel == "stem_block1a_kernel":
+            cost = costs["stem_block1a"]
+        elif kernel.startswith("mbconv_front"):
+            cost = costs[stage.replace("_dw", "_front")]
+        elif kernel.startswith("mbconv_block") or kernel.startswith("mbconv_mid"):
+            cost = costs[stage + "_block"]
+        else:
+            cost = costs[stage]
+        k["flops"] += cost[0]
+        k["bytes"] += cost[1]
+    return per_kernel, sum(ms for _, _, ms in prof)
+
+
+def roofline_of(per_kernel):
+    dom_name = max(per_kernel, key=lambda n: per_kernel[n]["ms"])
+    dom = per_kernel[dom_name]
+    avg_ms = dom["ms"] / dom["launches"]
+    t_flops = dom["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    t_bytes = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
+    traffic, traffic_src = measured_traffic(dom_name)
+    if t_flops >= t_bytes:
+        ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic}
+    else:
+        ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
+    roof.update({"kernel": dom_name, "launches_per_step": dom["launches"], "avg_launch_ms": round(avg_ms, 5), "traffic_source": traffic_src,
+                 "algorithmic_per_launch": {"flops": dom["flops"] / dom["launches"], "bytes": dom["bytes"] / dom["launches"]}})
+    kernels = {n: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
+               for n, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])}
+    return roof, kernels
+
+
+def event_ms(fn, reps):
+    """Average duration of fn() on torch's current stream (the stream every mkws_* call is launched on)."""
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0:
+        if args.gpus > 1:
+            respawn_under_torchrun(args)
+        world = 1
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    from multilingual_kws_amd import arch, synth, weights
+    from multilingual_kws_amd import arch, parallel, synth, weights
     from multilingual_kws_amd.embedding_model import EmbeddingModel
     from multilingual_kws_amd.frontend import Frontend
+    from multilingual_kws_amd.head import Head
 
-    B = args.batch
-    blob = weights.synthetic_blob()
+    cfg = args.config
+    B = args.batch or {"embed": 1024, "frontend": 1024, "finetune": 512, "stream": 256}[cfg]
+    blob = weights.synthetic_blob() if cfg != "frontend" else None
     fe = Frontend(max_samples=16000)
-    em = EmbeddingModel(blob, max_batch=B, device=dev)
+    em = EmbeddingModel(blob, max_batch=B, device=dev) if blob is not None else None
     for kv in args.opt:
         name, _, val = kv.partition("=")
         em.set_option(name, int(val))
@@ -122,10 +292,56 @@ def main():
     audio = torch.from_numpy(audio_np).to(dev)
     spec = torch.empty((B, 49, 40), dtype=torch.float32, device=dev)
     emb = torch.empty((B, 1024), dtype=torch.float32, device=dev)
+    units_per_step, unit, extra_out = B, "clips/s", {}
 
-    def step():
-        fe.forward(audio, out=spec)
-        em.forward(spec, out=emb)
+    if cfg == "embed":
+        metric = "clips/sec end-to-end (log-mel + embedding fwd), batch 1024, 1s@16kHz"
+        workload = ("configs[2]: batch=1024/GPU synthetic 1s@16kHz clips -> micro-frontend (int16 fixed-point, fp32 I/O) -> "
+                    "EfficientNet-B0 embedding forward (frozen, fp32 MFMA pointwise conv) -> [1024,1024]")
+
+        def step():
+            fe.forward(audio, out=spec)
+            em.forward(spec, out=emb)
+    elif cfg == "frontend":
+        metric = "clips/sec micro-frontend only, batch 1024, 1s@16kHz"
+        workload = "configs[1]: batch=1024/GPU synthetic 1s@16kHz fp32 clips -> micro-frontend -> [1024,49,40] fp32 (71 840 algorithmic bytes/clip)"
+
+        def step():
+            fe.forward(audio, out=spec)
+    elif cfg == "finetune":
+        from multilingual_kws_amd.embedding import input_data
+        metric = "clips/sec 5-shot 3-class head fine-tune step (augment + log-mel + frozen embedding fwd + head fwd/bwd/Adam), batch 512/GPU"
+        workload = ("configs[3]: 512 clips/GPU per step from 5 target + 256 unknown clips + 4x60 s background (synthetic): augmentation -> "
+                    "micro-frontend -> SpecAugment -> EfficientNet-B0 forward (frozen) -> head loss/gradient -> "
+                    "one RCCL all-reduce of 18 509 floats (N > 1) -> Keras Adam")
+        tmp = tempfile.mkdtemp(prefix="mkws_ft_")
+        d = synth.write_fewshot_dataset(tmp)
+        ms = input_data.standard_microspeech_model_settings(3)
+        ds = input_data.AudioDataset(ms, ["target"], d["bg_dir"], d["unknown"], unknown_percentage=50.0,
+                                     spec_aug_params=input_data.SpecAugParams(percentage=80), seed=1 + 1000003 * rank)
+        it = iter(ds.init_single_target(input_data.AUTOTUNE, d["train"], is_training=True).shuffle(1000).repeat().batch(B))
+        p0 = np.random.default_rng(0).uniform(-0.07, 0.07, 18507).astype(np.float32)      # identical head on every rank
+        head = Head(params=p0, max_batch=B, device=dev)
+
+        def step():
+            s, labels = next(it)
+            e = em.forward(s, out=emb)
+            parallel.dp_step(head, e, labels, lr=1e-3)
+    else:   # stream
+        from multilingual_kws_amd.embedding import batch_streaming_analysis as bsa, input_data
+        metric = "windows/sec streaming inference, 50 keywords on one shared embedding, 20 ms hop, batch 256"
+        workload = ("configs[4]: 60 s synthetic stream -> 2950 one-second windows (20 ms hop, frame-sharing micro-frontend) -> EfficientNet-B0 "
+                    "embedding in batches of 256 windows -> 50 few-shot heads in one launch; batch-1 latency reported beside it")
+        ms = input_data.standard_microspeech_model_settings(3)
+        stream = torch.from_numpy(np.concatenate([synth.clips_float32(1, first_clip=60 * rank + i)[0] for i in range(60)])).to(dev)
+        heads = [Head(max_batch=B, seed=2000 + k, device=dev) for k in range(50)]
+        nwin = len(bsa.window_offsets(stream.shape[0], 16000, 320))
+        units_per_step, unit = nwin, "windows/s"
+
+        def step():
+            specs = bsa.stream_spectrograms(ms, stream, 16000, 320)
+            for s in range(0, specs.shape[0], B):
+                Head.forward_many(heads, em.forward(specs[s:s + B]))
 
     def fence():
         torch.cuda.synchronize()
@@ -146,90 +362,61 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
+    value = world * units_per_step * args.steps / elapsed
 
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel, hipEvent-timed per launch on the launch stream ----
-        costs = arch.stage_costs(B)
-        prof = em.profile(spec, reps=args.profile_reps)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.profile_reps):
-            fe.forward(audio, out=spec)
-        e1.record()
-        torch.cuda.synchronize()
-        fe_ms = e0.elapsed_time(e1) / args.profile_reps
-        per_kernel = {"frontend_clip_kernel<float,4>": {"ms": fe_ms, "launches": 1, "flops": 0.0,
-                                                       "bytes": float(B * arch.FRONTEND_BYTES_PER_CLIP_F32)}}
-        for stage, kernel, ms in prof:
-            k = per_kernel.setdefault(kernel, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-            k["ms"] += ms
-            k["launches"] += 1
-            if stage.endswith("#reduce"):
-                cost = (0.0, 0.0)          # helper launch (split-K / SE partial): its work is booked on the main stage
-            else:
-                if kernel == "stem_dw_kernel":
-                    cost = costs["stem_dw"]
-                elif kernel == "stem_block1a_kernel":
-                    cost = costs["stem_block1a"]
-                elif kernel.startswith("mbconv_front"):
-                    cost = costs[stage.replace("_dw", "_front")]
-                elif kernel.startswith("mbconv_block"):
-                    cost = costs[stage + "_block"]
-                else:
-                    cost = costs[stage]
-            k["flops"] += cost[0]
-            k["bytes"] += cost[1]
-        dom_name = max(per_kernel, key=lambda n: per_kernel[n]["ms"])
-        dom = per_kernel[dom_name]
-        avg_ms = dom["ms"] / dom["launches"]
-        t_flops = dom["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
-        t_bytes = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        if t_flops >= t_bytes:
-            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic}
+        fe.forward(audio, out=spec)
+        fe_ms = event_ms(lambda: fe.forward(audio, out=spec), args.profile_reps)
+        fe_entry = {"frontend_clip_kernel<float,4>": {"ms": fe_ms, "launches": 1, "flops": 0.0,
+                                                     "bytes": float(B * arch.FRONTEND_BYTES_PER_CLIP_F32)}}
+        whole = {"frontend_ms": round(fe_ms, 4)}
+        if cfg == "frontend":
+            per_kernel = fe_entry
         else:
-            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
-        roof.update({"kernel": dom_name, "launches_per_step": dom["launches"], "avg_launch_ms": round(avg_ms, 5),
-                     "algorithmic_per_launch": {"flops": dom["flops"] / dom["launches"], "bytes": dom["bytes"] / dom["launches"]}})
-        kernels = {n: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
-                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
-                       "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
-                   for n, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])}
+            per_kernel, emb_ms = embed_roofline(em, spec, B, args.profile_reps, arch, extra=None if cfg == "stream" else fe_entry)
+            whole.update({"embedding_ms": round(emb_ms, 4),
+                          "tflops": round(units_per_step * arch.EMBED_FLOPS_PER_CLIP / (ms_per_step * 1e-3) / 1e12, 2)})
+        roof, kernels = roofline_of(per_kernel)
+        if cfg == "stream":
+            one = audio[:1].contiguous()
+            em1 = EmbeddingModel(blob, max_batch=1, device=dev)          # small-batch handles plan the multi-kernel path
+            heads1 = [h for h in heads]
+
+            def one_window():
+                Head.forward_many(heads1, em1.forward(fe.forward(one)))
+            for _ in range(20):
+                one_window()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(200):
+                one_window()
+                torch.cuda.synchronize()
+            extra_out["latency_ms_batch1"] = round((time.perf_counter() - t1) / 200 * 1e3, 4)
+            extra_out["windows_per_stream"] = nwin
         result = {
-            "metric": "clips/sec end-to-end (log-mel + embedding fwd), batch 1024, 1s@16kHz",
-            "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": round(value, 1), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: batch=1024/GPU synthetic 1s@16kHz clips -> micro-frontend (int16 fixed-point, "
-                                   "fp32 I/O) -> EfficientNet-B0 embedding forward (frozen, fp32 MFMA pointwise conv) -> [1024,1024]",
-                       "clips_per_gpu": B, "samples_per_clip": 16000, "weights": "synthetic seed 1234", "parallelism": f"clip-sharded x{world}"},
-            "roofline": roof,
-            "kernels": kernels,
-            "whole_step": {"tflops": round(B * arch.EMBED_FLOPS_PER_CLIP / (ms_per_step * 1e-3) / 1e12, 2),
-                           "frontend_ms": round(fe_ms, 4), "embedding_ms": round(sum(ms for _, _, ms in prof), 4)},
+            "config": {"workload": workload, "name": cfg, "clips_per_gpu": units_per_step, "samples_per_clip": 16000,
+                       "weights": "synthetic seed 1234", "parallelism": f"clip-sharded x{world}", "build": source_hash()},
+            "roofline": roof, "kernels": kernels, "whole_step": whole,
         }
-        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
-            spec_np = spec[:512].cpu().numpy()
-            result["cpu_baseline"] = cpu_baseline(spec_np, audio_np[:512], blob, args.cpu_seconds)
-        else:
-            result["cpu_baseline"] = None
+        result.update(extra_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
+            del em, fe
+            torch.cuda.empty_cache()
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+            except Exception as exc:      # the GPU measurement stands on its own; say what happened to the baseline
+                result["cpu_baseline"] = {"value": None, "unit": unit, "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

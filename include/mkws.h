@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKWS_ABI_VERSION 1
+#define MKWS_ABI_VERSION 2
 
 typedef enum mkws_status {
   MKWS_OK = 0,
@@ -186,10 +186,16 @@ int mkws_head_create(int in_dim, int hidden, int classes, int max_batch, mkws_he
 void mkws_head_destroy(mkws_head* hd);
 int mkws_head_param_count(const mkws_head* hd);
 /* Device pointers into the handle's own state (valid until destroy): params, grads, Adam m, Adam v.
- * Exposed so the data-parallel host code can all-reduce the flat gradient with RCCL in place. */
+ * Exposed so the data-parallel host code can all-reduce the flat gradient with RCCL in place.
+ * The gradient buffer holds mkws_head_grad_count() = P + 2 floats: the P gradients followed by the two
+ * statistics of the last mkws_head_loss_grad call {sum of per-row loss, number of correct argmax rows}, so
+ * that one data-parallel step is ONE all-reduce(sum) over that range. */
 float* mkws_head_params(mkws_head* hd);
 float* mkws_head_grads(mkws_head* hd);
-int mkws_head_set_params(mkws_head* hd, const float* h_params, int n);   /* also zeroes Adam state */
+int mkws_head_grad_count(const mkws_head* hd);
+/* Uploads h_params (host) and zeroes the gradient and Adam state, ordered on `stream`; returns after the
+ * stream has drained (h_params may be pageable). */
+int mkws_head_set_params(mkws_head* hd, const float* h_params, int n, void* stream);
 int mkws_head_get_params(mkws_head* hd, float* h_params, int n, void* stream);
 /* d_emb [B,in] -> d_probs [B,classes] (softmax probabilities, what model.predict returns). */
 int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, void* stream);
@@ -198,8 +204,9 @@ int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, 
  * -> d_probs [n_heads, B, classes].  `heads` is a host array of handles. */
 int mkws_heads_forward(mkws_head* const* heads, int n_heads, const float* d_emb, int B, float* d_probs, void* stream);
 /* Forward + mean sparse-CE loss + backward into the handle's grad buffer (gradient of the MEAN loss
- * over these B rows).  d_labels int32 [B].  d_stats float32[2] receives {sum of per-row loss,
- * number of correct argmax predictions} for these B rows. */
+ * over these B rows).  d_labels int32 [B].  d_stats float32[2] (optional, may be NULL) receives {sum of
+ * per-row loss, number of correct argmax predictions} for these B rows; the same two values are always
+ * written behind the gradient (mkws_head_grads()[P], [P+1]). */
 int mkws_head_loss_grad(mkws_head* hd, const float* d_emb, const int32_t* d_labels, int B,
                         float* d_stats, void* stream);
 /* Keras Adam update from the grad buffer (grad is multiplied by grad_scale first, e.g. 1/world_size

@@ -59,7 +59,8 @@ SYMBOLS = [
     ("mkws_head_param_count", _I, [_P]),
     ("mkws_head_params", _P, [_P]),
     ("mkws_head_grads", _P, [_P]),
-    ("mkws_head_set_params", _I, [_P, _P, _I]),
+    ("mkws_head_grad_count", _I, [_P]),
+    ("mkws_head_set_params", _I, [_P, _P, _I, _P]),
     ("mkws_head_get_params", _I, [_P, _P, _I, _P]),
     ("mkws_head_forward", _I, [_P, _P, _I, _P, _P]),
     ("mkws_heads_forward", _I, [ctypes.POINTER(_P), _I, _P, _I, _P, _P]),

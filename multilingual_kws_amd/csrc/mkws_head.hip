@@ -161,7 +161,9 @@ __global__ __launch_bounds__(256) void head_dw1_partial_kernel(HeadDims d, const
   }
 }
 
-// final reduce: grads = [sum of partials | db1 | dW2 | db2], stats = {sum loss, sum correct}
+// final reduce: grads = [sum of partials | db1 | dW2 | db2 | sum loss, sum correct]; the two statistics ride
+// behind the gradient so that a data-parallel step is ONE all-reduce of nparams + 2 floats; `stats` (optional)
+// receives a copy of them
 __global__ __launch_bounds__(256) void head_grad_finish_kernel(HeadDims d, const float* __restrict__ partial, int splits,
                                                                const float* __restrict__ hbuf, const float* __restrict__ dz,
                                                                const float* __restrict__ dpre, const float* __restrict__ rowstat, int B,
@@ -186,11 +188,12 @@ __global__ __launch_bounds__(256) void head_grad_finish_kernel(HeadDims d, const
       for (int b = 0; b < B; ++b) s += dz[(size_t)b * d.cls + c];
     }
     grads[i] = s;
-  } else if (i < nW1 + nsmall + 2 && stats) {
+  } else if (i < nW1 + nsmall + 2) {
     const int t = i - nW1 - nsmall;
     float s = 0.0f;
     for (int b = 0; b < B; ++b) s += rowstat[2 * b + t];
-    stats[t] = s;
+    grads[i] = s;
+    if (stats) stats[t] = s;
   }
 }
 
@@ -236,7 +239,7 @@ int mkws_head_create(int in_dim, int hidden, int classes, int max_batch, mkws_he
   hd->d = {in_dim, hidden, classes};
   hd->max_batch = max_batch;
   hd->nparams = in_dim * hidden + hidden + hidden * classes + classes;
-  const size_t P = ((size_t)hd->nparams + 63) & ~size_t(63);
+  const size_t P = ((size_t)hd->nparams + 2 + 63) & ~size_t(63);      // + 2: the loss / accuracy sums behind the gradient
   if (hipMalloc(reinterpret_cast<void**>(&hd->d_state), 4 * P * sizeof(float)) != hipSuccess) { delete hd; return fail(MKWS_ERR_ALLOC, "hipMalloc failed"); }
   (void)hipMemset(hd->d_state, 0, 4 * P * sizeof(float));
   hd->params = hd->d_state; hd->grads = hd->d_state + P; hd->m = hd->d_state + 2 * P; hd->v = hd->d_state + 3 * P;
@@ -259,15 +262,21 @@ void mkws_head_destroy(mkws_head* hd) {
 }
 
 int mkws_head_param_count(const mkws_head* hd) { return hd ? hd->nparams : fail(MKWS_ERR_INVALID_ARG, "head handle is NULL"); }
+int mkws_head_grad_count(const mkws_head* hd) { return hd ? hd->nparams + 2 : fail(MKWS_ERR_INVALID_ARG, "head handle is NULL"); }
 float* mkws_head_params(mkws_head* hd) { return hd ? hd->params : nullptr; }
 float* mkws_head_grads(mkws_head* hd) { return hd ? hd->grads : nullptr; }
 
-int mkws_head_set_params(mkws_head* hd, const float* h_params, int n) {
+int mkws_head_set_params(mkws_head* hd, const float* h_params, int n, void* stream) {
   if (!hd || !h_params) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
   if (n != hd->nparams) return fail(MKWS_ERR_INVALID_ARG, "expected %d parameters, got %d", hd->nparams, n);
-  MKWS_HIP(hipMemcpy(hd->params, h_params, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-  const size_t P = ((size_t)hd->nparams + 63) & ~size_t(63);
-  MKWS_HIP(hipMemset(hd->grads, 0, 3 * P * sizeof(float)));
+  // ordered on the caller's stream like every other entry point (a null-stream copy could overtake a
+  // loss_grad / adam_step still in flight on a non-blocking stream); h_params is pageable host memory, so
+  // the stream is drained before returning
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MKWS_HIP(hipMemcpyAsync(hd->params, h_params, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+  const size_t P = ((size_t)hd->nparams + 2 + 63) & ~size_t(63);
+  MKWS_HIP(hipMemsetAsync(hd->grads, 0, 3 * P * sizeof(float), s));
+  MKWS_HIP(hipStreamSynchronize(s));
   return MKWS_OK;
 }
 

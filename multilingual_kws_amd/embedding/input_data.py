@@ -373,6 +373,11 @@ class AudioDataset:
     def _draw_specaug_masks(self, B):
         """int32 [B,8] mask table for mkws_specaug_apply (spec_augment / map_spec_aug distributions)."""
         p = self.spec_aug_params
+        if p.frequency_n_range > 2 or p.time_n_range > 2:
+            # the device mask table (mkws_specaug_apply) has two frequency and two time slots per clip; the
+            # reference loops freq_n / time_n times (input_data.py:306-364) -- refuse rather than truncate
+            raise ValueError(f"SpecAugParams with more than 2 masks per axis is not supported by mkws_specaug_apply "
+                             f"(frequency_n_range={p.frequency_n_range}, time_n_range={p.time_n_range})")
         frames, chans = self.model_settings["spectrogram_length"], self.model_settings["fingerprint_width"]
         masks = np.zeros((B, 8), dtype=np.int32)
         apply = self.rng.uniform(0, 1, B) < p.percentage / 100
@@ -436,8 +441,9 @@ class AudioDataset:
                 ctypes.c_void_p(bg.data_ptr()) if bg is not None else None, bg.shape[1] if bg is not None else 0,
                 ctypes.c_void_p(d_items.data_ptr()), B, n, ctypes.c_void_p(audio.data_ptr()), _lib.current_stream_ptr()))
             spec = to_micro_spectrogram(self.model_settings, audio)
+            self.last_masks = None
             if ds.is_training:
-                masks = self._draw_specaug_masks(B)
+                masks = self.last_masks = self._draw_specaug_masks(B)
                 if masks.any():
                     d_masks = torch.from_numpy(masks).to(self.device)
                     _lib.check(L.mkws_specaug_apply(ctypes.c_void_p(spec.data_ptr()), ctypes.c_void_p(d_masks.data_ptr()), B,

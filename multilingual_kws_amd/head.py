@@ -33,6 +33,7 @@ class Head:
         self.max_batch = int(max_batch)
         self.nparams = _lib.check(self.L.mkws_head_param_count(self.h))
         self.step_t = 0
+        self._views = {}
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.set_params(params if params is not None else glorot_uniform_params(in_dim, hidden, classes, seed))
 
@@ -51,7 +52,7 @@ class Head:
         import torch
         p = np.ascontiguousarray(p, dtype=np.float32)
         with torch.cuda.device(self.device):
-            _lib.check(self.L.mkws_head_set_params(self.h, p.ctypes.data, p.shape[0]))
+            _lib.check(self.L.mkws_head_set_params(self.h, p.ctypes.data, p.shape[0], _lib.current_stream_ptr()))
         self.step_t = 0
 
     def get_params(self):
@@ -61,21 +62,26 @@ class Head:
             _lib.check(self.L.mkws_head_get_params(self.h, p.ctypes.data, self.nparams, _lib.current_stream_ptr()))
         return p
 
-    def grad_view(self):
-        """The flat gradient buffer as a torch tensor aliasing the handle's device memory (for RCCL)."""
-        return self._alias(self.L.mkws_head_grads(self.h))
+    def grad_view(self, with_stats=False):
+        """The flat gradient buffer as a torch tensor aliasing the handle's device memory (for RCCL).
+        with_stats: the all-reduce payload [P gradients | sum of row losses | #correct] (mkws_head_grad_count)."""
+        n = _lib.check(self.L.mkws_head_grad_count(self.h)) if with_stats else self.nparams
+        return self._alias(self.L.mkws_head_grads(self.h), n)
 
     def param_view(self):
-        return self._alias(self.L.mkws_head_params(self.h))
+        return self._alias(self.L.mkws_head_params(self.h), self.nparams)
 
-    def _alias(self, ptr):
+    def _alias(self, ptr, n):
         import torch
-
-        class _Holder:   # __cuda_array_interface__ producer over raw device memory
-            pass
-        hld = _Holder()
-        hld.__cuda_array_interface__ = {"shape": (self.nparams,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
-        return torch.as_tensor(hld, device=self.device)
+        key = (int(ptr), int(n))
+        t = self._views.get(key)
+        if t is None:
+            class _Holder:   # __cuda_array_interface__ producer over raw device memory
+                pass
+            hld = _Holder()
+            hld.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+            t = self._views[key] = torch.as_tensor(hld, device=self.device)
+        return t
 
     def forward(self, emb):
         """emb CUDA [B,in] -> probs CUDA [B,classes]."""

@@ -34,3 +34,36 @@ def clips_int16(num_clips, num_samples=16000, seed=0x5EED0000, first_clip=0):
 
 def clips_float32(num_clips, num_samples=16000, seed=0x5EED0000, first_clip=0):
     return clips_int16(num_clips, num_samples, seed, first_clip).astype(np.float32) / np.float32(32768.0)
+
+
+def wav_bytes(pcm16, rate=16000):
+    """Mono PCM16 RIFF/WAVE file image (what decode_wav reads)."""
+    import struct
+    data = np.asarray(pcm16, dtype="<i2").tobytes()
+    return (b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " +
+            struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * 2, 2, 16) + b"data" + struct.pack("<I", len(data)) + data)
+
+
+def write_fewshot_dataset(root, n_target=5, n_val=8, n_unknown=256, n_bg=4, bg_seconds=60):
+    """The synthetic fine-tune set of SURVEY.md section 8d (BASELINE configs[3]): n_target target clips,
+    n_unknown "unknown word" clips and n_bg background tracks of bg_seconds, all from clips_int16 with distinct
+    seeds, written as 16 kHz PCM16 WAV files in the reference's directory conventions.
+    Returns {"train", "val", "unknown": file lists, "bg_dir"}."""
+    import os
+    out = {"train": [], "val": [], "unknown": [], "bg_dir": os.path.join(root, "_background_noise_")}
+
+    def put(path, pcm):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "wb") as f:
+            f.write(wav_bytes(pcm))
+        return path
+    tgt = clips_int16(n_target + n_val, seed=0x7A60E700)
+    for i in range(n_target + n_val):
+        (out["train"] if i < n_target else out["val"]).append(put(os.path.join(root, "target", f"t{i}.wav"), tgt[i]))
+    unk = clips_int16(n_unknown, seed=0x0BAD0000)
+    for i in range(n_unknown):
+        out["unknown"].append(put(os.path.join(root, "unknown", f"u{i}.wav"), unk[i]))
+    for i in range(n_bg):
+        bg = clips_int16(1, num_samples=16000 * bg_seconds, seed=0xB6000000 + i)[0] // 8
+        put(os.path.join(out["bg_dir"], f"bg{i}.wav"), bg)
+    return out

@@ -45,9 +45,12 @@ def synthetic_blob(seed=DEFAULT_SEED, calibrate=True):
     """Seeded random weights following the initialisers the reference's model definition uses
     (EfficientNet conv: VarianceScaling(2, fan_out, truncated_normal); Dense: glorot_uniform,
     dense_2: lecun_normal) with non-trivial BatchNorm parameters so BN folding is exercised.
-    With calibrate=True (default) the BatchNorm moving statistics are then set from the activations of
-    a few spectrogram-like calibration inputs (as a trained network's would be), so every layer stays
-    input-dependent and parity tests are sensitive to how data -- not just biases -- flows."""
+    With calibrate=True (default) the BatchNorm moving statistics are then replaced by calibrated ones (set
+    from the activations of a few spectrogram-like inputs, as a trained network's would be, so every layer
+    stays input-dependent and parity tests are sensitive to how data -- not just biases -- flows).  The
+    calibrated statistics are DATA shipped with the package (data/synthetic_bn_<seed>.npy, written by
+    tools/calibrate_synthetic_bn.py, which holds the recipe); the product package itself contains no
+    host-side forward pass of the network."""
     rng = np.random.default_rng(seed)
     tensors = manifest()
     blob = np.zeros(tensors[-1]["offset"] + tensors[-1]["count"], dtype=np.float32)
@@ -81,76 +84,23 @@ def synthetic_blob(seed=DEFAULT_SEED, calibrate=True):
             raise ValueError(f"no initialiser for {name}")
         blob[t["offset"]:t["offset"] + t["count"]] = v.reshape(-1)
     if calibrate:
-        _calibrate_bn(blob, tensors, np.random.default_rng(seed + 1))
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"synthetic_bn_{int(seed)}.npy")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: run `python tools/calibrate_synthetic_bn.py --seed {int(seed)}` "
+                                    "(or pass calibrate=False for uncalibrated BatchNorm statistics)")
+        stats = np.load(path)
+        o = 0
+        for t in bn_stat_tensors(tensors):
+            blob[t["offset"]:t["offset"] + t["count"]] = stats[o:o + t["count"]]
+            o += t["count"]
+        if o != stats.shape[0]:
+            raise ValueError(f"{path} holds {stats.shape[0]} values, this architecture has {o} BatchNorm statistics")
     return blob
 
 
-def _calibrate_bn(blob, tensors, rng, n_clips=32):
-    """Sets every */moving_mean and */moving_variance from float64 activations of n_clips random
-    spectrogram-like inputs (+ seeded perturbation), quantised to a 2^-12 grid so the result does not
-    depend on the host's floating-point library.  Host-side weight synthesis only -- not a compute path."""
-    import torch
-    import torch.nn.functional as F
-    from .arch import BLOCKS
-    T = {t["name"]: t for t in tensors}
-
-    def get(name):
-        t = T[name]
-        return torch.from_numpy(blob[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"]).astype(np.float64))
-
-    def put(name, v):
-        t = T[name]
-        blob[t["offset"]:t["offset"] + t["count"]] = np.asarray(v, dtype=np.float32).reshape(-1)
-
-    def bn(x, p):
-        c = x.shape[1]
-        mean = x.mean(dim=(0, 2, 3)).numpy()
-        var = x.var(dim=(0, 2, 3), unbiased=False).numpy()
-        var = np.maximum(var, 0.1 * var.mean()) + 1e-5     # no near-dead channels: bounded gain
-        mean = mean + 0.1 * np.sqrt(var) * rng.standard_normal(c)
-        var = var * rng.uniform(0.7, 1.4, c)
-        mean = np.round(mean * 4096.0) / 4096.0
-        var = np.maximum(np.round(var * 4096.0), 1.0) / 4096.0
-        put(p + "/moving_mean", mean)
-        put(p + "/moving_variance", var)
-        g, b = get(p + "/gamma"), get(p + "/beta")
-        m, v = torch.from_numpy(mean), torch.from_numpy(var)
-        return (x - m.view(1, -1, 1, 1)) * (g / torch.sqrt(v + 1e-3)).view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
-
-    def conv(x, name, stride=1, bias=None):
-        return F.conv2d(x, get(name).permute(3, 2, 0, 1).contiguous(), None if bias is None else get(bias), stride=stride)
-
-    def swish(x):
-        return x * torch.sigmoid(x)
-
-    # spectrogram-like calibration fields k * 10/256, k in [0, 670]: white, smooth, banded (tonal), sparse
-    q = n_clips // 4
-    white = rng.uniform(0, 1, (q, 1, 49, 40))
-    smooth = F.interpolate(torch.from_numpy(rng.uniform(0, 1, (q, 1, 13, 10))), size=(49, 40), mode="bilinear",
-                           align_corners=False).numpy()
-    bands = np.clip(0.15 * rng.uniform(0, 1, (q, 1, 49, 40)) + (rng.uniform(0, 1, (q, 1, 1, 40)) > 0.8) * rng.uniform(0.5, 1, (q, 1, 49, 1)), 0, 1)
-    sparse = rng.uniform(0, 1, (n_clips - 3 * q, 1, 49, 40)) * (rng.uniform(0, 1, (n_clips - 3 * q, 1, 49, 40)) > 0.7)
-    x = torch.from_numpy(np.round(np.concatenate([white, smooth, bands, sparse]) * 670.0) * (10.0 / 256.0))
-    with torch.no_grad():
-        x = x / 255.0
-        x = F.pad(x, (0, 1, 1, 1))
-        x = swish(bn(conv(x, "stem_conv/kernel", 2), "stem_bn"))
-        for name, cin, cout, k, s, e in BLOCKS:
-            p = "block" + name
-            inp = x
-            if e != 1:
-                x = swish(bn(conv(x, p + "_expand_conv/kernel"), p + "_expand_bn"))
-            c = k // 2
-            pad = (c - (1 - x.shape[3] % 2), c, c - (1 - x.shape[2] % 2), c) if s == 2 else (c, c, c, c)
-            dw = get(p + "_dwconv/depthwise_kernel").permute(2, 3, 0, 1).contiguous()
-            x = swish(bn(F.conv2d(F.pad(x, pad), dw, stride=s, groups=x.shape[1]), p + "_bn"))
-            se = x.mean(dim=(2, 3), keepdim=True)
-            se = swish(conv(se, p + "_se_reduce/kernel", bias=p + "_se_reduce/bias"))
-            x = x * torch.sigmoid(conv(se, p + "_se_expand/kernel", bias=p + "_se_expand/bias"))
-            x = bn(conv(x, p + "_project_conv/kernel"), p + "_project_bn")
-            if s == 1 and cin == cout:
-                x = x + inp
-        bn(conv(x, "top_conv/kernel"), "top_bn")
+def bn_stat_tensors(tensors=None):
+    """Manifest entries of every BatchNorm moving_mean / moving_variance, in manifest order."""
+    return [t for t in (tensors or manifest()) if t["name"].split("/")[-1] in ("moving_mean", "moving_variance")]
 
 
 def save(path, blob):

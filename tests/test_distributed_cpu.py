@@ -23,15 +23,18 @@ class OracleHead:
     def __init__(self, p0):
         self.p = np.asarray(p0, dtype=np.float64).copy()
         self.opt = None
-        self.g = torch.zeros(len(p0), dtype=torch.float64)
+        self.buf = torch.zeros(len(p0) + 2, dtype=torch.float64)     # gradients | sum of row losses | #correct
+        self.g = self.buf[:-2]
+        self.collectives = 0
 
     def loss_grad(self, emb, labels):
         _, g, ncorrect, lsum = ho.loss_and_grad(self.p, emb.numpy(), labels.numpy(), *DIMS)
         self.g.copy_(torch.from_numpy(g))
-        return torch.tensor([lsum, float(ncorrect)], dtype=torch.float64)
+        self.buf[-2], self.buf[-1] = lsum, float(ncorrect)
+        return self.buf[-2:].clone()
 
-    def grad_view(self):
-        return self.g
+    def grad_view(self, with_stats=False):
+        return self.buf if with_stats else self.g
 
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         if self.opt is None:
@@ -56,10 +59,18 @@ def _worker(rank, world, port, out):
         assert parallel.is_distributed() and parallel.world_size() == world and parallel.rank() == rank
         head = OracleHead(_p0())
         stats_log = []
+        calls, real_all_reduce = [], dist.all_reduce
+
+        def counting_all_reduce(t, *a, **k):
+            calls.append(t.numel())
+            return real_all_reduce(t, *a, **k)
+        dist.all_reduce = counting_all_reduce
         for step in range(4):
             x, y = _data(100 + step, 16)
             xs, ys = x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8]       # shard the batch across ranks
             stats_log.append(parallel.dp_step(head, xs, ys, lr=1e-2).tolist())
+        dist.all_reduce = real_all_reduce
+        assert calls == [len(head.p) + 2] * 4, calls          # ONE collective per step: gradients + the two statistics
         t = torch.from_numpy(head.p.copy())
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)

@@ -133,3 +133,38 @@ def test_unknown_files_bank_and_sample_check(tmp_path):
         input_data.check_one_second_16k(str(bank / "r8k.wav"))
     with pytest.raises(FileNotFoundError):
         input_data.load_unknown_files(tmp_path)
+
+
+def test_specaug_mask_table_and_its_two_slot_limit():
+    """Host draws for mkws_specaug_apply: [B,8] table inside the image, and no silent truncation of >2 masks per axis."""
+    from multilingual_kws_amd.embedding import input_data
+    ms = input_data.standard_microspeech_model_settings(3)
+    ds = input_data.AudioDataset(ms, ["t"], None, [], spec_aug_params=input_data.SpecAugParams(percentage=100), seed=0)
+    m = ds._draw_specaug_masks(4096)
+    assert m.shape == (4096, 8) and m.dtype == np.int32
+    for k in range(2):
+        fs, fz, ts, tz = m[:, 2 * k], m[:, 2 * k + 1], m[:, 4 + 2 * k], m[:, 5 + 2 * k]
+        assert fz.min() == 0 and fz.max() == 2 and ((fs + fz) <= 40 - 1).all()        # start ~ U{0..40-size-1}
+        assert tz.min() == 0 and tz.max() == 2 and ((ts + tz) <= 49 - 1).all()
+    n_freq = (m[:, 1] > 0).astype(int) + (m[:, 3] > 0)
+    assert abs((n_freq == 0).mean() - 1 / 3) < 0.05 and abs((n_freq == 2).mean() - 1 / 3) < 0.05   # freq_n ~ U{0,1,2}
+    for bad in (dict(frequency_n_range=3), dict(time_n_range=4)):
+        ds3 = input_data.AudioDataset(ms, ["t"], None, [], spec_aug_params=input_data.SpecAugParams(**bad), seed=0)
+        with pytest.raises(ValueError):
+            ds3._draw_specaug_masks(8)
+
+
+def test_shipped_bn_calibration_file_is_what_the_recipe_produces():
+    """multilingual_kws_amd/data/synthetic_bn_1234.npy (data shipped with the package) == tools/calibrate_synthetic_bn.py."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("calibrate_synthetic_bn", os.path.join(root, "tools", "calibrate_synthetic_bn.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    shipped = np.load(os.path.join(root, "multilingual_kws_amd", "data", "synthetic_bn_1234.npy"))
+    assert shipped.dtype == np.float32 and np.array_equal(shipped, tool.calibrated_stats(1234))
+    from multilingual_kws_amd import weights
+    assert sum(t["count"] for t in weights.bn_stat_tensors()) == shipped.shape[0]
+    with pytest.raises(FileNotFoundError):
+        weights.synthetic_blob(seed=99)                       # no silent uncalibrated fallback
+    assert weights.synthetic_blob(seed=99, calibrate=False).shape == (weights.weight_count(),)
