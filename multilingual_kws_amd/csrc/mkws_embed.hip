@@ -22,7 +22,9 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -43,6 +45,8 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// value the optimizer cannot see through (stops loop-invariant hoisting of cheap index arithmetic into spilled registers)
+__device__ __forceinline__ int opaque_(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_SWISH: return swishf_(v);
@@ -1269,31 +1273,6 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// Whole-MBConv kernel for the tiny-image blocks (4x3 and 2x2 inputs: blocks 4b..7a).
-// One workgroup owns one 16-row MFMA tile of activations (4 clips of 2x2, or 1 clip of 4x3) and carries it
-// through expand -> depthwise -> SE -> gated project entirely in LDS; every weight of the block streams
-// through the workgroup exactly once as MFMA A-operand fragments, the activations are the B operand read
-// from LDS.  Nothing but the block input and output touches HBM, and there is one launch per block.
-//   phase A  E[16, Cexp]   = swish(BN(X[16, Cin] . We))                     (waves split the Cexp/16 tiles)
-//   phase B  E <- swish(BN(depthwise(E))) in place, S[clip, Cexp] = sum over pixels   (thread = clip x quad)
-//   phase C  r = swish(S/HW . Wr + br);  gate = sigmoid(r . We2 + be)       (K split over waves / tiles over waves)
-//   phase D  Y[16, Cout]   = BN((E * gate) . Wp) (+ X)                      (waves split the Cout/16 tiles)
-struct BlockArgs {
-  const float* X; int Cin;
-  const float* WpE; const float* scE; const float* shE; int KCe; int NTe;
-  const float* Wd; const float* scD; const float* shD;
-  const float* WrP; const float* br; int NTR;
-  const float* We2P; const float* be;
-  const float* WpP; const float* scP; const float* shP; int NTp;
-  float* Y; int Cout; int residual;
-  float* dbg_dw; float* dbg_gate;
-  int B, Cexp, se;
-#ifdef MKWS_FRONT_TIMING
-  unsigned long long* dbg_t;
-#endif
-};
-
 // acc[q][m] += sum_j W(j, tile0 + tstride*q) . xfrag(j, m) for j in [0, KC): weight fragments via a
 // DEPTH-deep register ring (prologue / branch-free steady state / drain, so hipcc emits counted vmcnt
 // waits); every weight fragment feeds MT activation tiles.
@@ -1392,6 +1371,385 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
   }
   if (SPLIT) acc[0][0] += acc_odd;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Whole-MBConv kernel for big-image blocks (used for 3a and 4a): expand -> depthwise -> squeeze-excite -> gated
+// projection (+ residual) in ONE launch, G clips per workgroup, two workgroups per CU.  Only the block input and
+// the block output touch HBM: the 6x-expanded tensor lives in LDS one CC-channel chunk at a time, the depthwise
+// output of ALL channels stays in LDS, the SE FCs run inside the workgroup and the projection reads its gated
+// operand rows straight from LDS.
+//   once       block input -> LDS as MFMA B-operand fragments (zero padded rows / k)
+//   per chunk  P1: E[G*HW, CC] = swish(BN(X . We[:, chunk])): wave tasks = (row tile, n-tile); both operands are
+//                  lane-linear ds_read_b128 fragments
+//              P2: depthwise (one output pixel x channel quad per item, out-of-image taps read a zero row) + BN +
+//                  swish -> D[:, chunk]
+//              Constants are staged global -> registers -> LDS one phase ahead ("load early, write late"): P1
+//              requests the depthwise taps / BN constants that P2 of the same chunk needs and stores them just
+//              before the barrier; P2 does the same for the expand weights / BN constants of the next chunk.
+//              Two barriers per chunk.
+//   SE         channel means = fixed-order two-step column sums of D;  r = swish(mean . Wr + br) (thread =
+//              (unit, channel slice), slices folded in fixed order);  gate = sigmoid(r . We + be)
+//   project    wave = (n-tile, row-tile lane): the K fragments of its n-tile stream through a register ring
+//              (requested before the SE phase), each feeding the wave's row tiles; gated D rows are the MFMA B
+//              operands, read from LDS; BN, residual
+// Every reduction has a fixed order and nothing depends on the batch size: results are bit-identical across batches.
+// Measured (profiles/r02_notes.md): wins for 3a (50 vs 68 us) and 4a (33 vs 49 us); for 2a / 2b / 3b the per-clip
+// serialisation of MFMA and VALU phases (their depthwise outputs leave room for one or two clips per CU only) ties
+// the three-kernel path, which therefore stays in place for those blocks.
+struct MidArgs {
+  const float* X; int Cin;
+  const float* WpE; const float* scE; const float* shE; int NTtotE;
+  const float* Wd; const float* scD; const float* shD;
+  const float* Wr; const float* br; const float* We; const float* be; int se;
+  const float* WpP; const float* scP; const float* shP;
+  float* Y; int Cout; int residual;
+  float* dbg_dw; float* dbg_gate;
+  int B;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbg_t;
+#endif
+};
+
+template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int G, int SEG>
+struct MidGeom {
+  static constexpr int HW = HT * WT;
+  static constexpr int HoT = (S == 1) ? HT : (HT + 1) / 2, WoT = (S == 1) ? WT : (WT + 1) / 2;
+  static constexpr int HoWo = HoT * WoT;
+  static constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+  static constexpr int NSEG = WoT / SEG;
+  static constexpr int NC = (SEG - 1) * S + KS;
+  static constexpr int Q = CC / 4, NTC = CC / 16, LDE = CC + 4, LDD = CEXP + 4;
+  static constexpr int NCH = CEXP / CC;
+  static constexpr int KC = CEXP / 16;
+  static constexpr int MTI = (G * HW + 15) / 16, MTO = (G * HoWo + 15) / 16;
+  // constants staged per chunk, in float4 units: [expand weight fragments | scE | shE] for P1, [taps | scD | shD] for P2
+  static constexpr int NW4 = KCT * NTC * 64, NS1 = NW4 + 2 * Q, NS2 = KS * KS * Q + 2 * Q;
+  // LDS carve (floats)
+  static constexpr int oX = 0;                                   // [KCT][MTI][256]; after the chunk loop: SE partials
+  static constexpr int oS1 = oX + KCT * MTI * 256;               // P1 constants of the current chunk
+  static constexpr int oS2 = oS1 + NS1 * 4;                      // P2 constants of the current chunk
+  static constexpr int oE = oS2 + NS2 * 4;                       // [G*HW + 1 zero row][LDE]   (oS1 .. oD: column-sum partials after the chunk loop)
+  static constexpr int oD = oE + (G * HW + 1) * LDE;             // [G*HoWo][LDD]
+  static constexpr int oMean = oD + G * HoWo * LDD;
+  static constexpr int oGate = oMean + G * CEXP;
+  static constexpr int oR = oGate + G * CEXP;
+  static constexpr int lds_floats = oR + G * 16;
+  static_assert(NSEG * SEG == WoT, "segments tile the output row");
+  static_assert(CEXP % CC == 0 && CC % 16 == 0, "chunks are whole MFMA tiles");
+};
+
+template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int NTP, int G, int SEG, int NTHR, int WPE>
+__global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
+  using GM = MidGeom<KS, S, KCT, HT, WT, CEXP, CC, G, SEG>;
+  constexpr int HW = GM::HW, HoT = GM::HoT, WoT = GM::WoT, HoWo = GM::HoWo, PT = GM::PT, PLF = GM::PLF;
+  constexpr int NSEG = GM::NSEG, NC = GM::NC, Q = GM::Q, NTC = GM::NTC, LDE = GM::LDE, LDD = GM::LDD, NCH = GM::NCH, KC = GM::KC;
+  constexpr int MTI = GM::MTI, MTO = GM::MTO, NW4 = GM::NW4, NS1 = GM::NS1, NS2 = GM::NS2;
+  constexpr int NW = NTHR / 64;
+  constexpr int SE_MAX = 10;                                     // SE units of blocks 2a..4a: 4, 6, 6, 10, 10
+  constexpr int TAP_ROW_UNROLL = (KS == 5) ? 1 : KS;             // 5x5: one tap row at a time (register budget at 4 waves per SIMD)
+  constexpr int NSL = NTHR / 16;                                 // channel slices of the SE reduce FC
+  constexpr int CPS = (CEXP + NSL - 1) / NSL;                    // channels per slice
+  constexpr int CQ = CEXP / 4;                                   // channel quads of D
+  constexpr int RS = NTHR / (G * CQ);                            // row slices of the column-sum pass
+  constexpr int R1 = (NS1 + NTHR - 1) / NTHR, R2 = (NS2 + NTHR - 1) / NTHR;
+  static_assert(NTHR % 64 == 0 && NTHR >= CEXP && NTHR >= 16 * G && RS >= 1, "thread roles");
+  static_assert(NTHR * G <= KCT * MTI * 256 && G * RS * CEXP <= GM::oD - GM::oS1, "aliased scratch fits");
+  extern __shared__ __attribute__((aligned(16))) float s_mid[];
+  float* s_X = s_mid + GM::oX;
+  float* s_part = s_X;                                           // [NSL][16][G] SE reduce partials (X fragments are dead by then)
+  float* s_W = s_mid + GM::oS1;                                  // [KCT][NTC][256] expand weight fragments
+  float* s_scE = s_W + NW4 * 4;                                  // [CC], then shE [CC]
+  float* s_wd = s_mid + GM::oS2;                                 // [KS*KS][CC] depthwise taps
+  float* s_scD = s_wd + KS * KS * CC;                            // [CC], then shD [CC]
+  float* s_E = s_mid + GM::oE;
+  f32x4* s_csum = reinterpret_cast<f32x4*>(s_W);                 // [G][RS][CQ] column-sum partials (staged constants and E are dead by then)
+  float* s_D = s_mid + GM::oD;
+  float* s_mean = s_mid + GM::oMean;                             // [G][CEXP]
+  float* s_gate = s_mid + GM::oGate;                             // [G][CEXP]
+  float* s_r = s_mid + GM::oR;                                   // [G][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b0 = blockIdx.x * G;
+  const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
+  const int rows = gvalid * HW, rows_out = gvalid * HoWo;
+  const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbgp = a.dbg_t + (size_t)blockIdx.x * 8;
+  unsigned long long t_p1 = 0, t_p2 = 0, t_red = 0, t_mark = 0;
+  if (tid == 0) { t_mark = wall_clock64(); dbgp[0] = t_mark; }
+#endif
+  // staged constants: element e (float4) of a phase's list comes from base + chunk * stride
+  auto src1 = [&](int e, int chn) -> const float* {
+    if (e < NW4) {
+      const int l = e & 63, jn = e >> 6, j = jn / NTC, ntl = jn - j * NTC;
+      return a.WpE + (((size_t)j * a.NTtotE + chn * NTC + ntl) * 64 + l) * 4;
+    }
+    const int q = e - NW4;
+    return (q < Q ? a.scE + 4 * q : a.shE + 4 * (q - Q)) + chn * CC;
+  };
+  auto src2 = [&](int e, int chn) -> const float* {
+    if (e < KS * KS * Q) {
+      const int t = e / Q, q = e - t * Q;
+      return a.Wd + (size_t)t * CEXP + chn * CC + 4 * q;
+    }
+    const int q = e - KS * KS * Q;
+    return (q < Q ? a.scD + 4 * q : a.shD + 4 * (q - Q)) + chn * CC;
+  };
+  f32x4 st1[R1], st2[R2];
+  auto load1 = [&](int chn) {
+#pragma unroll
+    for (int k = 0; k < R1; ++k) { const int e = tid + k * NTHR; st1[k] = *reinterpret_cast<const f32x4*>(src1(e < NS1 ? e : NS1 - 1, chn)); }
+  };
+  auto store1 = [&]() {
+#pragma unroll
+    for (int k = 0; k < R1; ++k) { const int e = tid + k * NTHR; if (e < NS1) *reinterpret_cast<f32x4*>(s_W + 4 * e) = st1[k]; }
+  };
+  auto load2 = [&](int chn) {
+#pragma unroll
+    for (int k = 0; k < R2; ++k) { const int e = tid + k * NTHR; st2[k] = *reinterpret_cast<const f32x4*>(src2(e < NS2 ? e : NS2 - 1, chn)); }
+  };
+  auto store2 = [&]() {
+#pragma unroll
+    for (int k = 0; k < R2; ++k) { const int e = tid + k * NTHR; if (e < NS2) *reinterpret_cast<f32x4*>(s_wd + 4 * e) = st2[k]; }
+  };
+  // ---- prologue: P1 constants of chunk 0, the block input as B fragments, the zero row ----
+  load1(0);
+  for (int jm = wave; jm < KCT * MTI; jm += NW) {
+    const int j = jm / MTI, m = jm - j * MTI;
+    const int r = m * 16 + c;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + 16 * j + 4 * g);
+    *reinterpret_cast<f32x4*>(s_X + ((size_t)jm * 64 + lane) * 4) = v;
+  }
+  if (tid < LDE / 4) *reinterpret_cast<f32x4*>(s_E + (size_t)G * HW * LDE + 4 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  store1();
+  __syncthreads();
+
+  for (int chn = 0; chn < NCH; ++chn) {
+    const int ch0 = chn * CC;
+    // ---- P1: expand this chunk into LDS ----
+    load2(chn);
+    {
+      const int ntasks = ((rows + 15) / 16) * NTC;
+      for (int t = wave; t < ntasks; t += NW) {
+        const int rt = t / NTC, ntl = t - rt * NTC;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KCT; ++j) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(s_W + ((size_t)(j * NTC + ntl) * 64 + lane) * 4);
+          const f32x4 x = *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MTI + rt) * 64 + lane) * 4);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4], x[s4], acc, 0, 0, 0);
+        }
+        const int row = rt * 16 + c;
+        if (row < rows) {
+          f32x4 y = acc * *reinterpret_cast<const f32x4*>(s_scE + ntl * 16 + 4 * g) + *reinterpret_cast<const f32x4*>(s_scE + CC + ntl * 16 + 4 * g);
+          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+          *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + ntl * 16 + 4 * g) = y;
+        }
+      }
+    }
+    store2();
+    __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+    if (tid == 0) { const unsigned long long t = wall_clock64(); t_p1 += t - t_mark; t_mark = t; }
+#endif
+    // ---- P2: depthwise from LDS -> D[:, chunk] ----
+    if (chn + 1 < NCH) load1(chn + 1);
+    {
+      const int zrow = G * HW;
+      const int nitems = gvalid * HoT * NSEG * Q;
+      for (int item = tid; item < nitems; item += NTHR) {
+        int r = item / Q;
+        const int tq = item - r * Q;
+        const int sg = r % NSEG; r /= NSEG;
+        const int oh = r % HoT, gi = r / HoT;
+        const float* E0 = s_E + 4 * tq;
+        const int ih0 = oh * S - PT, iw0 = sg * SEG * S - PLF;
+        int coff[NC];
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) coff[ci] = ((unsigned)(iw0 + ci) < (unsigned)WT) ? iw0 + ci : -1;
+        f32x4 acc[SEG];
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll TAP_ROW_UNROLL
+        for (int i = 0; i < KS; ++i) {
+          const int ih = ih0 + i;
+          const bool rok = (unsigned)ih < (unsigned)HT;
+          const int rbase = gi * HW + ih * WT;
+          f32x4 v[NC], w[KS];
+#pragma unroll
+          for (int ci = 0; ci < NC; ++ci) {
+            const int row = (rok && coff[ci] >= 0) ? rbase + coff[ci] : zrow;
+            v[ci] = *reinterpret_cast<const f32x4*>(E0 + (size_t)row * LDE);
+          }
+#pragma unroll
+          for (int jx = 0; jx < KS; ++jx) w[jx] = *reinterpret_cast<const f32x4*>(s_wd + (i * KS + jx) * CC + 4 * tq);
+#pragma unroll
+          for (int o = 0; o < SEG; ++o)
+#pragma unroll
+            for (int jx = 0; jx < KS; ++jx) acc[o] += v[o * S + jx] * w[jx];
+        }
+        const f32x4 scd = *reinterpret_cast<const f32x4*>(s_scD + 4 * tq), shd = *reinterpret_cast<const f32x4*>(s_scD + CC + 4 * tq);
+        float* dout = s_D + (size_t)(gi * HoWo + oh * WoT + sg * SEG) * LDD + ch0 + 4 * tq;
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
+          f32x4 y = acc[o] * scd + shd;
+          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+          *reinterpret_cast<f32x4*>(dout + (size_t)o * LDD) = y;
+        }
+      }
+    }
+    if (chn + 1 < NCH) store1();
+    __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+    if (tid == 0) { const unsigned long long t = wall_clock64(); t_p2 += t - t_mark; t_mark = t; }
+#endif
+  }
+  // The weights of the remaining phases are requested here (L2 hits: every workgroup uses the same ones): the SE
+  // weights of this thread's role, and the first fragments of the projection weight stream of this wave's n-tile.
+  float wr_pre[CPS], we_pre[SE_MAX];
+  {
+    const int n = tid & 15, sl = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < CPS; ++i) {
+      const int ch = sl * CPS + i;
+      wr_pre[i] = (ch < CEXP && n < a.se) ? a.Wr[(size_t)ch * a.se + n] : 0.0f;
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < SE_MAX; ++n2) we_pre[n2] = (tid < CEXP && n2 < a.se) ? a.We[(size_t)n2 * CEXP + tid] : 0.0f;
+  }
+  const float br_pre = (tid < 16 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
+  const float be_pre = (tid < CEXP) ? a.be[tid] : 0.0f;
+  constexpr int NWP = NW / NTP;                                  // row-tile lanes per n-tile (waves beyond NWP*NTP idle in the projection)
+  constexpr int MTW = (MTO + NWP - 1) / NWP;                     // row tiles per wave
+  constexpr int PD = (KC >= 8) ? 8 : 4;                          // depth of the projection weight ring
+  const int ntp = wave % NTP, rlp = wave / NTP;
+  const float* p_w = a.WpP + (size_t)g * 64 + c * 4;
+  f32x4 wqp[PD][1];
+  if (rlp < NWP) stream_mfma_prefetch<1, PD>(wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC);
+  if (a.dbg_dw) {
+    for (int i = tid; i < rows_out * CQ; i += NTHR) {
+      const int r = i / CQ, q4 = (i - r * CQ) * 4;
+      *reinterpret_cast<f32x4*>(a.dbg_dw + (row0_out + r) * CEXP + q4) = *reinterpret_cast<const f32x4*>(s_D + (size_t)r * LDD + q4);
+    }
+  }
+  // ---- SE squeeze: column sums of D in two fixed-order steps (row slices, then slices) ----
+  if (tid < G * RS * CQ) {
+    const int q = tid % CQ, rs = (tid / CQ) % RS, gi = tid / (CQ * RS);
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int r = rs; r < HoWo; r += RS) t += *reinterpret_cast<const f32x4*>(s_D + (size_t)(gi * HoWo + r) * LDD + 4 * q);
+    s_csum[tid] = t;
+  }
+  __syncthreads();
+  if (tid < G * CQ) {
+    const int q = tid % CQ, gi = tid / CQ;
+    f32x4 t = s_csum[(size_t)gi * RS * CQ + q];
+#pragma unroll 4
+    for (int rs = 1; rs < RS; ++rs) t += s_csum[((size_t)gi * RS + rs) * CQ + q];
+    *reinterpret_cast<f32x4*>(s_mean + (size_t)gi * CEXP + 4 * q) = t * (1.0f / (float)HoWo);
+  }
+  __syncthreads();
+  // ---- SE reduce: thread (unit n, channel slice sl) folds its CPS channels; slices are then added in fixed order ----
+  {
+    const int n = tid & 15, sl = tid >> 4;
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < CPS; ++i) {
+        const int ch = sl * CPS + i;
+        v += s_mean[gi * CEXP + (ch < CEXP ? ch : 0)] * wr_pre[i];
+      }
+      s_part[(sl * 16 + n) * G + gi] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < 16 * G) {
+    const int n = tid / G, gi = tid - n * G;
+    float v = 0.0f;
+#pragma unroll 8
+    for (int sl = 0; sl < NSL; ++sl) v += s_part[(sl * 16 + n) * G + gi];
+    s_r[gi * 16 + n] = (n < a.se) ? swishf_(v + br_pre) : 0.0f;
+  }
+  __syncthreads();
+  if (tid < CEXP) {
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+      float v = be_pre;
+#pragma unroll
+      for (int n2 = 0; n2 < SE_MAX; ++n2) v += s_r[gi * 16 + n2] * we_pre[n2];
+      const float gt = sigmoidf_(v);
+      s_gate[gi * CEXP + tid] = gt;
+      if (a.dbg_gate && gi < gvalid) a.dbg_gate[(size_t)(b0 + gi) * CEXP + tid] = gt;
+    }
+  }
+  __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+  if (tid == 0) { const unsigned long long t = wall_clock64(); t_red += t - t_mark; t_mark = t; }
+#endif
+  // ---- gated projection (+ BN, residual): every weight fragment of the stream feeds this wave's MTW row tiles ----
+  if (rlp < NWP) {
+    const float* erow[MTW];
+    const float* grow[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      int r = (rlp + NWP * m) * 16 + c;
+      if (r >= G * HoWo) r = G * HoWo - 1;                       // padding rows / tiles past the end: any finite row, never stored
+      erow[m] = s_D + (size_t)r * LDD + 4 * g;
+      grow[m] = s_gate + (size_t)(r / HoWo) * CEXP + 4 * g;
+    }
+    struct EG { f32x4 e, g; };
+    auto xload = [&](int j, int m) { return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow[m] + 16 * j)}; };
+    auto xmake = [](const EG& v) { return v.e * v.g; };
+    f32x4 acc[1][MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) acc[0][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stream_mfma<1, PD, MTW, true>(acc, wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC, xload, xmake);
+    const int n = ntp * 16 + 4 * g;
+    if (n < a.Cout) {
+      const f32x4 scp = *reinterpret_cast<const f32x4*>(a.scP + n), shp = *reinterpret_cast<const f32x4*>(a.shP + n);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int r = (rlp + NWP * m) * 16 + c;
+        if (r < rows_out) {
+          f32x4 y = acc[0][m] * scp + shp;
+          if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + n);
+          *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+        }
+      }
+    }
+  }
+#ifdef MKWS_FRONT_TIMING
+  __syncthreads();
+  if (tid == 0) { const unsigned long long t = wall_clock64(); dbgp[1] = t_p1; dbgp[2] = t_p2; dbgp[3] = t_red; dbgp[4] = t - t_mark; dbgp[5] = t; }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole-MBConv kernel for the tiny-image blocks (4x3 and 2x2 inputs: blocks 4b..7a).
+// One workgroup owns one 16-row MFMA tile of activations (4 clips of 2x2, or 1 clip of 4x3) and carries it
+// through expand -> depthwise -> SE -> gated project entirely in LDS; every weight of the block streams
+// through the workgroup exactly once as MFMA A-operand fragments, the activations are the B operand read
+// from LDS.  Nothing but the block input and output touches HBM, and there is one launch per block.
+//   phase A  E[16, Cexp]   = swish(BN(X[16, Cin] . We))                     (waves split the Cexp/16 tiles)
+//   phase B  E <- swish(BN(depthwise(E))) in place, S[clip, Cexp] = sum over pixels   (thread = clip x quad)
+//   phase C  r = swish(S/HW . Wr + br);  gate = sigmoid(r . We2 + be)       (K split over waves / tiles over waves)
+//   phase D  Y[16, Cout]   = BN((E * gate) . Wp) (+ X)                      (waves split the Cout/16 tiles)
+struct BlockArgs {
+  const float* X; int Cin;
+  const float* WpE; const float* scE; const float* shE; int KCe; int NTe;
+  const float* Wd; const float* scD; const float* shD;
+  const float* WrP; const float* br; int NTR;
+  const float* We2P; const float* be;
+  const float* WpP; const float* scP; const float* shP; int NTp;
+  float* Y; int Cout; int residual;
+  float* dbg_dw; float* dbg_gate;
+  int B, Cexp, se;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbg_t;
+#endif
+};
 
 // Flattened variant of stream_mfma for MANY short accumulation runs (phase A, SE expand): run r = tiles
 // [tile_of(r), +NTW), each KC chunks long.  The weight ring keeps DEPTH chunks in flight ACROSS runs, so a
@@ -1960,6 +2318,7 @@ struct mkws_embed {
   bool fuse_se = false;            // SE squeeze -> reduce-FC partials inside the producing kernel (saves the se_reduce launch, but the
                                    // serial tails cost more than the launch on MI355X: 624k vs 643k clips/s; kept for A/B)
   int fuse_stem = 2;               // 2: stem + whole block 1a in one kernel (stem_block1a_kernel); 1: stem + block-1a depthwise (stem_dw_kernel); 0: separate
+  int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 3a and 4a (where it measured faster), 2 = 2a..4a, 0 = never
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
@@ -1996,6 +2355,32 @@ struct ProfScope {
   ProfScope(const std::string& stage, const std::string& kernel) { if (g_prof) g_prof->begin(stage, kernel); }
   ~ProfScope() { if (g_prof) g_prof->end(); }
 };
+
+// Kernels launched with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// (kernel, device): a process-wide flag would leave the second GPU of a multi-device process at the default.
+int ensure_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(MKWS_ERR_HIP, "hipGetDevice failed");
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({fn, dev})) return MKWS_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return fail(MKWS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed: %s", bytes, hipGetErrorString(e));
+  done.insert({fn, dev});
+  return MKWS_OK;
+}
+
+int device_cu_count() {
+  static thread_local int cached_dev = -1, cached_cus = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return cached_cus;
+  if (dev != cached_dev) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) { cached_cus = n; cached_dev = dev; }
+  }
+  return cached_cus;
+}
 
 // ---- host-side packing -------------------------------------------------------------------------------
 struct Packer {
@@ -2166,8 +2551,7 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
     int nblk = (ngroups + 7) / 8; if (nblk > 256 * per_cu) nblk = 256 * per_cu;
     ProfScope ps(stage, std::string("pw_proj_kernel<") + std::to_string(L.NTtot) + "," + std::to_string(MT) + ">");
 #define MKWS_PJ(NT_, MT_) do { \
-      static bool attr_done = false; \
-      if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_proj_kernel<NT_, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_done = true; } \
+      (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&pw_proj_kernel<NT_, MT_>), 96 * 1024); \
       hipLaunchKernelGGL((pw_proj_kernel<NT_, MT_>), dim3(nblk), dim3(512), lds, s, a); } while (0)
     if (MT == 2) {
       switch (L.NTtot) { case 1: MKWS_PJ(1, 2); break; case 2: MKWS_PJ(2, 2); break; case 3: MKWS_PJ(3, 2); break; case 4: MKWS_PJ(4, 2); break; default: MKWS_PJ(5, 2); break; }
@@ -2358,8 +2742,7 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," +
                           std::to_string(b.W) + "," + std::to_string(MT) + "," + std::to_string(kBlockWaves) + ">");
 #define MKWS_BLOCK(KS, S, H_, W_, MT_) do { \
-    static bool attr_done = false; \
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), 160 * 1024) != MKWS_OK) return; \
     hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, a); } while (0)
   if (b.H == 4 && b.W == 3) {
     if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 3);
@@ -2388,6 +2771,72 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
             ph[5] / grid.x / 100.0, (double)(t1 - t0) / 100.0);
   }
 #endif
+}
+
+// Whole-block kernel for the big-image blocks 2a..4a (mbconv_mid_kernel): one instance per layer geometry.
+bool mid_supported(const BlockPlan& b) {
+  if (!b.has_expand || b.se.se > 10) return false;
+  const int ks = b.spec.kernel, st = b.spec.stride, ci = b.spec.in_ch, co = b.spec.out_ch;
+  return (b.H == 25 && b.W == 20 && ks == 3 && st == 2 && ci == 16 && co == 24) || (b.H == 13 && b.W == 10 && ks == 3 && st == 1 && ci == 24 && co == 24) ||
+         (b.H == 13 && b.W == 10 && ks == 5 && st == 2 && ci == 24 && co == 40) || (b.H == 7 && b.W == 5 && ks == 5 && st == 1 && ci == 40 && co == 40) ||
+         (b.H == 7 && b.W == 5 && ks == 3 && st == 2 && ci == 40 && co == 80);
+}
+
+template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int NTP, int G, int SEG, int NTHR, int WPE>
+void launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
+  using GM = MidGeom<KS, S, KCT, HT, WT, CEXP, CC, G, SEG>;
+  constexpr size_t lds = (size_t)GM::lds_floats * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS carve exceeds one CU");
+  auto* fn = &mbconv_mid_kernel<KS, S, KCT, HT, WT, CEXP, CC, NTP, G, SEG, NTHR, WPE>;
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024) != MKWS_OK) return;
+  ProfScope ps(stage, std::string("mbconv_mid_kernel<") + std::to_string(KS) + "," + std::to_string(S) + "," + std::to_string(HT) + "," + std::to_string(WT) +
+                          "," + std::to_string(CEXP) + "," + std::to_string(CC) + "," + std::to_string(G) + "," + std::to_string(NTHR) + ">");
+  const dim3 grid((a.B + G - 1) / G);
+#ifdef MKWS_FRONT_TIMING
+  static unsigned long long* d_t = nullptr;
+  if (!d_t) (void)hipMalloc(&d_t, sizeof(unsigned long long) * 8 * 65536);
+  MidArgs at = a; at.dbg_t = d_t;
+  hipLaunchKernelGGL(fn, grid, dim3(NTHR), lds, s, at);
+  (void)hipStreamSynchronize(s);
+  std::vector<unsigned long long> h((size_t)grid.x * 8);
+  (void)hipMemcpy(h.data(), d_t, h.size() * 8, hipMemcpyDeviceToHost);
+  double p1 = 0, p2 = 0, se = 0, pj = 0, tot = 0; unsigned long long t0 = ~0ull, t1 = 0;
+  for (size_t i = 0; i < grid.x; ++i) {
+    p1 += (double)h[8 * i + 1]; p2 += (double)h[8 * i + 2]; se += (double)h[8 * i + 3]; pj += (double)h[8 * i + 4]; tot += (double)(h[8 * i + 5] - h[8 * i]);
+    if (h[8 * i] < t0) t0 = h[8 * i];
+    if (h[8 * i + 5] > t1) t1 = h[8 * i + 5];
+  }
+  fprintf(stderr, "[mid-timing] %s CC %d G %d: %u workgroups x %d thr, lds %zu: expand %.2f  depthwise %.2f  SE %.2f  project %.2f  total %.2f us per workgroup; span %.2f us\n",
+          stage, CC, G, grid.x, NTHR, lds, p1 / grid.x / 100.0, p2 / grid.x / 100.0, se / grid.x / 100.0, pj / grid.x / 100.0, tot / grid.x / 100.0, (double)(t1 - t0) / 100.0);
+#else
+  hipLaunchKernelGGL(fn, grid, dim3(NTHR), lds, s, a);
+#endif
+}
+
+// fuse_mid: 1 = the blocks where the whole-block kernel measured faster (3a, 4a); 2 = all five big-image blocks
+// (A/B and parity runs); 0 = the three-kernel path everywhere.
+bool mid_enabled(const BlockPlan& b, int fuse_mid) {
+  if (!fuse_mid || !mid_supported(b)) return false;
+  if (fuse_mid >= 2) return true;
+  return (b.H == 13 && b.spec.kernel == 5) || (b.H == 7 && b.spec.stride == 2);
+}
+
+void launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+  MidArgs a;
+  a.X = X; a.Cin = b.spec.in_ch;
+  a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.NTtotE = b.expand.NTtot;
+  a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift;
+  a.Wr = b.se.Wr; a.br = b.se.br; a.We = b.se.We; a.be = b.se.be; a.se = b.se.se;
+  a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift;
+  a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
+  a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate; a.B = B;
+  const int ks = b.spec.kernel, st = b.spec.stride;
+  //                              KS S KCT  H   W  CEXP CC NTP G SEG NTHR WPE
+  if (b.H == 25) launch_mid_inst<3, 2, 1, 25, 20, 96, 16, 2, 1, 1, 1024, 4>(s, stage, a);                  // 2a
+  else if (b.H == 13 && ks == 3) launch_mid_inst<3, 1, 2, 13, 10, 144, 48, 2, 1, 2, 1024, 4>(s, stage, a); // 2b
+  else if (b.H == 13) launch_mid_inst<5, 2, 2, 13, 10, 144, 48, 3, 1, 1, 512, 4>(s, stage, a);             // 3a
+  else if (st == 1) launch_mid_inst<5, 1, 3, 7, 5, 240, 48, 3, 1, 1, 512, 4>(s, stage, a);                 // 3b
+  else launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 1, 512, 4>(s, stage, a);                              // 4a
 }
 
 void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B, int se_chunks) {
@@ -2449,8 +2898,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
   if (fused_1a) {
     ProfScope ps("block1a", "stem_block1a_kernel");
     const size_t lds = ((size_t)((51 * 41 + 3) & ~3) + 27 * 22 * 32 + 500 * 36 + 64 * 4 + 32 + 16 + 32) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_block1a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&stem_block1a_kernel), 160 * 1024)) return rc;
     hipLaunchKernelGGL(stem_block1a_kernel, dim3(B), dim3(512), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
                        em->norm_std, blk1a.dw.Wd, blk1a.dw.scale, blk1a.dw.shift, blk1a.se.Wr, blk1a.se.br, blk1a.se.We, blk1a.se.be,
                        blk1a.se.se, blk1a.project.Wp, blk1a.project.scale, blk1a.project.shift, em->bufB);
@@ -2484,6 +2932,16 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     }
     const bool want_expand_tap = stop && (p + "_expand") == stop;
     int se_chunks = 0;            // > 0: SE reduce partials were already produced by the upstream kernel
+    if (mid_enabled(b, em->fuse_mid) && !want_expand_tap) {
+      // big-image blocks: one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
+      const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
+      launch_mid(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+      if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
+      if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
+      if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
+      float* t = cur; cur = nxt; nxt = t;
+      continue;
+    }
     if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
@@ -2595,6 +3053,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // multi-kernel path, which spreads the weights of a layer over the chip.  Per handle, so results stay
   // bit-identical across the batch sizes one handle sees.
   em->fuse_block = (max_batch >= 384) ? 2 : 0;
+  em->fuse_mid = (max_batch >= 384) ? 1 : 0;
   (void)hipGetDevice(&em->device);
   Packer pk;
   std::vector<float> sc, sh;
@@ -2722,6 +3181,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (!em || !name) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
   if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "gemm_lds") == 0) { em->gemm_lds = value; return MKWS_OK; }
   if (strcmp(name, "proj_stream") == 0) { em->proj_stream = value; return MKWS_OK; }

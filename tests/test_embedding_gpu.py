@@ -48,28 +48,31 @@ def test_every_stage_matches_oracle(ctx):
 
 
 def test_execution_options_agree(ctx):
-    """fuse_front / fuse_block are A/B switches: every combination must match the oracle."""
+    """fuse_front / fuse_block / fuse_mid are A/B switches: every combination must match the oracle."""
     spec = _spec(np.random.default_rng(12), 9)
     x = torch.from_numpy(spec).to(ctx["dev"])
     ref = ctx["oracle"].forward(spec).numpy()
     try:
-        for front, block in ((0, 0), (1, 0), (1, 2), (0, 2), (1, 1)):
+        for front, block, mid in ((0, 0, 0), (1, 0, 0), (1, 2, 1), (0, 2, 0), (1, 1, 2), (0, 0, 1)):
             ctx["em"].set_option("fuse_front", front)
             ctx["em"].set_option("fuse_block", block)
+            ctx["em"].set_option("fuse_mid", mid)
             ctx["em"].set_option("fuse_stem", front * (1 + block % 2))      # 0, 1 and 2 all get exercised
             ctx["em"].set_option("gemm_lds", block % 2)
             ctx["em"].set_option("fuse_se", 1 - block % 2)
             ctx["em"].set_option("proj_stream", front)
             ctx["em"].set_option("fuse_gap", front)
-            assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block)
-            for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block2b", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a", "top", "gap"):
+            assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block, mid)
+            for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block2a_dw", "block2a_gate", "block2a", "block2b_dw", "block2b", "block3a_gate",
+                         "block3a", "block3b_dw", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a", "top", "gap"):
                 taps = {}
                 ctx["oracle"].forward(spec[:3], taps)
                 got = ctx["em"].tap(x[:3], name).cpu().numpy().reshape(taps[name].shape)
-                assert _rel(got, taps[name]) < REL_TOL, (front, block, name)
+                assert _rel(got, taps[name]) < REL_TOL, (front, block, mid, name)
     finally:
         ctx["em"].set_option("fuse_front", 1)
         ctx["em"].set_option("fuse_block", 2)
+        ctx["em"].set_option("fuse_mid", 1)
         ctx["em"].set_option("fuse_stem", 2)
         ctx["em"].set_option("gemm_lds", 0)
         ctx["em"].set_option("fuse_se", 0)
