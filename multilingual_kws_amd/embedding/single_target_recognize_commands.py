@@ -52,9 +52,11 @@ class SingleTargetRecognizeCommands(object):
             recognize_element.is_new_command = False
             return
         # mean target confidence over the window, accumulated as the reference does (score / count, summed in order)
+        # (in float64 like the reference's np.zeros accumulator: float32 inferences must not make this a float32 sum
+        # under NumPy 2 promotion rules -- a score within 1e-7 of the threshold could flip a decision)
         score = 0.0
         for _, res in self._previous_results:
-            score += res[self._target_id] / how_many
+            score += float(res[self._target_id]) / how_many
         above = score > self._detection_threshold
         label = self._labels[self._target_id] if above else "_silence_"
         if self._previous_top_label == "_silence_" or self._previous_top_time == -np.inf:

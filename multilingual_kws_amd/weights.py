@@ -41,7 +41,7 @@ def _trunc_normal(rng, shape, std):
     return (x * std).astype(np.float32)
 
 
-def synthetic_blob(seed=DEFAULT_SEED, calibrate=True):
+def synthetic_blob(seed=DEFAULT_SEED, calibrate=True, tensors=None):
     """Seeded random weights following the initialisers the reference's model definition uses
     (EfficientNet conv: VarianceScaling(2, fan_out, truncated_normal); Dense: glorot_uniform,
     dense_2: lecun_normal) with non-trivial BatchNorm parameters so BN folding is exercised.
@@ -52,7 +52,8 @@ def synthetic_blob(seed=DEFAULT_SEED, calibrate=True):
     tools/calibrate_synthetic_bn.py, which holds the recipe); the product package itself contains no
     host-side forward pass of the network."""
     rng = np.random.default_rng(seed)
-    tensors = manifest()
+    if tensors is None:       # (a caller without the built library -- tools/make_keras_golden.py on a TF machine -- passes tools/embedding_manifest.json)
+        tensors = manifest()
     blob = np.zeros(tensors[-1]["offset"] + tensors[-1]["count"], dtype=np.float32)
     for t in tensors:
         name, shape = t["name"], tuple(t["shape"])

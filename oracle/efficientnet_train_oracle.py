@@ -38,10 +38,14 @@ class TrainableEmbeddingOracle:
         g, b = w[p + "/gamma"], w[p + "/beta"]
         if training:
             mean = x.mean(dim=(0, 2, 3))
-            var = x.var(dim=(0, 2, 3), unbiased=False)
+            var = x.var(dim=(0, 2, 3), unbiased=False)               # normalisation uses the biased batch variance
             with torch.no_grad():
+                # Keras BatchNormalization on 4-D inputs takes the fused path, whose moving-variance update uses the
+                # Bessel-corrected batch variance (N/(N-1), N = B*H*W) -- tf.compat.v1.nn.fused_batch_norm semantics
+                n = x.shape[0] * x.shape[2] * x.shape[3]
+                var_u = var * (n / max(n - 1, 1))
                 self.new_moving[p + "/moving_mean"] = BN_MOMENTUM * w[p + "/moving_mean"] + (1 - BN_MOMENTUM) * mean
-                self.new_moving[p + "/moving_variance"] = BN_MOMENTUM * w[p + "/moving_variance"] + (1 - BN_MOMENTUM) * var
+                self.new_moving[p + "/moving_variance"] = BN_MOMENTUM * w[p + "/moving_variance"] + (1 - BN_MOMENTUM) * var_u
         else:
             mean, var = w[p + "/moving_mean"], w[p + "/moving_variance"]
         inv = g / torch.sqrt(var + BN_EPS)

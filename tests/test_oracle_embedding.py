@@ -41,37 +41,65 @@ def _np_swish(x):
     return x / (1.0 + np.exp(-x))
 
 
-def test_block3a_against_explicit_loops():
-    """MBConv 3a (k5, stride 2, asymmetric correct_pad, SE, no skip) re-derived with explicit numpy loops."""
+def _np_mbconv(x, w, name, cin, cout, k, stride, expand):
+    """One MBConv block (Keras EfficientNet, inference) with explicit numpy loops for the depthwise conv; returns
+    (expand, dw, gate, out) as float64 NHWC arrays.  Independent of torch.nn.functional (the oracle's engine)."""
+    p = "block" + name
+    e = x
+    if expand != 1:
+        e = _np_swish(_np_bn(x @ w[p + "_expand_conv/kernel"][0, 0], w, p + "_expand_bn"))
+    H, W = e.shape[1], e.shape[2]
+    c = k // 2
+    if stride == 2:          # ZeroPadding2D(correct_pad) + "valid"
+        (pt, pb), (pl, pr) = (c - (1 - H % 2), c), (c - (1 - W % 2), c)
+    else:                    # "same"
+        (pt, pb), (pl, pr) = (c, c), (c, c)
+    ep = np.pad(e, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    kd = w[p + "_dwconv/depthwise_kernel"][..., 0]           # [k,k,C]
+    Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
+    d = np.zeros((x.shape[0], Ho, Wo, e.shape[-1]))
+    for oh in range(Ho):
+        for ow in range(Wo):
+            for i in range(k):
+                for j in range(k):
+                    d[:, oh, ow] += ep[:, oh * stride + i, ow * stride + j] * kd[i, j]
+    d = _np_swish(_np_bn(d, w, p + "_bn"))
+    s = d.mean(axis=(1, 2))
+    r = _np_swish(s @ w[p + "_se_reduce/kernel"][0, 0] + w[p + "_se_reduce/bias"])
+    g = 1.0 / (1.0 + np.exp(-(r @ w[p + "_se_expand/kernel"][0, 0] + w[p + "_se_expand/bias"])))
+    out = _np_bn((d * g[:, None, None, :]) @ w[p + "_project_conv/kernel"][0, 0], w, p + "_project_bn")
+    if stride == 1 and cin == cout:
+        out = out + x
+    return e, d, g, out
+
+
+def test_every_block_against_explicit_loops():
+    """All 16 MBConv blocks (3x3 / 5x5, stride 1 / 2 with every correct_pad case, expand 1 / 6, SE, residual) chained
+    through an explicit-loop float64 re-derivation: each block's expand / depthwise / gate / output taps of the oracle
+    are reproduced to 1e-9, so the oracle does not rest on F.conv2d's conventions alone."""
+    from multilingual_kws_amd.arch import BLOCKS
     blob = weights.synthetic_blob()
     w = {k: v.astype(np.float64) for k, v in eo.split_blob(blob).items()}
     rng = np.random.default_rng(5)
     spec = (rng.integers(0, 670, size=(2, 49, 40)).astype(np.float32) * np.float32(10 / 256))
     taps = {}
     eo.EmbeddingOracle(blob, torch.float64).forward(spec, taps)
-    x = taps["block2b"].astype(np.float64)                 # [2,13,10,24] NHWC, input of 3a
-    p = "block3a"
-    e = _np_swish(_np_bn(x @ w[p + "_expand_conv/kernel"][0, 0], w, p + "_expand_bn"))
-    assert np.allclose(e, taps[p + "_expand"], rtol=1e-9, atol=1e-11)
-    (pt, pb), (pl, pr) = (2, 2), (1, 2)
-    ep = np.pad(e, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
-    k = w[p + "_dwconv/depthwise_kernel"][..., 0]           # [5,5,C]
-    Ho, Wo = (13 + 4 - 5) // 2 + 1, (10 + 3 - 5) // 2 + 1
-    assert (Ho, Wo) == (7, 5)
-    d = np.zeros((2, Ho, Wo, e.shape[-1]))
-    for oh in range(Ho):
-        for ow in range(Wo):
-            for i in range(5):
-                for j in range(5):
-                    d[:, oh, ow] += ep[:, oh * 2 + i, ow * 2 + j] * k[i, j]
-    d = _np_swish(_np_bn(d, w, p + "_bn"))
-    assert np.allclose(d, taps[p + "_dw"], rtol=1e-9, atol=1e-11)
-    s = d.mean(axis=(1, 2))
-    r = _np_swish(s @ w[p + "_se_reduce/kernel"][0, 0] + w[p + "_se_reduce/bias"])
-    g = 1.0 / (1.0 + np.exp(-(r @ w[p + "_se_expand/kernel"][0, 0] + w[p + "_se_expand/bias"])))
-    assert np.allclose(g, taps[p + "_gate"], rtol=1e-9, atol=1e-11)
-    out = _np_bn((d * g[:, None, None, :]) @ w[p + "_project_conv/kernel"][0, 0], w, p + "_project_bn")
-    assert np.allclose(out, taps[p], rtol=1e-9, atol=1e-11)
+    x = taps["stem"].astype(np.float64)
+    shapes = []
+    for name, cin, cout, k, stride, expand in BLOCKS:
+        p = "block" + name
+        e, d, g, out = _np_mbconv(x, w, name, cin, cout, k, stride, expand)
+        if expand != 1:
+            assert np.allclose(e, taps[p + "_expand"], rtol=1e-9, atol=1e-11), p
+        assert np.allclose(d, taps[p + "_dw"], rtol=1e-9, atol=1e-11), p
+        assert np.allclose(g, taps[p + "_gate"], rtol=1e-9, atol=1e-11), p
+        assert np.allclose(out, taps[p], rtol=1e-9, atol=1e-11), p
+        shapes.append(out.shape[1:])
+        x = out                                            # chain the re-derivation, not the oracle's output
+    assert shapes[0] == (25, 20, 16) and shapes[2] == (13, 10, 24) and shapes[4] == (7, 5, 40) and shapes[7] == (4, 3, 80)
+    assert shapes[10] == (4, 3, 112) and shapes[14] == (2, 2, 192) and shapes[15] == (2, 2, 320)
+    top = _np_swish(_np_bn(x @ w["top_conv/kernel"][0, 0], w, "top_bn"))
+    assert np.allclose(top, taps["top"], rtol=1e-9, atol=1e-11)
 
 
 def test_stem_and_head_against_explicit_math():

@@ -33,7 +33,8 @@ def test_training_mode_uses_batch_statistics_and_updates_moving_averages():
     y = torch.nn.functional.conv2d(x, o.w["stem_conv/kernel"].detach().permute(3, 2, 0, 1), stride=2)
     mean = y.mean(dim=(0, 2, 3)); var = y.var(dim=(0, 2, 3), unbiased=False)
     assert torch.allclose(o.new_moving["stem_bn/moving_mean"], BN_MOMENTUM * o.w["stem_bn/moving_mean"] + (1 - BN_MOMENTUM) * mean)
-    assert torch.allclose(o.new_moving["stem_bn/moving_variance"], BN_MOMENTUM * o.w["stem_bn/moving_variance"] + (1 - BN_MOMENTUM) * var)
+    n = y.shape[0] * y.shape[2] * y.shape[3]          # Keras' fused BN feeds the Bessel-corrected variance to the moving average
+    assert torch.allclose(o.new_moving["stem_bn/moving_variance"], BN_MOMENTUM * o.w["stem_bn/moving_variance"] + (1 - BN_MOMENTUM) * var * n / (n - 1))
     assert len(o.new_moving) == 2 * 49                                      # every BatchNormalization layer (49 of them)
 
 

@@ -40,6 +40,18 @@ def test_detector_release_and_refire_respect_suppression():
         SingleTargetRecognizeCommands(["a", "b", "c"], 100, 0.5, 500, 4, 2).process_latest_result(np.zeros(2), 0, RecognizeResult())
 
 
+def test_detector_accumulates_in_float64_for_float32_inferences():
+    """float32 softmax rows (what model.predict returns) must be averaged in float64 like the reference's np.zeros sum."""
+    rc = SingleTargetRecognizeCommands(labels=["_silence_", "_unknown_", "k"], average_window_duration_ms=100, detection_threshold=0.5,
+                                       suppression_ms=0, minimum_count=1, target_id=2)
+    el = RecognizeResult()
+    vals = np.asarray([0.1, 0.7000001, 0.7], dtype=np.float32)
+    for i, v in enumerate(vals):
+        rc.process_latest_result(np.asarray([0, 0, v], dtype=np.float32), 40 * i, el)
+    assert isinstance(el.score, float) and not isinstance(el.score, np.floating)
+    assert el.score == sum(float(v) / 3 for v in vals)
+
+
 def test_detector_average_is_over_the_window():
     # one spike cannot fire: mean over >= 4 windows stays below threshold
     assert [e for e in _run([0.0] * 10 + [1.0] + [0.0] * 10) if e[1] == "kw"] == []
