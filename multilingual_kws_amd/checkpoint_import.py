@@ -1,0 +1,416 @@
+"""TensorFlow-free importer for the checkpoint every reference caller loads: the Keras SavedModel directory
+`multilingual_context_73_0.8011` (docker/Dockerfile:69-70; transfer_learning.py:36 `tf.keras.models.load_model`).
+
+A SavedModel keeps its variables in a TensorFlow *tensor bundle*, `variables/variables.index` +
+`variables/variables.data-0000N-of-0000M` (tensorflow/core/util/tensor_bundle/tensor_bundle.{h,cc}):
+
+  * `.index` is an SSTable in TensorFlow's port of the LevelDB table format (tensorflow/core/lib/io/table*.cc,
+    format.cc): data blocks of prefix-compressed (shared, non_shared, value_len, key delta, value) entries with a
+    restart array, each block followed by a 5-byte trailer (compression type: 0 none / 1 snappy; masked CRC32C), an
+    index block mapping last-keys to block handles, and a 48-byte footer (metaindex handle, index handle, magic
+    0xdb4775248b80fb57).
+  * key "" holds a BundleHeaderProto (num_shards, endianness, version); every other key is a checkpoint key whose
+    value is a BundleEntryProto (dtype, shape, shard_id, offset, size, crc32c) pointing into a data shard
+    (tensorflow/core/protobuf/tensor_bundle.proto).
+  * TF2 (object-based) checkpoints name variables by their path in the object graph, e.g.
+    `layer_with_weights-3/kernel/.ATTRIBUTES/VARIABLE_VALUE`; key `_CHECKPOINTABLE_OBJECT_GRAPH` holds a serialized
+    TrackableObjectGraph (tensorflow/core/protobuf/trackable_object_graph.proto) whose SerializedTensor entries
+    carry both the checkpoint key and the variable's `full_name` ("stem_conv/kernel", "block2a_expand_bn/gamma", ...).
+
+`load_savedmodel(dir)` returns {Keras variable name: ndarray}; `import_savedmodel(dir)` the weight blob of
+multilingual_kws_amd.weights (names = mkws_embed_weight_manifest).  Variables are matched by `full_name` (nested
+model prefixes and ":0" dropped); when an object graph has no usable full names, positionally: weighted layers in
+object-graph order against the manifest's layer order (identical to Keras' layer order for this architecture).
+
+HONEST STATUS: the released checkpoint is a GitHub release asset and cannot be fetched in this environment, and
+TensorFlow cannot be installed, so this reader is verified against bundles written by the independent minimal
+writer in tests/util_bundle.py (both block encodings, snappy literals/copies by known-answer vectors, CRC32C
+known answers) -- NOT yet against `multilingual_context_73_0.8011` itself.
+"""
+import os
+import struct
+
+import numpy as np
+
+TABLE_MAGIC = 0xDB4775248B80FB57
+OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
+ATTR_SUFFIX = "/.ATTRIBUTES/VARIABLE_VALUE"
+# tensorflow/core/framework/types.proto
+DTYPES = {1: np.dtype("<f4"), 2: np.dtype("<f8"), 3: np.dtype("<i4"), 4: np.dtype("u1"), 5: np.dtype("<i2"), 6: np.dtype("i1"),
+          9: np.dtype("<i8"), 10: np.dtype("?"), 17: np.dtype("<u2"), 19: np.dtype("<f2"), 22: np.dtype("<u4"), 23: np.dtype("<u8")}
+DT_STRING = 7
+
+
+class CheckpointFormatError(ValueError):
+    pass
+
+
+# ---- CRC32C (Castagnoli), TF's mask ---------------------------------------------------------------------------------
+def _crc_table():
+    t = []
+    for n in range(256):
+        c = n
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        t.append(c)
+    return t
+
+
+_CRC = _crc_table()
+
+
+def crc32c(data, crc=0):
+    c = crc ^ 0xFFFFFFFF
+    for b in bytes(data):
+        c = _CRC[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def mask_crc(c):
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ---- varints / protobuf wire format ---------------------------------------------------------------------------------
+def read_varint(buf, pos):
+    out = shift = 0
+    while True:
+        if pos >= len(buf):
+            raise CheckpointFormatError("truncated varint")
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+        if shift > 63:
+            raise CheckpointFormatError("varint too long")
+
+
+def parse_proto(buf):
+    """Wire-level parse: [(field number, wire type, value)]; value = int (varint / fixed) or bytes (length-delimited)."""
+    out, pos = [], 0
+    buf = bytes(buf)
+    while pos < len(buf):
+        tag, pos = read_varint(buf, pos)
+        field, wt = tag >> 3, tag & 7
+        if wt == 0:
+            v, pos = read_varint(buf, pos)
+        elif wt == 1:
+            v = struct.unpack_from("<Q", buf, pos)[0]
+            pos += 8
+        elif wt == 2:
+            n, pos = read_varint(buf, pos)
+            if pos + n > len(buf):
+                raise CheckpointFormatError("truncated length-delimited field")
+            v = buf[pos:pos + n]
+            pos += n
+        elif wt == 5:
+            v = struct.unpack_from("<I", buf, pos)[0]
+            pos += 4
+        else:
+            raise CheckpointFormatError(f"unsupported protobuf wire type {wt}")
+        out.append((field, wt, v))
+    return out
+
+
+def _signed64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+# ---- snappy (raw format: varint length, then literal / copy elements) ------------------------------------------------
+def snappy_decompress(buf):
+    buf = bytes(buf)
+    n, pos = read_varint(buf, 0)
+    out = bytearray()
+    while pos < len(buf):
+        tag = buf[pos]
+        pos += 1
+        kind = tag & 3
+        if kind == 0:                                   # literal
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(buf[pos:pos + nb], "little")
+                pos += nb
+            ln += 1
+            out += buf[pos:pos + ln]
+            pos += ln
+            continue
+        if kind == 1:                                   # copy, 1-byte offset
+            ln = ((tag >> 2) & 7) + 4
+            off = ((tag >> 5) << 8) | buf[pos]
+            pos += 1
+        elif kind == 2:                                 # copy, 2-byte offset
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(buf[pos:pos + 2], "little")
+            pos += 2
+        else:                                           # copy, 4-byte offset
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(buf[pos:pos + 4], "little")
+            pos += 4
+        if off == 0 or off > len(out):
+            raise CheckpointFormatError("snappy copy reaches before the start of the output")
+        for _ in range(ln):                             # byte-wise: copies may overlap their own output
+            out.append(out[-off])
+    if len(out) != n:
+        raise CheckpointFormatError(f"snappy stream decodes to {len(out)} bytes, header says {n}")
+    return bytes(out)
+
+
+# ---- SSTable ---------------------------------------------------------------------------------------------------------
+def _read_block(data, offset, size, verify=True):
+    raw = data[offset:offset + size]
+    if len(raw) != size or offset + size + 5 > len(data):
+        raise CheckpointFormatError("block handle points outside the file")
+    ctype = data[offset + size]
+    if verify:
+        stored = struct.unpack_from("<I", data, offset + size + 1)[0]
+        if mask_crc(crc32c(data[offset:offset + size + 1])) != stored:
+            raise CheckpointFormatError("block checksum mismatch")
+    if ctype == 0:
+        return raw
+    if ctype == 1:
+        return snappy_decompress(raw)
+    raise CheckpointFormatError(f"unknown block compression type {ctype}")
+
+
+def _block_entries(block):
+    if len(block) < 4:
+        raise CheckpointFormatError("block too small")
+    nrestarts = struct.unpack_from("<I", block, len(block) - 4)[0]
+    end = len(block) - 4 - 4 * nrestarts
+    if end < 0:
+        raise CheckpointFormatError("bad restart array")
+    pos, key = 0, b""
+    while pos < end:
+        shared, pos = read_varint(block, pos)
+        non_shared, pos = read_varint(block, pos)
+        vlen, pos = read_varint(block, pos)
+        if shared > len(key) or pos + non_shared + vlen > end:
+            raise CheckpointFormatError("corrupt block entry")
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        yield key, block[pos:pos + vlen]
+        pos += vlen
+
+
+def read_table(path, verify=True):
+    """{key bytes: value bytes} of a TensorFlow / LevelDB-format SSTable file."""
+    data = open(path, "rb").read()
+    if len(data) < 48 or struct.unpack_from("<Q", data, len(data) - 8)[0] != TABLE_MAGIC:
+        raise CheckpointFormatError(f"{path}: not a TensorFlow table file (bad magic)")
+    footer = data[-48:]
+    _, pos = read_varint(footer, 0)          # metaindex handle (unused)
+    _, pos = read_varint(footer, pos)
+    ioff, pos = read_varint(footer, pos)
+    isize, pos = read_varint(footer, pos)
+    out = {}
+    for _, handle in _block_entries(_read_block(data, ioff, isize, verify)):
+        boff, p = read_varint(handle, 0)
+        bsize, _ = read_varint(handle, p)
+        for k, v in _block_entries(_read_block(data, boff, bsize, verify)):
+            out[bytes(k)] = bytes(v)
+    return out
+
+
+# ---- tensor bundle ---------------------------------------------------------------------------------------------------
+class BundleReader:
+    """Reads `<prefix>.index` + `<prefix>.data-XXXXX-of-YYYYY`."""
+
+    def __init__(self, prefix, verify=True):
+        self.prefix = prefix
+        table = read_table(prefix + ".index", verify)
+        if b"" not in table:
+            raise CheckpointFormatError("bundle has no header entry")
+        hdr = {f: v for f, _, v in parse_proto(table[b""])}
+        self.num_shards = hdr.get(1, 1)
+        if hdr.get(2, 0) != 0:
+            raise CheckpointFormatError("big-endian bundles are not supported")
+        self.entries = {}
+        for k, v in table.items():
+            if k == b"":
+                continue
+            e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "sliced": False}
+            for f, _, val in parse_proto(v):
+                if f == 1:
+                    e["dtype"] = val
+                elif f == 2:
+                    for f2, _, dim in parse_proto(val):
+                        if f2 == 2:
+                            e["shape"].append(_signed64(dict((a, c) for a, _, c in parse_proto(dim)).get(1, 0)))
+                elif f == 3:
+                    e["shard_id"] = val
+                elif f == 4:
+                    e["offset"] = val
+                elif f == 5:
+                    e["size"] = val
+                elif f == 6:
+                    e["crc32c"] = val
+                elif f == 7:
+                    e["sliced"] = True
+            self.entries[k.decode("utf-8")] = e
+        self._shards = {}
+
+    def keys(self):
+        return sorted(self.entries)
+
+    def _shard(self, i):
+        if i not in self._shards:
+            path = f"{self.prefix}.data-{i:05d}-of-{self.num_shards:05d}"
+            self._shards[i] = np.memmap(path, dtype=np.uint8, mode="r")
+        return self._shards[i]
+
+    def raw(self, key):
+        e = self.entries[key]
+        if e["sliced"]:
+            raise CheckpointFormatError(f"{key}: partitioned (sliced) variables are not supported")
+        buf = self._shard(e["shard_id"])[e["offset"]:e["offset"] + e["size"]]
+        if buf.shape[0] != e["size"]:
+            raise CheckpointFormatError(f"{key}: data shard is truncated")
+        return buf
+
+    def tensor(self, key, verify_crc=False):
+        e = self.entries[key]
+        buf = self.raw(key)
+        if e["dtype"] == DT_STRING:
+            b = bytes(buf)
+            n = int(np.prod(e["shape"])) if e["shape"] else 1
+            lens, pos = [], 0
+            for _ in range(n):
+                ln, pos = read_varint(b, pos)
+                lens.append(ln)
+            pos += 4                                       # masked crc32c of the lengths
+            out = []
+            for ln in lens:
+                out.append(b[pos:pos + ln])
+                pos += ln
+            return out[0] if not e["shape"] else out
+        if e["dtype"] not in DTYPES:
+            raise CheckpointFormatError(f"{key}: unsupported dtype enum {e['dtype']}")
+        if verify_crc and e["crc32c"] is not None and mask_crc(crc32c(bytes(buf))) != e["crc32c"]:
+            raise CheckpointFormatError(f"{key}: tensor checksum mismatch")
+        dt = DTYPES[e["dtype"]]
+        arr = np.frombuffer(bytes(buf), dtype=dt)
+        if arr.size != int(np.prod(e["shape"])) if e["shape"] else arr.size != 1:
+            raise CheckpointFormatError(f"{key}: {arr.size} elements do not fill shape {e['shape']}")
+        return arr.reshape(e["shape"])
+
+    def object_graph(self):
+        """[(node children [(child id, local name)], attributes [(name, full_name, checkpoint_key)])] or None."""
+        if OBJECT_GRAPH_KEY not in self.entries:
+            return None
+        nodes = []
+        for f, _, nb in parse_proto(self.tensor(OBJECT_GRAPH_KEY)):
+            if f != 1:
+                continue
+            children, attrs = [], []
+            for f2, _, v in parse_proto(nb):
+                if f2 == 1:
+                    d = dict((a, c) for a, _, c in parse_proto(v))
+                    children.append((d.get(1, 0), d.get(2, b"").decode("utf-8")))
+                elif f2 == 2:
+                    d = dict((a, c) for a, _, c in parse_proto(v))
+                    attrs.append((d.get(1, b"").decode("utf-8"), d.get(2, b"").decode("utf-8"), d.get(3, b"").decode("utf-8")))
+            nodes.append((children, attrs))
+        return nodes
+
+
+# ---- Keras naming ----------------------------------------------------------------------------------------------------
+def _short(full_name):
+    parts = full_name.split(":")[0].split("/")
+    return "/".join(parts[-2:])
+
+
+def _layer_order_variables(nodes):
+    """Variables in Keras layer order: DFS over `layer_with_weights-K` children (K ascending), each layer's own
+    variables (object-graph children that own a VARIABLE_VALUE attribute) in the order the layer lists them."""
+    order, seen = [], set()
+
+    def visit(i):
+        if i in seen:
+            return
+        seen.add(i)
+        children, _ = nodes[i]
+        layers = sorted(((int(n.rsplit("-", 1)[1]), c) for c, n in children if n.startswith("layer_with_weights-")), key=lambda t: t[0])
+        if layers:
+            for _, c in layers:
+                visit(c)
+            return
+        for c, n in children:                                  # a leaf layer: its variables
+            for aname, full, key in nodes[c][1]:
+                if aname == "VARIABLE_VALUE":
+                    order.append((n, full, key))
+    visit(0)
+    return order
+
+
+def load_savedmodel(path, verify=True):
+    """{Keras variable name ("stem_conv/kernel", ...): float32 ndarray} from a SavedModel directory, a
+    `variables/` directory or a bundle prefix.  Optimizer slots and the classifier layer beyond dense_2 are returned
+    too when present (callers pick what they need)."""
+    prefix = path
+    for cand in (os.path.join(path, "variables", "variables"), os.path.join(path, "variables"), path):
+        if os.path.exists(cand + ".index"):
+            prefix = cand
+            break
+    else:
+        raise FileNotFoundError(f"no variables.index under {path}")
+    rd = BundleReader(prefix, verify)
+    nodes = rd.object_graph()
+    named, positional = {}, []
+    if nodes is not None:
+        for _, attrs in nodes:
+            for aname, full, key in attrs:
+                if aname == "VARIABLE_VALUE" and full and key in rd.entries and "/.OPTIMIZER_SLOT/" not in key:
+                    named.setdefault(_short(full), key)
+        positional = [(n, key) for n, _, key in _layer_order_variables(nodes) if key in rd.entries]
+    else:                                                       # TF1-style name-based checkpoint: keys are variable names
+        for k in rd.keys():
+            named.setdefault(_short(k), k)
+    return {"reader": rd, "named": named, "positional": positional}
+
+
+def import_savedmodel(path, verify=True):
+    """SavedModel directory -> weight blob of multilingual_kws_amd.weights (validated against the manifest)."""
+    from . import weights
+    info = load_savedmodel(path, verify)
+    rd, named = info["reader"], info["named"]
+    tensors = weights.manifest()
+    have_all = all(t["name"] in named for t in tensors)
+    out = {}
+    if have_all:
+        for t in tensors:
+            out[t["name"]] = rd.tensor(named[t["name"]])
+    else:
+        # positional fallback: group the manifest by layer, walk the checkpoint's weighted layers in order
+        layers, cur = [], None
+        for t in tensors:
+            lname = t["name"].split("/")[0]
+            if lname != cur:
+                layers.append([])
+                cur = lname
+            layers[-1].append(t)
+        seq = info["positional"]
+        groups, last = [], None
+        for local, key in seq:
+            base = key[:-len(ATTR_SUFFIX)] if key.endswith(ATTR_SUFFIX) else key
+            owner = base.rsplit("/", 1)[0]
+            if owner != last:
+                groups.append({})
+                last = owner
+            groups[-1][local] = key
+        if len(groups) < len(layers):
+            raise CheckpointFormatError(f"checkpoint has {len(groups)} weighted layers, the embedding needs {len(layers)} "
+                                        f"(and no usable variable names were found: missing e.g. {[t['name'] for t in tensors if t['name'] not in named][:3]})")
+        for lay, grp in zip(layers, groups):
+            for t in lay:
+                leaf = t["name"].split("/")[1]
+                if leaf not in grp:
+                    raise CheckpointFormatError(f"layer {t['name'].split('/')[0]}: checkpoint layer has {sorted(grp)}, no '{leaf}'")
+                out[t["name"]] = rd.tensor(grp[leaf])
+    for t in tensors:
+        v = np.asarray(out[t["name"]], dtype=np.float32)
+        if t["name"].startswith("normalization/") and v.size == 1:
+            v = v.reshape(t["shape"])
+        out[t["name"]] = v
+    return weights.from_named_tensors(out)

@@ -24,13 +24,18 @@ CATEGORIES = 3   # silence + unknown + target keyword
 
 
 def load_base_model(base_model_path, max_batch=1024):
-    """The frozen embedding model.  base_model_path: a weight-container directory written by
+    """The frozen embedding model.  base_model_path: what the reference passes to tf.keras.models.load_model
+    (transfer_learning.py:36) -- a Keras SavedModel directory such as multilingual_context_73_0.8011, read without
+    TensorFlow by multilingual_kws_amd.checkpoint_import -- or a weight-container directory written by
     multilingual_kws_amd.weights.save() (flat float32 blob + manifest with Keras variable names), or
     "synthetic[:SEED]" for the seeded random weights used by benchmarks."""
     p = str(base_model_path)
     if p.startswith("synthetic"):
         seed = int(p.split(":")[1]) if ":" in p else weights.DEFAULT_SEED
         blob = weights.synthetic_blob(seed)
+    elif os.path.exists(os.path.join(p, "variables", "variables.index")):
+        from .. import checkpoint_import
+        blob = checkpoint_import.import_savedmodel(p)
     else:
         blob = weights.load(p)
     return EmbeddingModel(blob, max_batch=max_batch), blob

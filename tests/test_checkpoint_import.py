@@ -1,0 +1,134 @@
+"""TensorFlow-free SavedModel variable-bundle importer (multilingual_kws_amd/checkpoint_import.py) against bundles
+written by the independent minimal writer of tests/util_bundle.py, plus known-answer vectors for CRC32C and snappy.
+NOT verified against the released multilingual_context_73_0.8011 (not fetchable here) -- see the module docstring."""
+import os
+
+import numpy as np
+import pytest
+
+from multilingual_kws_amd import checkpoint_import as ci, weights
+from tests import util_bundle as ub
+
+
+def test_crc32c_and_mask_known_answers():
+    assert ci.crc32c(b"123456789") == 0xE3069283                       # the CRC-32C check value
+    assert ci.crc32c(bytes(32)) == 0x8A9136AA                          # RFC 3720 B.4: 32 zero bytes
+    assert ci.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43                 # RFC 3720 B.4: 32 bytes of 0xff
+    assert ci.crc32c(b"6789", ci.crc32c(b"12345")) == 0xE3069283       # incremental use
+    c = ci.crc32c(b"foo")
+    assert ci.mask_crc(c) != c and ci.mask_crc(c) == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_snappy_known_answer_vectors():
+    # literal "abcd", then an overlapping 1-byte-offset copy (offset 4, length 8), then a 2-byte-offset copy (offset 12, length 5)
+    stream = bytes([17]) + bytes([3 << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1 | (0 << 5), 4]) + bytes([((5 - 1) << 2) | 2, 12, 0])
+    assert ci.snappy_decompress(stream) == b"abcdabcdabcd" + b"abcda"
+    # run-length style: literal "x" + copy offset 1 length 10 (overlaps its own output)
+    assert ci.snappy_decompress(bytes([11, 0, ord("x"), ((10 - 4) << 2) | 1, 1])) == b"x" * 11
+    # long literal with a 2-byte length, as the writer emits
+    raw = bytes(range(256)) * 5
+    assert ci.snappy_decompress(ub.snappy_literals(raw)) == raw
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.snappy_decompress(bytes([4, 0, ord("x"), (0 << 2) | 1, 9]))      # copy from before the start
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.snappy_decompress(bytes([9, 0, ord("x")]))                        # shorter than its header says
+
+
+@pytest.mark.parametrize("compress", [False, True])
+@pytest.mark.parametrize("block_entries,restart", [(1, 1), (7, 4), (1000, 16)])
+def test_table_round_trip(tmp_path, compress, block_entries, restart):
+    rng = np.random.default_rng(0)
+    items = {b"": b"hdr"}
+    for i in range(83):
+        items[f"layer_with_weights-{i // 3}/var{i % 3}/.ATTRIBUTES/VARIABLE_VALUE".encode()] = rng.bytes(int(rng.integers(0, 40)))
+    path = str(tmp_path / "t.index")
+    ub.write_table(path, items, block_entries=block_entries, restart_interval=restart, compress=compress)
+    assert ci.read_table(path) == items
+    raw = bytearray(open(path, "rb").read())
+    raw[10] ^= 0x40                                                  # corrupt a data block
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.read_table(path)
+    open(path, "wb").write(bytes(raw[:-3]))
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.read_table(path)
+
+
+def _keras_layers():
+    """[(layer name, [leaf names])] of the embedding model in Keras layer order, from the manifest, + what else the released
+    checkpoint holds: Normalization's count and the 761-way classifier the reference cuts off (transfer_learning.py:36-43)."""
+    layers = []
+    for t in weights.manifest():
+        lname, leaf = t["name"].split("/")
+        if not layers or layers[-1][0] != lname:
+            layers.append((lname, []))
+        layers[-1][1].append(leaf)
+    layers[0][1].append("count")
+    layers.append(("dense_3", ["kernel", "bias"]))
+    return layers
+
+
+def _write_model(tmp_path, blob, with_full_names, name_prefix="", **table_kw):
+    layers = _keras_layers()
+    graph, keys = ub.keras_object_graph(layers, with_full_names, name_prefix)
+    tensors = {}
+    for t in weights.manifest():
+        tensors[keys[t["name"]]] = blob[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"])
+    tensors[keys["normalization/count"]] = np.asarray(0, dtype=np.int64)
+    tensors[keys["dense_3/kernel"]] = np.zeros((1024, 761), np.float32)
+    tensors[keys["dense_3/bias"]] = np.zeros(761, np.float32)
+    tensors["optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE"] = np.asarray(12345, dtype=np.int64)
+    d = tmp_path / "saved_model" / "variables"
+    os.makedirs(d)
+    ub.write_bundle(str(d / "variables"), tensors, graph, **table_kw)
+    return str(tmp_path / "saved_model")
+
+
+def test_import_savedmodel_by_variable_name(tmp_path):
+    blob = weights.synthetic_blob(seed=3, calibrate=False)
+    path = _write_model(tmp_path, blob, with_full_names=True, name_prefix="efficientnetb0/", compress=True, block_entries=16)
+    got = ci.import_savedmodel(path)
+    assert got.dtype == np.float32 and np.array_equal(got, blob)
+    info = ci.load_savedmodel(path)
+    assert "dense_3/kernel" in info["named"] and info["reader"].tensor(info["named"]["dense_3/kernel"]).shape == (1024, 761)
+    rd = info["reader"]
+    assert rd.tensor("optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE") == 12345
+    small = info["named"]["stem_bn/gamma"]
+    assert np.array_equal(rd.tensor(small, verify_crc=True), blob[[t for t in weights.manifest() if t["name"] == "stem_bn/gamma"][0]["offset"]:][:32])
+
+
+def test_import_savedmodel_positionally_when_names_are_missing(tmp_path):
+    blob = weights.synthetic_blob(seed=4, calibrate=False)
+    path = _write_model(tmp_path, blob, with_full_names=False)
+    assert np.array_equal(ci.import_savedmodel(path), blob)
+
+
+def test_import_errors(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        ci.import_savedmodel(str(tmp_path))
+    # a checkpoint of some other model: too few weighted layers, no matching names
+    graph, keys = ub.keras_object_graph([("conv", ["kernel", "bias"])], with_full_names=True)
+    os.makedirs(tmp_path / "m" / "variables")
+    ub.write_bundle(str(tmp_path / "m" / "variables" / "variables"), {keys["conv/kernel"]: np.zeros((3, 3), np.float32),
+                                                                      keys["conv/bias"]: np.zeros(3, np.float32)}, graph)
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.import_savedmodel(str(tmp_path / "m"))
+    (tmp_path / "bad").mkdir()
+    (tmp_path / "bad" / "variables.index").write_bytes(b"\0" * 64)
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.import_savedmodel(str(tmp_path / "bad" / "variables"))
+
+
+def test_load_base_model_dispatches_on_a_savedmodel_directory(tmp_path, monkeypatch):
+    """transfer_learning.load_base_model(path) takes what the reference's tf.keras.models.load_model takes."""
+    from multilingual_kws_amd.embedding import transfer_learning as tl
+    blob = weights.synthetic_blob(seed=5, calibrate=False)
+    path = _write_model(tmp_path, blob, with_full_names=True)
+    seen = {}
+
+    class FakeEmbedding:
+        def __init__(self, b, max_batch=0):
+            seen["blob"] = b
+    monkeypatch.setattr(tl, "EmbeddingModel", FakeEmbedding)
+    _, got = tl.load_base_model(path, max_batch=4)
+    assert np.array_equal(got, blob) and seen["blob"] is got
