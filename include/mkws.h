@@ -212,6 +212,9 @@ int mkws_heads_forward(mkws_head* const* heads, int n_heads, const float* d_emb,
  * written behind the gradient (mkws_head_grads()[P], [P+1]). */
 int mkws_head_loss_grad(mkws_head* hd, const float* d_emb, const int32_t* d_labels, int B,
                         float* d_stats, void* stream);
+/* After mkws_head_loss_grad on the same B rows: d(mean loss)/d(embedding rows) -> d_dx [B, in]  (what
+ * backprop_into_embedding=True propagates into the embedding network, transfer_learning.py:94-112). */
+int mkws_head_input_grad(mkws_head* hd, float* d_dx, int B, void* stream);
 /* Keras Adam update from the grad buffer (grad is multiplied by grad_scale first, e.g. 1/world_size
  * after a sum all-reduce): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps). */
 int mkws_head_adam_step(mkws_head* hd, float lr, float beta1, float beta2, float eps, int step_t,
@@ -244,6 +247,58 @@ int mkws_augment_batch(const float* d_bank0, const float* d_bank1, const float* 
 /* SpecAugment masking in place on d_spec [B, frames, channels]; d_masks int32 [B,8] =
  * {freq0 start, size, freq1 start, size, time0 start, size, time1 start, size}; size 0 = no mask. */
 int mkws_specaug_apply(float* d_spec, const int32_t* d_masks, int B, int frames, int channels, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training operators for `backprop_into_embedding=True` (multilingual_kws/embedding/transfer_learning.py:94-112).
+ * The reference un-freezes the whole nested EfficientNet, so Keras runs xfer.fit with training=True through
+ * keras/applications/efficientnet.py: BatchNormalization on batch statistics (+ moving-average updates), per-block
+ * drop-connect, gradients into every kernel / bias / gamma / beta, Adam.  Keras owns the graph there; here the tape
+ * is host code (multilingual_kws_amd/embedding_trainer.py) and each numerical operator is one entry point below.
+ * All tensors are device float32, NHWC viewed as row-major [M, C]; parameters keep their Keras layouts (1x1 conv
+ * kernel = [K, N], depthwise [kh, kw, C], dense [in, out]).  `act`: 0 none, 1 swish, 2 relu, 3 selu, 4 sigmoid.
+ * Cross-workgroup reductions use fp32 atomics (gradients are not bit-reproducible; inference is unaffected).
+ * ---------------------------------------------------------------------------------------------- */
+/* C[M,N] (+)= op(A)[M,K] . op(B)[K,N] on the fp32 MFMA; op(A)(m,k) = transA ? A[k*lda+m] : A[m*lda+k], likewise B.
+ * ksplit > 1 splits K over workgroups and adds into C atomically (requires accumulate = 1 and a zeroed or live C). */
+int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
+                 int accumulate, int ksplit, void* stream);
+/* Batch statistics of Z [M,C] per channel: mean, biased variance (two passes). */
+int mkws_op_bn_stats(const float* d_Z, int M, int C, float* d_mean, float* d_var, void* stream);
+/* A = act(gamma * (Z - mean) / sqrt(var + eps) + beta) */
+int mkws_op_bn_act_fwd(const float* d_Z, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, float eps, int act,
+                       float* d_A, int M, int C, void* stream);
+/* Backward of the above through the batch statistics: d_dA [M,C] holds dLoss/dA on entry and dLoss/dZ on return;
+ * d_dgamma / d_dbeta [C] are written; d_scratch: 2*C floats. */
+int mkws_op_bn_act_bwd(const float* d_Z, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, float eps, int act,
+                       float* d_dA, float* d_dgamma, float* d_dbeta, float* d_scratch, int M, int C, void* stream);
+/* moving = momentum * moving + (1 - momentum) * batch; the variance enters Bessel-corrected (M/(M-1)) as in Keras' fused BN. */
+int mkws_op_bn_update_moving(float* d_moving_mean, float* d_moving_var, const float* d_mean, const float* d_var, float momentum, int M, int C, void* stream);
+/* Depthwise k x k conv (k = 3, 5; stride 1, 2) with explicit top / left padding (Keras "same" or correct_pad), raw output. */
+int mkws_op_dwconv_fwd(const float* d_X, const float* d_W, float* d_Z, int B, int H, int W, int C, int k, int stride, int pad_top, int pad_left, int Ho,
+                       int Wo, void* stream);
+/* d_dX (may be NULL) <- input gradient, d_dW [k,k,C] <- weight gradient. */
+int mkws_op_dwconv_bwd(const float* d_X, const float* d_W, const float* d_dZ, float* d_dX, float* d_dW, int B, int H, int W, int C, int k, int stride,
+                       int pad_top, int pad_left, int Ho, int Wo, void* stream);
+/* Stem: Rescaling(1/255) + Normalization + ZeroPadding2D(((1,1),(0,1))) + Conv2D(32,3,s2,valid) on [B,49,40] -> raw [B,25,20,32]. */
+int mkws_op_stem_fwd(const float* d_spec, const float* d_W, float norm_mean, float norm_std, float* d_Z, int B, void* stream);
+int mkws_op_stem_bwd_weight(const float* d_spec, const float* d_dZ, float norm_mean, float norm_std, float* d_dW, int B, void* stream);
+/* mean over HW: A [B,HW,C] -> [B,C] */
+int mkws_op_pool_hw(const float* d_A, float* d_mean, int B, int HW, int C, void* stream);
+/* out[b,hw,c] = A[b,hw,c] * g[b,c]   (SE excite) */
+int mkws_op_scale_channels(const float* d_A, const float* d_g, float* d_out, int B, int HW, int C, void* stream);
+/* backward of the excite multiply: dA = dOut * g,  dg[b,c] = sum_hw dOut * A */
+int mkws_op_se_bwd(const float* d_A, const float* d_g, const float* d_dOut, float* d_dA, float* d_dg, int B, int HW, int C, void* stream);
+/* X[b,hw,c] += v[b,c] * scale   (backward of a mean over HW) */
+int mkws_op_add_bcast(float* d_X, const float* d_v, float scale, int B, int HW, int C, void* stream);
+/* A = act(Z + bias);  backward: d_dA <- dA * act'(Z + bias) in place, d_dbias [N] <- its column sums */
+int mkws_op_bias_act_fwd(const float* d_Z, const float* d_bias, int act, float* d_A, int M, int N, void* stream);
+int mkws_op_bias_act_bwd(const float* d_Z, const float* d_bias, int act, float* d_dA, float* d_dbias, int M, int N, void* stream);
+/* out[b,:] = a[b,:] * row_scale[b] (+ c[b,:] if c != NULL): drop-connect (keep / (1 - rate)) + residual add, and its backward */
+int mkws_op_row_scale_add(const float* d_a, const float* d_row_scale, const float* d_c, float* d_out, int B, int64_t per_row, void* stream);
+int mkws_op_axpy(float* d_y, const float* d_x, float alpha, int64_t n, void* stream);
+/* Keras Adam over a flat buffer (same arithmetic as mkws_head_adam_step). */
+int mkws_op_adam(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps, int step_t,
+                 float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

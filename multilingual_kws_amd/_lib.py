@@ -66,6 +66,26 @@ SYMBOLS = [
     ("mkws_heads_forward", _I, [ctypes.POINTER(_P), _I, _P, _I, _P, _P]),
     ("mkws_head_loss_grad", _I, [_P, _P, _P, _I, _P, _P]),
     ("mkws_head_adam_step", _I, [_P, _F, _F, _F, _F, _I, _F, _P]),
+    ("mkws_head_input_grad", _I, [_P, _P, _I, _P]),
+    # training operators (backprop_into_embedding)
+    ("mkws_op_gemm", _I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    ("mkws_op_bn_stats", _I, [_P, _I, _I, _P, _P, _P]),
+    ("mkws_op_bn_act_fwd", _I, [_P, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),
+    ("mkws_op_bn_act_bwd", _I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P]),
+    ("mkws_op_bn_update_moving", _I, [_P, _P, _P, _P, _F, _I, _I, _P]),
+    ("mkws_op_dwconv_fwd", _I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    ("mkws_op_dwconv_bwd", _I, [_P, _P, _P, _P, _P] + [_I] * 10 + [_P]),
+    ("mkws_op_stem_fwd", _I, [_P, _P, _F, _F, _P, _I, _P]),
+    ("mkws_op_stem_bwd_weight", _I, [_P, _P, _F, _F, _P, _I, _P]),
+    ("mkws_op_pool_hw", _I, [_P, _P, _I, _I, _I, _P]),
+    ("mkws_op_scale_channels", _I, [_P, _P, _P, _I, _I, _I, _P]),
+    ("mkws_op_se_bwd", _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    ("mkws_op_add_bcast", _I, [_P, _P, _F, _I, _I, _I, _P]),
+    ("mkws_op_bias_act_fwd", _I, [_P, _P, _I, _P, _I, _I, _P]),
+    ("mkws_op_bias_act_bwd", _I, [_P, _P, _I, _P, _P, _I, _I, _P]),
+    ("mkws_op_row_scale_add", _I, [_P, _P, _P, _P, _I, ctypes.c_int64, _P]),
+    ("mkws_op_axpy", _I, [_P, _P, _F, ctypes.c_int64, _P]),
+    ("mkws_op_adam", _I, [_P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _I, _F, _P]),
 ]
 
 _lib = None

@@ -197,6 +197,21 @@ __global__ __launch_bounds__(256) void head_grad_finish_kernel(HeadDims d, const
   }
 }
 
+// gradient of the mean loss w.r.t. the head's input rows: dX[b,k] = sum_j dpre[b,j] * W1[k,j]   (backprop_into_embedding)
+__global__ __launch_bounds__(256) void head_input_grad_kernel(HeadDims d, const float* __restrict__ params, const float* __restrict__ dpre, int B,
+                                                              float* __restrict__ dX) {
+  const size_t total = (size_t)B * d.in;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % d.in);
+    const size_t b = i / d.in;
+    const float* w = params + (size_t)k * d.hid;
+    const float* dp = dpre + b * d.hid;
+    float s = 0.0f;
+    for (int j = 0; j < d.hid; ++j) s += dp[j] * w[j];
+    dX[i] = s;
+  }
+}
+
 // Keras Adam (optimizer_v2/adam.py): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)
 __global__ __launch_bounds__(256) void head_adam_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ m,
                                                         float* __restrict__ v, int n, float lr_t, float beta1, float beta2, float eps,
@@ -335,6 +350,16 @@ int mkws_head_loss_grad(mkws_head* hd, const float* d_emb, const int32_t* d_labe
   const int total = hd->nparams + 2;
   hipLaunchKernelGGL(head_grad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, hd->d, hd->partial, splits, hd->hbuf, hd->dz, hd->dpre,
                      hd->rowstat, B, hd->grads, d_stats);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_head_input_grad(mkws_head* hd, float* d_dx, int B, void* stream) {
+  if (!hd || !d_dx) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
+  if (B <= 0 || B > hd->max_batch) return fail(MKWS_ERR_INVALID_ARG, "batch %d outside [1, max_batch=%d]", B, hd->max_batch);
+  const size_t total = (size_t)B * hd->d.in;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(head_input_grad_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, hd->dpre, B, d_dx);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

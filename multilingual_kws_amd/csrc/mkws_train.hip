@@ -1,0 +1,607 @@
+// mkws_train.hip -- training-mode operators for `backprop_into_embedding=True`
+// (multilingual_kws/embedding/transfer_learning.py:94-112: the reference un-freezes the whole nested EfficientNet, so
+// Keras runs it with training=True: BatchNormalization on batch statistics with moving-average updates, per-block
+// drop-connect, gradients into every kernel / bias / gamma / beta, Adam over all of them).
+//
+// The reference's training graph lives in Keras (Python); here the graph (forward tape + backward sweep) is host
+// code in multilingual_kws_amd/embedding_trainer.py and every numerical operator is one of the C-ABI entry points
+// below (include/mkws.h, "training operators").  All tensors are NHWC float32 viewed as row-major [M, C]; parameter
+// tensors keep their Keras layouts (conv kernels HWIO = [K, N] for 1x1, depthwise [kh, kw, C], dense [in, out]), so
+// the flat parameter / gradient buffers are the weight blob itself.
+// Reductions that cross workgroups use fp32 atomics (training is stochastic anyway: SpecAugment, drop-connect);
+// the inference path of this library stays bit-reproducible and does not use these kernels.
+#include "mkws_common.h"
+
+#include <cmath>
+
+#pragma clang fp contract(fast)
+
+namespace mkws {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+enum TrainAct { TA_NONE = 0, TA_SWISH = 1, TA_RELU = 2, TA_SELU = 3, TA_SIGMOID = 4 };
+constexpr float kSeluScale = 1.0507009873554805f, kSeluAlpha = 1.6732632423543772f;
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_fwd(float y, int act) {
+  switch (act) {
+    case TA_SWISH: return y * sigm(y);
+    case TA_RELU: return y > 0.0f ? y : 0.0f;
+    case TA_SELU: return kSeluScale * (y > 0.0f ? y : kSeluAlpha * expm1f(y));
+    case TA_SIGMOID: return sigm(y);
+    default: return y;
+  }
+}
+// d act(y) / dy
+__device__ __forceinline__ float act_grad(float y, int act) {
+  switch (act) {
+    case TA_SWISH: { const float s = sigm(y); return s * (1.0f + y * (1.0f - s)); }
+    case TA_RELU: return y > 0.0f ? 1.0f : 0.0f;
+    case TA_SELU: return kSeluScale * (y > 0.0f ? 1.0f : kSeluAlpha * expf(y));
+    case TA_SIGMOID: { const float s = sigm(y); return s * (1.0f - s); }
+    default: return 1.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic fp32 GEMM on the MFMA (v_mfma_f32_16x16x4_f32, exact fp32): C[M,N] (+)= op(A)[M,K] . op(B)[K,N].
+// 64x64 block tile, 4 waves (2x2), each wave 2x2 MFMA tiles; K step 16 through LDS.  Operands are read with guarded
+// scalar loads, so any M, N, K, leading dimension and both transposes work (1x1-conv forward: NN; input gradient
+// dZ . W^T: NT; weight gradient X^T . dZ: TN with the long reduction split over blockIdx.z and fp32 atomics).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
+                                                         int K, int lda, int ldb, int ldc, int accumulate, int ksplit) {
+  __shared__ float As[64][17];
+  __shared__ float Bs[16][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kper = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
+  const int kbeg = blockIdx.z * kper, kend = (kbeg + kper < K) ? kbeg + kper : K;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                      // A tile: 64 x 16
+      const int e = tid + 256 * i;
+      const int r = TA ? (e & 63) : (e >> 4), kk = TA ? (e >> 6) : (e & 15);
+      const int m = m0 + r, k = k0 + kk;
+      float v = 0.0f;
+      if (m < M && k < kend) v = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+      As[r][kk] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                      // B tile: 16 x 64
+      const int e = tid + 256 * i;
+      const int kk = TB ? (e & 15) : (e >> 6), cn = TB ? (e >> 4) : (e & 63);
+      const int n = n0 + cn, k = k0 + kk;
+      float v = 0.0f;
+      if (n < N && k < kend) v = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
+      Bs[kk][cn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[wm * 32 + i * 16 + (lane & 15)][ks + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[ks + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn * 32 + j * 16 + (lane & 15);
+        if (m < M && n < N) {
+          float* dst = C + (size_t)m * ldc + n;
+          if (ksplit > 1) atomicAdd(dst, acc[i][j][r]);
+          else *dst = accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+        }
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-channel sums over the rows of Z [M, C]: out[c] += sum_m f(Z[m, c]); MODE 0: z;  MODE 1: (z - mean[c])^2.
+// block = 64 channel lanes x 4 row lanes; grid (ceil(C/64), row chunks).
+template <int MODE>
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ Z, const float* __restrict__ mean, float* __restrict__ out, int M, int C) {
+  __shared__ float s[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per < M) ? r0 + per : M;
+  float acc = 0.0f;
+  if (c < C) {
+    const float mu = MODE == 1 ? mean[c] : 0.0f;
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float z = Z[(size_t)r * C + c];
+      acc += MODE == 1 ? (z - mu) * (z - mu) : z;
+    }
+  }
+  s[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(out + c, (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]));
+}
+
+__global__ void scale_vec_kernel(float* __restrict__ v, float s, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] *= s;
+}
+
+// A = act(gamma * (Z - mean) * rsqrt(var + eps) + beta)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+                                                         float* __restrict__ A, size_t total, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float xh = (Z[i] - mean[c]) * rsqrtf(var[c] + eps);
+    A[i] = act_fwd(gamma[c] * xh + beta[c], act);
+  }
+}
+
+// backward step 1: dY = dA * act'(y) in place, and sums[c] += dY, sums[C + c] += dY * xhat
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+                                                                float* __restrict__ dA, float* __restrict__ sums, int M, int C) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per < M) ? r0 + per : M;
+  float a1 = 0.0f, a2 = 0.0f;
+  if (c < C) {
+    const float mu = mean[c], inv = rsqrtf(var[c] + eps), g = gamma[c], b = beta[c];
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const size_t i = (size_t)r * C + c;
+      const float xh = (Z[i] - mu) * inv;
+      const float dy = dA[i] * act_grad(g * xh + b, act);
+      dA[i] = dy;
+      a1 += dy;
+      a2 += dy * xh;
+    }
+  }
+  s1[rl][cl] = a1; s2[rl][cl] = a2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(sums + c, (s1[0][cl] + s1[1][cl]) + (s1[2][cl] + s1[3][cl]));
+    atomicAdd(sums + C + c, (s2[0][cl] + s2[1][cl]) + (s2[2][cl] + s2[3][cl]));
+  }
+}
+
+// backward step 2: dZ = gamma * inv * (dY - sum(dY)/M - xhat * sum(dY xhat)/M) in place; dgamma, dbeta written by block 0
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ gamma, float eps, float* __restrict__ dY, const float* __restrict__ sums,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
+  const size_t total = (size_t)M * C;
+  const float invM = 1.0f / (float)M;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float inv = rsqrtf(var[c] + eps);
+    const float xh = (Z[i] - mean[c]) * inv;
+    dY[i] = gamma[c] * inv * (dY[i] - sums[c] * invM - xh * sums[C + c] * invM);
+  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
+}
+
+// moving = momentum * moving + (1 - momentum) * batch  (variance: Bessel-corrected, Keras' fused BN)
+__global__ void bn_moving_kernel(float* __restrict__ mmean, float* __restrict__ mvar, const float* __restrict__ mean, const float* __restrict__ var,
+                                 float momentum, float bessel, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    mmean[c] = momentum * mmean[c] + (1.0f - momentum) * mean[c];
+    mvar[c] = momentum * mvar[c] + (1.0f - momentum) * var[c] * bessel;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise conv (explicit TF/Keras padding pt / pl), raw output
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Z, int B, int H, int Wd,
+                                                     int C, int k, int s, int pt, int pl, int Ho, int Wo) {
+  const int cq = C / 4;
+  const size_t total = (size_t)B * Ho * Wo * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int q = (int)(i % cq);
+    size_t p = i / cq;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ii = 0; ii < k; ++ii) {
+      const int ih = oh * s - pt + ii;
+      if (ih < 0 || ih >= H) continue;
+      for (int jj = 0; jj < k; ++jj) {
+        const int iw = ow * s - pl + jj;
+        if (iw < 0 || iw >= Wd) continue;
+        acc += *reinterpret_cast<const f32x4*>(X + (((size_t)b * H + ih) * Wd + iw) * C + 4 * q) * *reinterpret_cast<const f32x4*>(W + (size_t)(ii * k + jj) * C + 4 * q);
+      }
+    }
+    *reinterpret_cast<f32x4*>(Z + i * 4) = acc;
+  }
+}
+
+// dX[b,ih,iw,c] = sum_{i,j} dZ[b,oh,ow,c] W[i,j,c] over the outputs that read this input
+__global__ __launch_bounds__(256) void dw_bwd_input_kernel(const float* __restrict__ dZ, const float* __restrict__ W, float* __restrict__ dX, int B, int H,
+                                                           int Wd, int C, int k, int s, int pt, int pl, int Ho, int Wo) {
+  const int cq = C / 4;
+  const size_t total = (size_t)B * H * Wd * cq;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int q = (int)(i % cq);
+    size_t p = i / cq;
+    const int iw = (int)(p % Wd); p /= Wd;
+    const int ih = (int)(p % H);
+    const int b = (int)(p / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ii = 0; ii < k; ++ii) {
+      const int t = ih + pt - ii;
+      if (t < 0 || t % s != 0) continue;
+      const int oh = t / s;
+      if (oh >= Ho) continue;
+      for (int jj = 0; jj < k; ++jj) {
+        const int u = iw + pl - jj;
+        if (u < 0 || u % s != 0) continue;
+        const int ow = u / s;
+        if (ow >= Wo) continue;
+        acc += *reinterpret_cast<const f32x4*>(dZ + (((size_t)b * Ho + oh) * Wo + ow) * C + 4 * q) * *reinterpret_cast<const f32x4*>(W + (size_t)(ii * k + jj) * C + 4 * q);
+      }
+    }
+    *reinterpret_cast<f32x4*>(dX + i * 4) = acc;
+  }
+}
+
+// dW[i,j,c] += sum_{b,oh,ow} dZ[b,oh,ow,c] X[b, oh*s-pt+i, ow*s-pl+j, c];  block = 64 channel quads x 4 position lanes
+template <int KS>
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ dW, int B, int H,
+                                                            int Wd, int C, int s, int pt, int pl, int Ho, int Wo) {
+  const int ql = threadIdx.x & 63, pl4 = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + ql;
+  if (q * 4 >= C) return;
+  const int npos = B * Ho * Wo;
+  const int per = (npos + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = (p0 + per < npos) ? p0 + per : npos;
+  f32x4 acc[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int p = p0 + pl4; p < p1; p += 4) {
+    const int ow = p % Wo, oh = (p / Wo) % Ho, b = p / (Wo * Ho);
+    const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + (size_t)p * C + 4 * q);
+#pragma unroll
+    for (int ii = 0; ii < KS; ++ii) {
+      const int ih = oh * s - pt + ii;
+      if (ih < 0 || ih >= H) continue;
+#pragma unroll
+      for (int jj = 0; jj < KS; ++jj) {
+        const int iw = ow * s - pl + jj;
+        if (iw < 0 || iw >= Wd) continue;
+        acc[ii * KS + jj] += dz * *reinterpret_cast<const f32x4*>(X + (((size_t)b * H + ih) * Wd + iw) * C + 4 * q);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dW + (size_t)t * C + 4 * q + r, acc[t][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: Rescaling(1/255) + Normalization + ZeroPadding2D(((1,1),(0,1))) + Conv2D(32, 3, s2, valid), raw output [B,25,20,32]
+__device__ __forceinline__ float stem_in(const float* img, int ih, int iw, float nm, float ns) {
+  return (ih >= 0 && ih < 49 && iw < 40) ? __fdiv_rn(img[ih * 40 + iw] * (1.0f / 255.0f) - nm, ns) : 0.0f;
+}
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ spec, const float* __restrict__ W /*[9][32]*/, float nm, float ns,
+                                                       float* __restrict__ Z, int B) {
+  const size_t total = (size_t)B * 500 * 8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int q = (int)(i & 7);
+    const size_t pix = i >> 3;
+    const int b = (int)(pix / 500), r = (int)(pix % 500), oh = r / 20, ow = r % 20;
+    const float* img = spec + (size_t)b * 1960;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) acc += *reinterpret_cast<const f32x4*>(W + (ii * 3 + jj) * 32 + 4 * q) * stem_in(img, oh * 2 - 1 + ii, ow * 2 + jj, nm, ns);
+    *reinterpret_cast<f32x4*>(Z + pix * 32 + 4 * q) = acc;
+  }
+}
+__global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ spec, const float* __restrict__ dZ, float nm, float ns,
+                                                              float* __restrict__ dW /*[9][32]*/, int B) {
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;            // 8 quads x 32 pixel lanes
+  const int npix = B * 500;
+  const int per = (npix + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int p = p0 + pl; p < p1; p += 32) {
+    const int b = p / 500, r = p % 500, oh = r / 20, ow = r % 20;
+    const float* img = spec + (size_t)b * 1960;
+    const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + (size_t)p * 32 + 4 * q);
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) acc[ii * 3 + jj] += dz * stem_in(img, oh * 2 - 1 + ii, ow * 2 + jj, nm, ns);
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dW + t * 32 + 4 * q + r, acc[t][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// squeeze-excite pieces and small elementwise operators
+// mean[b,c] = (1/HW) sum_hw A[b,hw,c]
+__global__ __launch_bounds__(256) void pool_hw_kernel(const float* __restrict__ A, float* __restrict__ mean, int B, int HW, int C) {
+  const int cq = C / 4;
+  const int total = B * cq;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int b = i / cq, q = i % cq;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p) s += *reinterpret_cast<const f32x4*>(A + ((size_t)b * HW + p) * C + 4 * q);
+    *reinterpret_cast<f32x4*>(mean + (size_t)b * C + 4 * q) = s * (1.0f / (float)HW);
+  }
+}
+// out[b,hw,c] = A[b,hw,c] * g[b,c]
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ A, const float* __restrict__ g, float* __restrict__ out, int B, int HW, int C) {
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const size_t b = i / ((size_t)HW * C);
+    out[i] = A[i] * g[b * C + c];
+  }
+}
+// dA[b,hw,c] = dOut * g[b,c];  dg[b,c] = sum_hw dOut * A
+__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ A, const float* __restrict__ g, const float* __restrict__ dOut, float* __restrict__ dA,
+                                                     float* __restrict__ dg, int B, int HW, int C) {
+  const int cq = C / 4;
+  const int total = B * cq;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int b = i / cq, q = i % cq;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (size_t)b * C + 4 * q);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p) {
+      const size_t o = ((size_t)b * HW + p) * C + 4 * q;
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dOut + o);
+      s += d * *reinterpret_cast<const f32x4*>(A + o);
+      *reinterpret_cast<f32x4*>(dA + o) = d * gv;
+    }
+    *reinterpret_cast<f32x4*>(dg + (size_t)b * C + 4 * q) = s;
+  }
+}
+// X[b,hw,c] += v[b,c] * scale   (gradient of a mean over hw; also: broadcast add)
+__global__ __launch_bounds__(256) void add_bcast_kernel(float* __restrict__ X, const float* __restrict__ v, float scale, int B, int HW, int C) {
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const size_t b = i / ((size_t)HW * C);
+    X[i] += v[b * C + c] * scale;
+  }
+}
+// A = act(Z + bias)
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ bias, int act, float* __restrict__ A, size_t total, int N) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) A[i] = act_fwd(Z[i] + bias[i % N], act);
+}
+// dZ = dA * act'(Z + bias) in place
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ bias, int act, float* __restrict__ dA, size_t total, int N) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dA[i] *= act_grad(Z[i] + bias[i % N], act);
+}
+// out[b, :] = a[b, :] * s[b] + c[b, :]   (c may be NULL)  -- drop-connect + residual add, and its backward
+__global__ __launch_bounds__(256) void row_scale_add_kernel(const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ c, float* __restrict__ out,
+                                                            int B, size_t per_row) {
+  const size_t total = (size_t)B * per_row;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const float v = a[i] * s[i / per_row];
+    out[i] = c ? v + c[i] : v;
+  }
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] += alpha * x[i];
+}
+// Keras Adam over a flat buffer (same arithmetic as head_adam_kernel)
+__global__ __launch_bounds__(256) void train_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                         float lr_t, float b1, float b2, float eps, float grad_scale) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    m[i] = mi; v[i] = vi;
+    p[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
+  }
+}
+
+inline int grid_for(size_t total, int cap = 8192) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+}  // namespace mkws
+
+using namespace mkws;
+
+#define MKWS_REQ(cond, ...) do { if (!(cond)) return fail(MKWS_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
+
+extern "C" {
+
+int mkws_op_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
+                 void* stream) {
+  MKWS_REQ(A && B && C, "gemm: NULL operand");
+  MKWS_REQ(M > 0 && N > 0 && K > 0 && ksplit >= 1, "gemm: bad dimensions");
+  MKWS_REQ(ksplit == 1 || accumulate, "gemm: a split reduction adds into C (zero it and pass accumulate=1)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
+  if (!transA && !transB) hipLaunchKernelGGL((train_gemm_kernel<false, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
+  else if (!transA) hipLaunchKernelGGL((train_gemm_kernel<false, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
+  else if (!transB) hipLaunchKernelGGL((train_gemm_kernel<true, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
+  else hipLaunchKernelGGL((train_gemm_kernel<true, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_bn_stats(const float* Z, int M, int C, float* mean, float* var, void* stream) {
+  MKWS_REQ(Z && mean && var && M > 0 && C > 0, "bn_stats: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int chunks = (M + 255) / 256; if (chunks > 256) chunks = 256; if (chunks < 1) chunks = 1;
+  const dim3 grid((C + 63) / 64, chunks);
+  MKWS_HIP(hipMemsetAsync(mean, 0, (size_t)C * sizeof(float), s));
+  MKWS_HIP(hipMemsetAsync(var, 0, (size_t)C * sizeof(float), s));
+  hipLaunchKernelGGL((col_sum_kernel<0>), grid, dim3(256), 0, s, Z, nullptr, mean, M, C);
+  hipLaunchKernelGGL(scale_vec_kernel, dim3((C + 255) / 256), dim3(256), 0, s, mean, 1.0f / (float)M, C);
+  hipLaunchKernelGGL((col_sum_kernel<1>), grid, dim3(256), 0, s, Z, mean, var, M, C);
+  hipLaunchKernelGGL(scale_vec_kernel, dim3((C + 255) / 256), dim3(256), 0, s, var, 1.0f / (float)M, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_bn_act_fwd(const float* Z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, float* A, int M, int C,
+                       void* stream) {
+  MKWS_REQ(Z && mean && var && gamma && beta && A && M > 0 && C > 0, "bn_act_fwd: bad arguments");
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), Z, mean, var, gamma, beta, eps, act, A, total, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_bn_act_bwd(const float* Z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, float* dA, float* dgamma,
+                       float* dbeta, float* scratch, int M, int C, void* stream) {
+  MKWS_REQ(Z && mean && var && gamma && beta && dA && dgamma && dbeta && scratch && M > 0 && C > 0, "bn_act_bwd: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int chunks = (M + 255) / 256; if (chunks > 256) chunks = 256; if (chunks < 1) chunks = 1;
+  MKWS_HIP(hipMemsetAsync(scratch, 0, 2 * (size_t)C * sizeof(float), s));
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, scratch, M, C);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)M * C)), dim3(256), 0, s, Z, mean, var, gamma, eps, dA, scratch, dgamma, dbeta, M, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_bn_update_moving(float* moving_mean, float* moving_var, const float* mean, const float* var, float momentum, int M, int C, void* stream) {
+  MKWS_REQ(moving_mean && moving_var && mean && var && M > 0 && C > 0, "bn_update_moving: bad arguments");
+  const float bessel = M > 1 ? (float)M / (float)(M - 1) : 1.0f;
+  hipLaunchKernelGGL(bn_moving_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), moving_mean, moving_var, mean, var, momentum, bessel, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_dwconv_fwd(const float* X, const float* W, float* Z, int B, int H, int Wd, int C, int k, int s, int pt, int pl, int Ho, int Wo, void* stream) {
+  MKWS_REQ(X && W && Z && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_fwd: bad arguments");
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), X, W, Z, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_dwconv_bwd(const float* X, const float* W, const float* dZ, float* dX, float* dW, int B, int H, int Wd, int C, int k, int s, int pt, int pl, int Ho,
+                       int Wo, void* stream) {
+  MKWS_REQ(X && W && dZ && dW && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_bwd: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dX) hipLaunchKernelGGL(dw_bwd_input_kernel, dim3(grid_for((size_t)B * H * Wd * (C / 4))), dim3(256), 0, st, dZ, W, dX, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
+  MKWS_HIP(hipMemsetAsync(dW, 0, (size_t)k * k * C * sizeof(float), st));
+  int chunks = (B * Ho * Wo + 63) / 64; if (chunks > 128) chunks = 128; if (chunks < 1) chunks = 1;
+  const dim3 grid((C / 4 + 63) / 64, chunks);
+  if (k == 3) hipLaunchKernelGGL((dw_bwd_weight_kernel<3>), grid, dim3(256), 0, st, X, dZ, dW, B, H, Wd, C, s, pt, pl, Ho, Wo);
+  else hipLaunchKernelGGL((dw_bwd_weight_kernel<5>), grid, dim3(256), 0, st, X, dZ, dW, B, H, Wd, C, s, pt, pl, Ho, Wo);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_stem_fwd(const float* spec, const float* W, float norm_mean, float norm_std, float* Z, int B, void* stream) {
+  MKWS_REQ(spec && W && Z && B > 0, "stem_fwd: bad arguments");
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid_for((size_t)B * 500 * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), spec, W, norm_mean, norm_std, Z, B);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_stem_bwd_weight(const float* spec, const float* dZ, float norm_mean, float norm_std, float* dW, int B, void* stream) {
+  MKWS_REQ(spec && dZ && dW && B > 0, "stem_bwd_weight: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MKWS_HIP(hipMemsetAsync(dW, 0, 9 * 32 * sizeof(float), s));
+  int blocks = (B * 500 + 255) / 256; if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, dZ, norm_mean, norm_std, dW, B);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_pool_hw(const float* A, float* mean, int B, int HW, int C, void* stream) {
+  MKWS_REQ(A && mean && B > 0 && HW > 0 && C % 4 == 0, "pool_hw: bad arguments");
+  hipLaunchKernelGGL(pool_hw_kernel, dim3(grid_for((size_t)B * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), A, mean, B, HW, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_scale_channels(const float* A, const float* g, float* out, int B, int HW, int C, void* stream) {
+  MKWS_REQ(A && g && out && B > 0 && HW > 0 && C > 0, "scale_channels: bad arguments");
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for((size_t)B * HW * C)), dim3(256), 0, static_cast<hipStream_t>(stream), A, g, out, B, HW, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_se_bwd(const float* A, const float* g, const float* dOut, float* dA, float* dg, int B, int HW, int C, void* stream) {
+  MKWS_REQ(A && g && dOut && dA && dg && B > 0 && HW > 0 && C % 4 == 0, "se_bwd: bad arguments");
+  hipLaunchKernelGGL(se_bwd_kernel, dim3(grid_for((size_t)B * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), A, g, dOut, dA, dg, B, HW, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_add_bcast(float* X, const float* v, float scale, int B, int HW, int C, void* stream) {
+  MKWS_REQ(X && v && B > 0 && HW > 0 && C > 0, "add_bcast: bad arguments");
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for((size_t)B * HW * C)), dim3(256), 0, static_cast<hipStream_t>(stream), X, v, scale, B, HW, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_bias_act_fwd(const float* Z, const float* bias, int act, float* A, int M, int N, void* stream) {
+  MKWS_REQ(Z && bias && A && M > 0 && N > 0, "bias_act_fwd: bad arguments");
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(bias_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), Z, bias, act, A, total, N);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_bias_act_bwd(const float* Z, const float* bias, int act, float* dA, float* dbias, int M, int N, void* stream) {
+  MKWS_REQ(Z && bias && dA && dbias && M > 0 && N > 0, "bias_act_bwd: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, Z, bias, act, dA, total, N);
+  MKWS_HIP(hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), s));
+  int chunks = (M + 63) / 64; if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL((col_sum_kernel<0>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, dA, nullptr, dbias, M, N);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_row_scale_add(const float* a, const float* row_scale, const float* c, float* out, int B, int64_t per_row, void* stream) {
+  MKWS_REQ(a && row_scale && out && B > 0 && per_row > 0, "row_scale_add: bad arguments");
+  hipLaunchKernelGGL(row_scale_add_kernel, dim3(grid_for((size_t)B * per_row)), dim3(256), 0, static_cast<hipStream_t>(stream), a, row_scale, c, out, B, (size_t)per_row);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_axpy(float* y, const float* x, float alpha, int64_t n, void* stream) {
+  MKWS_REQ(y && x && n > 0, "axpy: bad arguments");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), y, x, alpha, (size_t)n);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_adam(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step_t, float grad_scale,
+                 void* stream) {
+  MKWS_REQ(params && grads && m && v && n > 0 && step_t >= 1, "adam: bad arguments");
+  const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, step_t)) / (1.0 - std::pow((double)beta1, step_t));
+  hipLaunchKernelGGL(train_adam_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, m, v, (size_t)n, (float)lr_t, beta1, beta2,
+                     eps, grad_scale);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+}  // extern "C"

@@ -117,10 +117,6 @@ def transfer_learn(
     batch_size is the PER-RANK batch under torch.distributed (weak scaling)."""
     if base_model_output != "dense_2":
         raise ValueError(f'this build cuts the embedding at "dense_2" (got {base_model_output!r})')
-    if backprop_into_embedding:
-        # The reference's second phase un-freezes the whole nested EfficientNet (SURVEY.md section 3c
-        # quirk); it needs conv/depthwise/BN backward kernels, which are outside this hot path.
-        raise NotImplementedError("backprop_into_embedding=True is not supported (frozen embedding only)")
     import torch
     rank, world = parallel.rank(), parallel.world_size()
     embedding, blob = load_base_model(base_model_path, max_batch=max(batch_size, 64))
@@ -149,32 +145,62 @@ def transfer_learn(
     val_ds = init_val_ds.batch(batch_size)
 
     steps_per_epoch = batch_size * num_batches          # (sic) -- reference :89
-    history = {"loss": [], "accuracy": [], "val_loss": [], "val_accuracy": []}
     train_iter = iter(train_ds)
-    for epoch in range(num_epochs):
-        acc_stats = torch.zeros(2, dtype=torch.float64, device=embedding.device)
-        seen = 0
-        for _ in range(steps_per_epoch):
-            spec, labels = next(train_iter)
-            emb = embedding.forward(spec)
-            stats = parallel.dp_step(head, emb, labels, lr=primary_lr)
-            acc_stats += stats.to(torch.float64)
-            seen += spec.shape[0] * world
-        tl, ta = (acc_stats / max(seen, 1)).tolist()
-        # validation: every rank evaluates the full (small) validation set
-        vstats, vseen = np.zeros(2), 0
-        for spec, labels in val_ds:
-            probs = xfer.predict_device(spec[..., 0])
-            lab = labels.long()
-            vstats[0] += float(-torch.log(torch.clamp(probs[torch.arange(len(lab)), lab], min=1e-7)).sum())
-            vstats[1] += float((probs.argmax(1) == lab).sum())
-            vseen += len(lab)
-        vl, va = (vstats / max(vseen, 1)).tolist()
-        for k, v in zip(("loss", "accuracy", "val_loss", "val_accuracy"), (tl, ta, vl, va)):
-            history[k].append(v)
-        if verbose and rank == 0:
-            print(f"Epoch {epoch + 1}/{num_epochs} - {steps_per_epoch} steps - loss: {tl:.4f} - accuracy: {ta:.4f} "
-                  f"- val_loss: {vl:.4f} - val_accuracy: {va:.4f}")
+    phases = [("head", primary_lr)]
+    if backprop_into_embedding:
+        # reference :94-112: `layer.trainable = True` on the nested embedding Model un-freezes ALL of its layers
+        # (BatchNormalization too), the model is re-compiled with a fresh Adam(embedding_lr) and fitted again for
+        # the same number of epochs; the returned history / val_accuracy are the second fit's.
+        phases.append(("all", embedding_lr))
+    trainer, history = None, None
+    for phase, lr in phases:
+        if phase == "all":
+            from ..arch import BLOCKS
+            from ..embedding_trainer import DROP_CONNECT_RATE, EmbeddingTrainer
+            trainer = EmbeddingTrainer(blob, device=embedding.device)
+            head.reset_optimizer()
+        history = {"loss": [], "accuracy": [], "val_loss": [], "val_accuracy": []}
+        for epoch in range(num_epochs):
+            acc_stats = torch.zeros(2, dtype=torch.float64, device=embedding.device)
+            seen = 0
+            for _ in range(steps_per_epoch):
+                spec, labels = next(train_iter)
+                if trainer is None:
+                    emb = embedding.forward(spec)
+                    stats = parallel.dp_step(head, emb, labels, lr=lr)
+                else:
+                    nb = spec.shape[0]
+                    masks = {name: audio_dataset.rng.uniform(0, 1, nb) >= DROP_CONNECT_RATE * bi / len(BLOCKS)
+                             for bi, (name, cin, cout, k, s, e) in enumerate(BLOCKS) if s == 1 and cin == cout}
+                    emb = trainer.forward_train(spec, masks)
+                    stats = head.loss_grad(emb, labels)
+                    trainer.backward(head.input_grad(nb), allreduce=world > 1)
+                    if world > 1:
+                        stats = parallel.allreduce_sum_(head.grad_view(with_stats=True))[-2:]
+                    head.adam_step(lr=lr, grad_scale=1.0 / world)
+                    trainer.adam_step(lr=lr, grad_scale=1.0 / world)
+                acc_stats += stats.to(torch.float64)
+                seen += spec.shape[0] * world
+            tl, ta = (acc_stats / max(seen, 1)).tolist()
+            if trainer is not None:      # validation runs the inference kernels on the current weights (moving statistics)
+                blob = trainer.blob()
+                embedding = EmbeddingModel(blob, max_batch=max(batch_size, 64), device=embedding.device)
+                xfer.embedding, xfer._blob = embedding, blob
+                xfer.base_model_path = "fine-tuned:" + str(base_model_path)
+            # validation: every rank evaluates the full (small) validation set
+            vstats, vseen = np.zeros(2), 0
+            for spec, labels in val_ds:
+                probs = xfer.predict_device(spec[..., 0])
+                lab = labels.long()
+                vstats[0] += float(-torch.log(torch.clamp(probs[torch.arange(len(lab)), lab], min=1e-7)).sum())
+                vstats[1] += float((probs.argmax(1) == lab).sum())
+                vseen += len(lab)
+            vl, va = (vstats / max(vseen, 1)).tolist()
+            for k, v in zip(("loss", "accuracy", "val_loss", "val_accuracy"), (tl, ta, vl, va)):
+                history[k].append(v)
+            if verbose and rank == 0:
+                print(f"Epoch {epoch + 1}/{num_epochs} - {steps_per_epoch} steps - loss: {tl:.4f} - accuracy: {ta:.4f} "
+                      f"- val_loss: {vl:.4f} - val_accuracy: {va:.4f}")
     if csvlog_dest is not None and rank == 0:
         with open(csvlog_dest, "w", newline="") as f:
             w = csv.writer(f)

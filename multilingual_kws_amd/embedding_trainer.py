@@ -1,0 +1,270 @@
+"""Training-mode embedding network for `backprop_into_embedding=True`
+(multilingual_kws/embedding/transfer_learning.py:94-112).
+
+The reference sets `layer.trainable = True` on the nested embedding Model, which un-freezes EVERY layer inside it
+(BatchNormalization included -- SURVEY.md section 3c), so the second `xfer.fit` runs keras/applications/efficientnet.py
+with training=True: BatchNormalization normalises with batch statistics and updates its moving averages
+(momentum 0.99, eps 1e-3), residual blocks apply drop-connect (Dropout with noise_shape (None,1,1,1), rate
+0.2 * block_index / 16), and Adam(embedding_lr) updates every kernel, bias, gamma and beta.
+
+Keras owns that graph in the reference; this module is its host-side counterpart: a forward tape and a backward
+sweep over the C-ABI training operators of include/mkws.h (`mkws_op_*`, hand-written HIP in csrc/mkws_train.hip).
+PyTorch only provides device memory, streams and torch.distributed.  Parameters, gradients and Adam moments are flat
+device buffers in the weight blob's own order and Keras layouts, so the gradient all-reduce is a handful of
+contiguous RCCL calls, issued as soon as a range of the buffer is final (the dense layers -- 93 % of the bytes --
+finish first) so they overlap the rest of the backward sweep.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib, weights
+from .arch import BLOCKS
+
+BN_EPS, BN_MOMENTUM, DROP_CONNECT_RATE = 1e-3, 0.99, 0.2
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+def _down(h, w, k):
+    pt, pl = k // 2 - (1 - h % 2), k // 2 - (1 - w % 2)
+    return (h + pt + k // 2 - k) // 2 + 1, (w + pl + k // 2 - k) // 2 + 1, pt, pl
+
+
+class EmbeddingTrainer:
+    def __init__(self, weight_blob, device=None):
+        import torch
+        self.torch = torch
+        self.L = _lib.lib()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        blob = np.ascontiguousarray(weight_blob, dtype=np.float32)
+        if blob.shape[0] != weights.weight_count():
+            raise ValueError(f"blob has {blob.shape[0]} floats, architecture needs {weights.weight_count()}")
+        self.tensors = {t["name"]: t for t in weights.manifest()}
+        self.params = torch.from_numpy(blob.copy()).to(self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.step_t = 0
+        self.norm_mean = float(blob[self.tensors["normalization/mean"]["offset"]])
+        self.norm_std = max(float(np.sqrt(blob[self.tensors["normalization/variance"]["offset"]])), 1e-7)
+        self.tape = None
+        self._pending = []
+
+    # ---- plumbing -----------------------------------------------------------------------------------------------------
+    def _s(self):
+        return _lib.current_stream_ptr()
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    def P(self, name):
+        t = self.tensors[name]
+        return self.params[t["offset"]:t["offset"] + t["count"]]
+
+    def G(self, name):
+        t = self.tensors[name]
+        return self.grads[t["offset"]:t["offset"] + t["count"]]
+
+    def new(self, *shape):
+        return self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
+
+    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, acc=0, ksplit=1):
+        _lib.check(self.L.mkws_op_gemm(self._p(A), self._p(B), self._p(C), M, N, K, lda, ldb, ldc, ta, tb, acc, ksplit, self._s()))
+
+    def blob(self):
+        """Current parameters (incl. updated BatchNorm moving statistics) as a host weight blob."""
+        return self.params.cpu().numpy()
+
+    # ---- layers ---------------------------------------------------------------------------------------------------------
+    def _bn_fwd(self, Z, M, C, prefix, act):
+        mean, var = self.new(C), self.new(C)
+        _lib.check(self.L.mkws_op_bn_stats(self._p(Z), M, C, self._p(mean), self._p(var), self._s()))
+        A = self.new(M, C)
+        _lib.check(self.L.mkws_op_bn_act_fwd(self._p(Z), self._p(mean), self._p(var), self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")),
+                                             BN_EPS, act, self._p(A), M, C, self._s()))
+        # Keras updates the moving averages during the training-mode forward pass
+        _lib.check(self.L.mkws_op_bn_update_moving(self._p(self.P(prefix + "/moving_mean")), self._p(self.P(prefix + "/moving_variance")), self._p(mean), self._p(var),
+                                                   BN_MOMENTUM, M, C, self._s()))
+        return A, (Z, mean, var, M, C, prefix, act)
+
+    def _bn_bwd(self, rec, dA):
+        """dA [M,C] (dLoss/dA) -> overwritten with dLoss/dZ; writes dgamma / dbeta."""
+        Z, mean, var, M, C, prefix, act = rec
+        scratch = self.new(2 * C)
+        _lib.check(self.L.mkws_op_bn_act_bwd(self._p(Z), self._p(mean), self._p(var), self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")), BN_EPS, act,
+                                             self._p(dA), self._p(self.G(prefix + "/gamma")), self._p(self.G(prefix + "/beta")), self._p(scratch), M, C, self._s()))
+        return dA
+
+    def _conv_fwd(self, X, M, K, N, wname):
+        Z = self.new(M, N)
+        self.gemm(X, self.P(wname), Z, M, N, K, K, N, N)
+        return Z
+
+    def _conv_bwd(self, X, dZ, M, K, N, wname, need_dx=True):
+        """dW += X^T dZ (long reduction split over workgroups), dX = dZ W^T."""
+        ksplit = max(1, min(64, M // 512))
+        self.gemm(X, dZ, self.G(wname), K, N, M, K, N, N, ta=1, tb=0, acc=1, ksplit=ksplit)
+        if not need_dx:
+            return None
+        dX = self.new(M, K)
+        self.gemm(dZ, self.P(wname), dX, M, K, N, N, N, K, ta=0, tb=1)
+        return dX
+
+    def _fc_fwd(self, X, M, K, N, prefix, act):
+        Z = self.new(M, N)
+        self.gemm(X, self.P(prefix + "/kernel"), Z, M, N, K, K, N, N)
+        A = self.new(M, N)
+        _lib.check(self.L.mkws_op_bias_act_fwd(self._p(Z), self._p(self.P(prefix + "/bias")), act, self._p(A), M, N, self._s()))
+        return A, (X, Z, M, K, N, prefix, act)
+
+    def _fc_bwd(self, rec, dA, need_dx=True):
+        X, Z, M, K, N, prefix, act = rec
+        _lib.check(self.L.mkws_op_bias_act_bwd(self._p(Z), self._p(self.P(prefix + "/bias")), act, self._p(dA), self._p(self.G(prefix + "/bias")), M, N, self._s()))
+        return self._conv_bwd(X, dA, M, K, N, prefix + "/kernel", need_dx)
+
+    # ---- forward (training mode) ------------------------------------------------------------------------------------------
+    def forward_train(self, spec, drop_masks=None):
+        """spec CUDA [B,49,40(,1)] -> embedding CUDA [B,1024] in TRAINING mode; keeps the tape for backward().
+        drop_masks: {block name: bool [B] of KEPT samples} for the residual blocks, or None (no drop-connect)."""
+        torch = self.torch
+        spec = spec.to(self.device, dtype=torch.float32)
+        if spec.dim() == 4:
+            spec = spec[..., 0]
+        spec = spec.contiguous()
+        B = spec.shape[0]
+        tape = {"spec": spec, "B": B, "blocks": []}
+        H, W = 25, 20
+        Z = self.new(B * H * W, 32)
+        _lib.check(self.L.mkws_op_stem_fwd(self._p(spec), self._p(self.P("stem_conv/kernel")), self.norm_mean, self.norm_std, self._p(Z), B, self._s()))
+        x, tape["stem_bn"] = self._bn_fwd(Z, B * H * W, 32, "stem_bn", ACT_SWISH)
+        for bi, (name, cin, cout, k, s, e) in enumerate(BLOCKS):
+            p = "block" + name
+            ce, se = cin * e, max(1, int(cin * 0.25))
+            rec = {"name": name, "inp": x, "H": H, "W": W, "cin": cin, "cout": cout, "k": k, "s": s, "ce": ce, "se": se}
+            Min = B * H * W
+            if e != 1:
+                Ze = self._conv_fwd(x, Min, cin, ce, p + "_expand_conv/kernel")
+                Ae, rec["expand_bn"] = self._bn_fwd(Ze, Min, ce, p + "_expand_bn", ACT_SWISH)
+            else:
+                Ae = x
+            if s == 2:
+                Ho, Wo, pt, pl = _down(H, W, k)
+            else:
+                Ho, Wo, pt, pl = H, W, k // 2, k // 2
+            rec.update(Ho=Ho, Wo=Wo, pt=pt, pl=pl, Ae=Ae)
+            Mout = B * Ho * Wo
+            Zd = self.new(Mout, ce)
+            _lib.check(self.L.mkws_op_dwconv_fwd(self._p(Ae), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(Zd), B, H, W, ce, k, s, pt, pl, Ho, Wo, self._s()))
+            Ad, rec["dw_bn"] = self._bn_fwd(Zd, Mout, ce, p + "_bn", ACT_SWISH)
+            mean = self.new(B, ce)
+            _lib.check(self.L.mkws_op_pool_hw(self._p(Ad), self._p(mean), B, Ho * Wo, ce, self._s()))
+            R, rec["se_reduce"] = self._fc_fwd(mean, B, ce, se, p + "_se_reduce", ACT_SWISH)
+            Gt, rec["se_expand"] = self._fc_fwd(R, B, se, ce, p + "_se_expand", ACT_SIGMOID)
+            As = self.new(Mout, ce)
+            _lib.check(self.L.mkws_op_scale_channels(self._p(Ad), self._p(Gt), self._p(As), B, Ho * Wo, ce, self._s()))
+            rec.update(Ad=Ad, Gt=Gt, As=As)
+            Zp = self._conv_fwd(As, Mout, ce, cout, p + "_project_conv/kernel")
+            Pj, rec["project_bn"] = self._bn_fwd(Zp, Mout, cout, p + "_project_bn", ACT_NONE)
+            rec["residual"] = (s == 1 and cin == cout)
+            if rec["residual"]:
+                scale = torch.ones(B, dtype=torch.float32, device=self.device)
+                if drop_masks is not None and name in drop_masks:
+                    rate = DROP_CONNECT_RATE * bi / len(BLOCKS)
+                    scale = torch.as_tensor(np.asarray(drop_masks[name]), device=self.device).to(torch.float32) / (1.0 - rate)
+                rec["keep_scale"] = scale.contiguous()
+                out = self.new(Mout, cout)
+                _lib.check(self.L.mkws_op_row_scale_add(self._p(Pj), self._p(rec["keep_scale"]), self._p(x), self._p(out), B, Ho * Wo * cout, self._s()))
+                x = out
+            else:
+                x = Pj
+            tape["blocks"].append(rec)
+            H, W = Ho, Wo
+        HW = H * W
+        tape["top_in"], tape["HW"] = x, HW
+        Zt = self._conv_fwd(x, B * HW, 320, 1280, "top_conv/kernel")
+        At, tape["top_bn"] = self._bn_fwd(Zt, B * HW, 1280, "top_bn", ACT_SWISH)
+        gap = self.new(B, 1280)
+        _lib.check(self.L.mkws_op_pool_hw(self._p(At), self._p(gap), B, HW, 1280, self._s()))
+        a, tape["dense"] = self._fc_fwd(gap, B, 1280, 2048, "dense", ACT_RELU)
+        a, tape["dense_1"] = self._fc_fwd(a, B, 2048, 2048, "dense_1", ACT_RELU)
+        emb, tape["dense_2"] = self._fc_fwd(a, B, 2048, 1024, "dense_2", ACT_SELU)
+        self.tape = tape
+        return emb
+
+    # ---- backward ---------------------------------------------------------------------------------------------------------
+    def backward(self, d_emb, allreduce=False):
+        """d_emb CUDA [B,1024] = dLoss/dEmbedding of the forward_train() batch.  Fills self.grads (blob layout).
+        allreduce: sum the gradient over torch.distributed ranks, overlapped with the sweep."""
+        torch = self.torch
+        tape = self.tape
+        if tape is None:
+            raise RuntimeError("backward() needs a forward_train() first")
+        B = tape["B"]
+        self.grads.zero_()
+        self._pending = []
+        d = d_emb.to(self.device, dtype=torch.float32).contiguous().clone()
+        d = self._fc_bwd(tape["dense_2"], d)
+        d = self._fc_bwd(tape["dense_1"], d)
+        if allreduce:      # dense_1 / dense_2 (25 M of the 52 MB) are final: their all-reduce runs under the rest of the sweep
+            self._allreduce_range(self.tensors["dense_1/kernel"]["offset"], self.grads.shape[0])
+        d = self._fc_bwd(tape["dense"], d)
+        HW = tape["HW"]
+        dAt = torch.zeros((B * HW, 1280), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.mkws_op_add_bcast(self._p(dAt), self._p(d), 1.0 / HW, B, HW, 1280, self._s()))
+        dZt = self._bn_bwd(tape["top_bn"], dAt)
+        d = self._conv_bwd(tape["top_in"], dZt, B * HW, 320, 1280, "top_conv/kernel")
+        if allreduce:
+            self._allreduce_range(self.tensors["top_conv/kernel"]["offset"], self.tensors["dense_1/kernel"]["offset"])
+        for rec in reversed(tape["blocks"]):
+            p = "block" + rec["name"]
+            H, W, Ho, Wo, cin, cout, ce, se, k, s = (rec[q] for q in ("H", "W", "Ho", "Wo", "cin", "cout", "ce", "se", "k", "s"))
+            Min, Mout = B * H * W, B * Ho * Wo
+            d_out = d
+            if rec["residual"]:
+                dP = self.new(Mout, cout)
+                _lib.check(self.L.mkws_op_row_scale_add(self._p(d_out), self._p(rec["keep_scale"]), None, self._p(dP), B, Ho * Wo * cout, self._s()))
+            else:
+                dP = d_out
+            dZp = self._bn_bwd(rec["project_bn"], dP)
+            dAs = self._conv_bwd(rec["As"], dZp, Mout, ce, cout, p + "_project_conv/kernel")
+            dAd, dG = self.new(Mout, ce), self.new(B, ce)
+            _lib.check(self.L.mkws_op_se_bwd(self._p(rec["Ad"]), self._p(rec["Gt"]), self._p(dAs), self._p(dAd), self._p(dG), B, Ho * Wo, ce, self._s()))
+            dR = self._fc_bwd(rec["se_expand"], dG)
+            dmean = self._fc_bwd(rec["se_reduce"], dR)
+            _lib.check(self.L.mkws_op_add_bcast(self._p(dAd), self._p(dmean), 1.0 / (Ho * Wo), B, Ho * Wo, ce, self._s()))
+            dZd = self._bn_bwd(rec["dw_bn"], dAd)
+            dAe = self.new(Min, ce)
+            _lib.check(self.L.mkws_op_dwconv_bwd(self._p(rec["Ae"]), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(dZd), self._p(dAe),
+                                                 self._p(self.G(p + "_dwconv/depthwise_kernel")), B, H, W, ce, k, s, rec["pt"], rec["pl"], Ho, Wo, self._s()))
+            if "expand_bn" in rec:
+                dZe = self._bn_bwd(rec["expand_bn"], dAe)
+                d_in = self._conv_bwd(rec["inp"], dZe, Min, cin, ce, p + "_expand_conv/kernel")
+            else:
+                d_in = dAe
+            if rec["residual"]:
+                _lib.check(self.L.mkws_op_axpy(self._p(d_in), self._p(d_out), 1.0, d_in.numel(), self._s()))
+            d = d_in
+        dZ0 = self._bn_bwd(tape["stem_bn"], d)
+        _lib.check(self.L.mkws_op_stem_bwd_weight(self._p(tape["spec"]), self._p(dZ0), self.norm_mean, self.norm_std, self._p(self.G("stem_conv/kernel")), B, self._s()))
+        if allreduce:
+            self._allreduce_range(0, self.tensors["top_conv/kernel"]["offset"])
+            for h in self._pending:
+                h.wait()
+            self._pending = []
+        self.tape = None
+
+    def _allreduce_range(self, lo, hi):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            self._pending.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """Keras Adam over the whole blob (moving statistics / Normalization constants have zero gradient and stay put)."""
+        self.step_t += 1
+        _lib.check(self.L.mkws_op_adam(self._p(self.params), self._p(self.grads), self._p(self.m), self._p(self.v), self.params.shape[0], lr, beta1, beta2, eps,
+                                       self.step_t, grad_scale, self._s()))
+
+    def named_grads(self):
+        g = self.grads.cpu().numpy()
+        return {n: g[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"]) for n, t in self.tensors.items()}

@@ -121,6 +121,18 @@ class Head:
                                                   emb.shape[0], ctypes.c_void_p(self._stats.data_ptr()), _lib.current_stream_ptr()))
         return self._stats
 
+    def input_grad(self, B):
+        """After loss_grad on B rows: d(mean loss)/d(embedding rows), CUDA [B, in] (backprop_into_embedding)."""
+        import torch
+        dx = torch.empty((B, self.in_dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mkws_head_input_grad(self.h, ctypes.c_void_p(dx.data_ptr()), B, _lib.current_stream_ptr()))
+        return dx
+
+    def reset_optimizer(self):
+        """A fresh Adam (zero moments, t = 0) on the current parameters -- what re-compiling the Keras model does."""
+        self.set_params(self.get_params())
+
     def adam_step(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         import torch
         self.step_t += 1

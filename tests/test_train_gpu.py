@@ -1,0 +1,312 @@
+"""-m gpu: `backprop_into_embedding=True` (reference transfer_learning.py:94-112).
+Training operators (mkws_op_*) against plain PyTorch-CPU fp32/fp64 references of the same op, the whole
+training-mode network's gradients against oracle/efficientnet_train_oracle.py (float64 autograd, itself checked
+against finite differences in tests/test_oracle_train.py), and the two-phase transfer_learn call."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.util_data import make_fewshot_dataset
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from multilingual_kws_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+
+    class Ops:
+        pass
+    o = Ops()
+    o.L, o.dev, o.check, o.s = L, dev, _lib.check, _lib.current_stream_ptr
+    o.p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    o.t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    return o
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,ks", [(130, 96, 16, 0, 0, 1), (77, 24, 144, 0, 0, 1), (64, 40, 100, 0, 1, 1), (16, 96, 4000, 1, 0, 7),
+                                            (240, 10, 6, 0, 0, 1), (5, 6, 240, 0, 1, 1), (2048, 1024, 8, 1, 0, 1), (33, 65, 17, 1, 1, 1)])
+def test_gemm_all_transposes(ops, M, N, K, ta, tb, ks):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    dA, dB = ops.t(A), ops.t(B)
+    C = torch.zeros((M, N), dtype=torch.float32, device=ops.dev)
+    ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 1 if ks > 1 else 0, ks, ops.s()))
+    assert _rel(C.cpu().numpy(), ref) < 1e-5
+    if ks == 1:      # accumulate
+        ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 1, 1, ops.s()))
+        assert _rel(C.cpu().numpy(), 2 * ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,C,act", [(1000, 32, 1), (48, 240, 1), (96, 24, 0), (4000, 96, 1)])
+def test_batchnorm_train_forward_backward(ops, M, C, act):
+    rng = np.random.default_rng(C)
+    Z = (rng.standard_normal((M, C)) * rng.uniform(0.2, 3, C) + rng.standard_normal(C)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, C).astype(np.float32), (0.1 * rng.standard_normal(C)).astype(np.float32)
+    dA = rng.standard_normal((M, C)).astype(np.float32)
+    z = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+    g, b = torch.tensor(gamma, dtype=torch.float64, requires_grad=True), torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    y = g * (z - mean) / torch.sqrt(var + 1e-3) + b
+    a = y * torch.sigmoid(y) if act == 1 else y
+    (a * torch.tensor(dA, dtype=torch.float64)).sum().backward()
+    dZ, dm, dv = ops.t(Z), torch.empty(C, device=ops.dev), torch.empty(C, device=ops.dev)
+    ops.check(ops.L.mkws_op_bn_stats(ops.p(dZ), M, C, ops.p(dm), ops.p(dv), ops.s()))
+    assert _rel(dm.cpu().numpy(), mean.detach().numpy()) < 1e-5 and _rel(dv.cpu().numpy(), var.detach().numpy()) < 1e-5
+    dg, db, A = ops.t(gamma), ops.t(beta), torch.empty((M, C), device=ops.dev)
+    ops.check(ops.L.mkws_op_bn_act_fwd(ops.p(dZ), ops.p(dm), ops.p(dv), ops.p(dg), ops.p(db), 1e-3, act, ops.p(A), M, C, ops.s()))
+    assert _rel(A.cpu().numpy(), a.detach().numpy()) < 1e-5
+    d, gg, gb, scr = ops.t(dA), torch.empty(C, device=ops.dev), torch.empty(C, device=ops.dev), torch.empty(2 * C, device=ops.dev)
+    ops.check(ops.L.mkws_op_bn_act_bwd(ops.p(dZ), ops.p(dm), ops.p(dv), ops.p(dg), ops.p(db), 1e-3, act, ops.p(d), ops.p(gg), ops.p(gb), ops.p(scr), M, C, ops.s()))
+    assert _rel(d.cpu().numpy(), z.grad.numpy()) < 2e-4
+    assert _rel(gg.cpu().numpy(), g.grad.numpy()) < 2e-4 and _rel(gb.cpu().numpy(), b.grad.numpy()) < 2e-4
+    mm, mv = ops.t(np.zeros(C)), ops.t(np.ones(C))
+    ops.check(ops.L.mkws_op_bn_update_moving(ops.p(mm), ops.p(mv), ops.p(dm), ops.p(dv), 0.99, M, C, ops.s()))
+    assert _rel(mm.cpu().numpy(), 0.01 * mean.detach().numpy()) < 1e-5
+    assert _rel(mv.cpu().numpy(), 0.99 + 0.01 * var.detach().numpy() * M / (M - 1)) < 1e-5
+
+
+@pytest.mark.parametrize("H,W,C,k,s", [(25, 20, 96, 3, 2), (13, 10, 144, 5, 2), (7, 5, 240, 5, 1), (4, 3, 480, 3, 1), (4, 3, 672, 5, 2), (2, 2, 1152, 5, 1)])
+def test_depthwise_forward_backward(ops, H, W, C, k, s):
+    from oracle.efficientnet_oracle import correct_pad
+    rng = np.random.default_rng(H * C)
+    B = 3
+    X = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    Wt = rng.standard_normal((k, k, C)).astype(np.float32)
+    if s == 2:
+        (pt, pb), (pl, pr) = correct_pad(H, W, k)
+    else:
+        pt = pb = pl = pr = k // 2
+    x = torch.tensor(X, dtype=torch.float64).permute(0, 3, 1, 2).requires_grad_(True)
+    w = torch.tensor(Wt, dtype=torch.float64).permute(2, 0, 1)[:, None].requires_grad_(True)
+    z = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, stride=s, groups=C)
+    Ho, Wo = z.shape[2], z.shape[3]
+    dZ = rng.standard_normal((B, Ho, Wo, C)).astype(np.float32)
+    (z * torch.tensor(dZ, dtype=torch.float64).permute(0, 3, 1, 2)).sum().backward()
+    dx, dw, dz, Z = ops.t(X), ops.t(Wt), ops.t(dZ), torch.empty((B, Ho, Wo, C), device=ops.dev)
+    ops.check(ops.L.mkws_op_dwconv_fwd(ops.p(dx), ops.p(dw), ops.p(Z), B, H, W, C, k, s, pt, pl, Ho, Wo, ops.s()))
+    assert _rel(Z.cpu().numpy(), z.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    gX, gW = torch.empty_like(dx), torch.empty_like(dw)
+    ops.check(ops.L.mkws_op_dwconv_bwd(ops.p(dx), ops.p(dw), ops.p(dz), ops.p(gX), ops.p(gW), B, H, W, C, k, s, pt, pl, Ho, Wo, ops.s()))
+    assert _rel(gX.cpu().numpy(), x.grad.permute(0, 2, 3, 1).numpy()) < 1e-5
+    assert _rel(gW.cpu().numpy(), w.grad[:, 0].permute(1, 2, 0).numpy()) < 1e-4
+
+
+def test_stem_se_and_elementwise_operators(ops):
+    rng = np.random.default_rng(0)
+    B = 4
+    spec = (rng.integers(0, 670, size=(B, 49, 40)) * (10 / 256)).astype(np.float32)
+    Wt = rng.standard_normal((3, 3, 1, 32)).astype(np.float32)
+    x = (torch.tensor(spec, dtype=torch.float64)[:, None] / 255.0 - 0.1) / 0.7
+    w = torch.tensor(Wt, dtype=torch.float64).permute(3, 2, 0, 1).requires_grad_(True)
+    z = F.conv2d(F.pad(x, (0, 1, 1, 1)), w, stride=2)
+    dZ = rng.standard_normal((B, 25, 20, 32)).astype(np.float32)
+    (z * torch.tensor(dZ, dtype=torch.float64).permute(0, 3, 1, 2)).sum().backward()
+    ds, dw, Z = ops.t(spec), ops.t(Wt), torch.empty((B, 25, 20, 32), device=ops.dev)
+    ops.check(ops.L.mkws_op_stem_fwd(ops.p(ds), ops.p(dw), 0.1, 0.7, ops.p(Z), B, ops.s()))
+    assert _rel(Z.cpu().numpy(), z.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    gW, ddZ = torch.empty((3, 3, 1, 32), device=ops.dev), ops.t(dZ)
+    ops.check(ops.L.mkws_op_stem_bwd_weight(ops.p(ds), ops.p(ddZ), 0.1, 0.7, ops.p(gW), B, ops.s()))
+    assert _rel(gW.cpu().numpy(), w.grad.permute(2, 3, 1, 0).numpy()) < 1e-4
+    # SE pieces
+    HW, C = 12, 80
+    A, g, dO = rng.standard_normal((B, HW, C)).astype(np.float32), rng.uniform(0, 1, (B, C)).astype(np.float32), rng.standard_normal((B, HW, C)).astype(np.float32)
+    dA_, dg_, dOut = ops.t(A), ops.t(g), ops.t(dO)
+    mean, out = torch.empty((B, C), device=ops.dev), torch.empty((B, HW, C), device=ops.dev)
+    ops.check(ops.L.mkws_op_pool_hw(ops.p(dA_), ops.p(mean), B, HW, C, ops.s()))
+    assert _rel(mean.cpu().numpy(), A.mean(1)) < 1e-6
+    ops.check(ops.L.mkws_op_scale_channels(ops.p(dA_), ops.p(dg_), ops.p(out), B, HW, C, ops.s()))
+    assert _rel(out.cpu().numpy(), A * g[:, None]) < 1e-6
+    gA, gg = torch.empty((B, HW, C), device=ops.dev), torch.empty((B, C), device=ops.dev)
+    ops.check(ops.L.mkws_op_se_bwd(ops.p(dA_), ops.p(dg_), ops.p(dOut), ops.p(gA), ops.p(gg), B, HW, C, ops.s()))
+    assert _rel(gA.cpu().numpy(), dO * g[:, None]) < 1e-6 and _rel(gg.cpu().numpy(), (dO * A).sum(1)) < 1e-5
+    ops.check(ops.L.mkws_op_add_bcast(ops.p(gA), ops.p(dg_), 0.25, B, HW, C, ops.s()))
+    assert _rel(gA.cpu().numpy(), dO * g[:, None] + 0.25 * g[:, None]) < 1e-6
+    # bias + activation and its backward, all four activations
+    M, N = 37, 50
+    Zb, bias, dAb = rng.standard_normal((M, N)).astype(np.float32), rng.standard_normal(N).astype(np.float32), rng.standard_normal((M, N)).astype(np.float32)
+    fns = {1: lambda y: y * torch.sigmoid(y), 2: torch.relu, 3: torch.selu, 4: torch.sigmoid}
+    for act, fn in fns.items():
+        zz = torch.tensor(Zb, dtype=torch.float64, requires_grad=True)
+        bb = torch.tensor(bias, dtype=torch.float64, requires_grad=True)
+        a = fn(zz + bb)
+        (a * torch.tensor(dAb, dtype=torch.float64)).sum().backward()
+        Ab, d, gb = torch.empty((M, N), device=ops.dev), ops.t(dAb), torch.empty(N, device=ops.dev)
+        dZb, dbias = ops.t(Zb), ops.t(bias)                 # (kept alive: a temporary's memory would be recycled under the kernel)
+        ops.check(ops.L.mkws_op_bias_act_fwd(ops.p(dZb), ops.p(dbias), act, ops.p(Ab), M, N, ops.s()))
+        assert _rel(Ab.cpu().numpy(), a.detach().numpy()) < 1e-6, act
+        ops.check(ops.L.mkws_op_bias_act_bwd(ops.p(dZb), ops.p(dbias), act, ops.p(d), ops.p(gb), M, N, ops.s()))
+        assert _rel(d.cpu().numpy(), zz.grad.numpy()) < 1e-5 and _rel(gb.cpu().numpy(), bb.grad.numpy()) < 1e-5, act
+    # drop-connect + residual, axpy, Adam
+    a, c, sc = ops.t(A), ops.t(dO), ops.t(np.array([0.0, 1.25, 1.25, 0.0]))
+    out = torch.empty((B, HW, C), device=ops.dev)
+    ops.check(ops.L.mkws_op_row_scale_add(ops.p(a), ops.p(sc), ops.p(c), ops.p(out), B, HW * C, ops.s()))
+    assert _rel(out.cpu().numpy(), A * np.array([0, 1.25, 1.25, 0], np.float32)[:, None, None] + dO) < 1e-6
+    ops.check(ops.L.mkws_op_axpy(ops.p(out), ops.p(a), -2.0, out.numel(), ops.s()))
+    assert _rel(out.cpu().numpy(), A * np.array([0, 1.25, 1.25, 0], np.float32)[:, None, None] + dO - 2 * A) < 1e-5
+    from oracle import head_oracle as ho
+    n = 1000
+    p0, gr = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    P, Gd, m, v = ops.t(p0), ops.t(gr), ops.t(np.zeros(n)), ops.t(np.zeros(n))
+    opt, pr = ho.KerasAdam(n, lr=1e-3), p0.astype(np.float64)
+    for t in range(1, 4):
+        ops.check(ops.L.mkws_op_adam(ops.p(P), ops.p(Gd), ops.p(m), ops.p(v), n, 1e-3, 0.9, 0.999, 1e-7, t, 0.5, ops.s()))
+        pr = opt.step(pr, 0.5 * gr.astype(np.float64))
+    assert np.abs(P.cpu().numpy() - pr).max() < 1e-6
+
+
+def test_training_mode_gradients_match_the_oracle():
+    """Every trainable tensor's gradient (d sum(emb . proj)) in training mode (batch statistics, drop-connect) against the
+    float64 autograd oracle; tolerance 1e-3 of the tensor's largest gradient."""
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding_trainer import EmbeddingTrainer
+    from oracle.efficientnet_train_oracle import TrainableEmbeddingOracle
+    blob = weights.synthetic_blob()
+    rng = np.random.default_rng(3)
+    B = 6
+    spec = (rng.integers(0, 670, size=(B, 49, 40)).astype(np.float32) * np.float32(10 / 256))
+    proj = rng.standard_normal(1024)
+    masks = {"2b": np.array([1, 1, 0, 1, 1, 1], bool), "4c": np.array([1, 0, 1, 1, 0, 1], bool), "6d": np.array([0, 1, 1, 1, 1, 1], bool)}
+    o = TrainableEmbeddingOracle(blob)
+    o.zero_grad()
+    ref_emb = o.forward(spec, training=True, drop_masks={k: torch.tensor(v) for k, v in masks.items()})
+    (ref_emb @ torch.from_numpy(proj)).sum().backward()
+    ref = o.grads()
+    tr = EmbeddingTrainer(blob)
+    emb = tr.forward_train(torch.from_numpy(spec).cuda(), masks)
+    assert _rel(emb.cpu().numpy(), ref_emb.detach().numpy()) < 1e-4
+    tr.backward(torch.from_numpy(np.tile(proj.astype(np.float32), (B, 1))).cuda())
+    got = tr.named_grads()
+    # A beta (or bias-like shift) that feeds a 1x1 conv followed by a batch-statistics BN has an exactly-zero gradient
+    # (block1a_project_bn/beta, ...): the oracle returns 1e-17 there, fp32 1e-9, so tensors are compared relative to
+    # their own largest gradient with an absolute floor of 1e-6 of the network's largest one.
+    gmax = max(float(np.abs(g).max()) for g in ref.values())
+    worst = {}
+    for name, g in ref.items():
+        err = float(np.abs(got[name].reshape(g.shape).astype(np.float64) - g).max())
+        worst[name] = err / max(float(np.abs(g).max()), 1e-3 * gmax)
+        assert err <= 1e-3 * float(np.abs(g).max()) + 1e-6 * gmax, (name, err, float(np.abs(g).max()), gmax)
+    assert len(worst) == len(o.trainable)
+    print("largest per-tensor gradient error (relative):", max(worst.values()), "over", len(worst), "tensors; gmax", gmax)
+    for name in ("normalization/mean", "stem_bn/moving_mean", "top_bn/moving_variance"):
+        assert not got[name].any()                                         # non-trainable: zero gradient
+    # moving statistics after the training-mode forward (momentum 0.99, Bessel-corrected variance)
+    newp = tr.blob()
+    for name, val in o.new_moving.items():
+        t = tr.tensors[name]
+        assert _rel(newp[t["offset"]:t["offset"] + t["count"]], val.detach().numpy()) < 1e-5, name
+    # one Adam step moves every trainable tensor by ~lr and leaves the rest alone
+    before = tr.blob()
+    tr.adam_step(lr=1e-3)
+    after = tr.blob()
+    t = tr.tensors["dense_2/kernel"]
+    d = np.abs(after - before)[t["offset"]:t["offset"] + t["count"]]
+    assert 0.5e-3 < d.max() < 1.01e-3
+    t = tr.tensors["block5a_bn/moving_mean"]
+    assert np.array_equal(after[t["offset"]:t["offset"] + t["count"]], before[t["offset"]:t["offset"] + t["count"]])
+
+
+def test_head_input_gradient():
+    from multilingual_kws_amd.head import Head
+    from oracle import head_oracle as ho
+    rng = np.random.default_rng(0)
+    p0 = ho.glorot_uniform_params(seed=4)
+    x = (rng.standard_normal((40, 1024)) * 0.3).astype(np.float32)
+    y = rng.integers(0, 3, 40)
+    hd = Head(params=p0, max_batch=64)
+    hd.loss_grad(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda())
+    dx = hd.input_grad(40).cpu().numpy()
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    W1, b1, W2, b2 = [torch.tensor(a, dtype=torch.float64) for a in ho.unpack(p0, 1024, 18, 3)]
+    z = torch.tanh(xt @ W1 + b1) @ W2 + b2
+    F.cross_entropy(z, torch.from_numpy(y)).backward()
+    assert _rel(dx, xt.grad.numpy()) < 1e-4
+    hd.adam_step(lr=1e-3)
+    hd.reset_optimizer()
+    assert hd.step_t == 0 and not hd.grad_view().any()
+
+
+def test_transfer_learn_with_backprop_into_embedding(tmp_path):
+    """The reference's two-phase call: frozen-embedding fit, then everything un-frozen with Adam(embedding_lr)."""
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+    data = make_fewshot_dataset(str(tmp_path / "d"))
+    ms = input_data.standard_microspeech_model_settings(3)
+    name, model, details = tl.transfer_learn(
+        target="target", train_files=data["train"], val_files=data["val"], unknown_files=data["unknown"],
+        num_epochs=2, num_batches=1, batch_size=16, primary_lr=0.001, backprop_into_embedding=True, embedding_lr=0.0001,
+        model_settings=ms, base_model_path="synthetic", base_model_output="dense_2", UNKNOWN_PERCENTAGE=50.0,
+        bg_datadir=data["bg_dir"], csvlog_dest=None, verbose=0, seed=5)
+    assert set(details) == {"num_epochs", "batch_size", "num_batches", "val_accuracy", "target"}
+    assert name == f"xfer_epochs_2_bs_16_nbs_1_val_acc_{details['val_accuracy']:0.2f}_target_target"
+    h = model.history
+    assert all(len(h[k]) == 2 and np.isfinite(h[k]).all() for k in ("loss", "accuracy", "val_loss", "val_accuracy"))
+    # the embedding really moved: kernels by Adam, BatchNorm moving statistics by the training-mode forwards
+    base = weights.synthetic_blob()
+    tuned = model._blob
+    T = {t["name"]: t for t in weights.manifest()}
+    for nme in ("stem_conv/kernel", "block3a_dwconv/depthwise_kernel", "block6b_se_reduce/bias", "top_bn/gamma", "dense_2/kernel", "block2a_bn/moving_mean"):
+        t = T[nme]
+        assert not np.array_equal(tuned[t["offset"]:t["offset"] + t["count"]], base[t["offset"]:t["offset"] + t["count"]]), nme
+    assert np.isfinite(tuned).all()
+    # returned model: inference kernels on the fine-tuned weights == the inference oracle on the same weights
+    from oracle import head_oracle as ho
+    from oracle.efficientnet_oracle import EmbeddingOracle
+    specs = np.stack([input_data.file2spec(ms, f) for f in data["val"]])
+    preds = model.predict(specs[..., None])
+    ref_probs, _ = ho.forward(model.head.get_params(), EmbeddingOracle(tuned).forward(specs).numpy())
+    assert np.abs(preds - ref_probs).max() < 1e-3 and np.array_equal(preds.argmax(1), ref_probs.argmax(1))
+    model.save(str(tmp_path / "m"))
+    again = tl.TransferLearnedModel.load(str(tmp_path / "m"), max_batch=64)
+    assert np.array_equal(again.predict(specs[..., None]), preds)
+
+
+def test_bucketed_gradient_allreduce_over_rccl():
+    """backward(allreduce=True) in a 1-rank "nccl" (= RCCL) group: three contiguous ranges of the flat gradient buffer
+    (dense_1.., top_conv..dense_1, 0..top_conv) are all-reduced as they become final and cover the buffer exactly once."""
+    import socket
+    import torch.distributed as dist
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding_trainer import EmbeddingTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(1)
+        spec = torch.from_numpy(rng.integers(0, 670, size=(4, 49, 40)).astype(np.float32) * np.float32(10 / 256)).cuda()
+        d_emb = torch.from_numpy(rng.standard_normal((4, 1024)).astype(np.float32)).cuda()
+        tr = EmbeddingTrainer(weights.synthetic_blob())
+        tr.forward_train(spec)
+        tr.backward(d_emb)
+        plain = tr.grads.clone()
+        spans, real = [], dist.all_reduce
+        tr2 = EmbeddingTrainer(weights.synthetic_blob())
+        tr2.forward_train(spec)
+        real_ptr = tr2.grads.data_ptr()
+
+        def counting2(t, *a, **k):
+            lo = (t.data_ptr() - real_ptr) // 4
+            spans.append((lo, lo + t.numel()))
+            return real(t, *a, **k)
+        dist.all_reduce = counting2
+        tr2.backward(d_emb, allreduce=True)
+        dist.all_reduce = real
+        assert len(spans) == 3
+        spans.sort()
+        assert spans[0][0] == 0 and spans[-1][1] == tr2.grads.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        # atomics make gradients order-dependent in the last bits: equal within fp32 round-off, not bit for bit
+        assert float((tr2.grads - plain).abs().max() / plain.abs().max()) < 1e-5
+    finally:
+        dist.destroy_process_group()
