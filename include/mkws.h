@@ -145,23 +145,15 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
 /* Execution options (A/B switches for measurement; results are equal up to fp32 rounding):
  *   "fuse_front" (default 1): expand 1x1 conv + depthwise conv in one kernel (expanded tensor stays in LDS);
  *                 0 = separate GEMM and depthwise kernels.
- *   "gemm_lds" (default 0): 0 = 1x1-conv / dense layers use the direct-to-register MFMA kernel; 1 = a planner may
- *                 pick the LDS-staged GEMM kernel (operands shared by the block's waves, full-line activation
- *                 loads; measured slower on MI355X for these shapes); 100+i forces LDS configuration i.
- *   "fuse_se" (default 0): 1 = the partial sums of the SE reduce FC are produced by the depthwise kernels
- *                 themselves (one SE launch per block instead of two; measured slower on MI355X).
  *   "fuse_block" (default 2 for handles with max_batch >= 384, else 0): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
  *                 ONE kernel, 4 clips per workgroup, activations resident in LDS; 1 = only the 2x2 blocks
  *                 (6b..7a); 0 = the multi-kernel path everywhere.
  *   "fuse_mid" (default 1 for handles with max_batch >= 384, else 0): blocks with big images run expand -> depthwise -> SE ->
  *                 project as ONE kernel per block (depthwise output of all channels resident in LDS): 1 = blocks 3a and 4a
  *                 (where it measured faster than the three-kernel path), 2 = all of 2a..4a, 0 = never.
- *   "proj_stream" (default 0): 1 = gated projection convs of the big-image blocks (2a..4a) use the streaming
- *                 kernel (activations cross HBM once, packed weights in LDS; measured equal on MI355X);
- *                 0 = the generic GEMM kernel.
  *   "fuse_gap" (default 1): global average pool fused into the top conv epilogue (its [B*4,1280] output is never stored).
- *   "fuse_stem" (default 2): 2 = stem conv + the whole of block 1a in one kernel (one clip per workgroup, both
- *                 25x20x32 activations stay in LDS); 1 = stem conv + block-1a depthwise; 0 = separate kernels. */
+ *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (one clip per workgroup, both 25x20x32
+ *                 activations stay in LDS); 0 = separate kernels. */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
 
 /* Measurement aid (NOT capturable: it records a hipEvent pair around every kernel launch and

@@ -95,102 +95,6 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ spe
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused stem + block-1a depthwise: spectrogram [49,40] -> (Rescaling, Normalization, pad, 3x3 s2 conv, BN,
-// swish) -> LDS [25x20x32 with a zero halo] -> depthwise 3x3 "same" + BN + swish -> Y [B,25,20,32] + SE sums.
-// One workgroup per clip; the 64 KB stem output never goes to HBM; halos make every tap unconditional.
-__global__ __launch_bounds__(256) void stem_dw_kernel(const float* __restrict__ spec, const float* __restrict__ w /*[9][32]*/,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift, float norm_mean,
-                                                      float norm_std, const float* __restrict__ Wd /*[9][32]*/, const float* __restrict__ scD,
-                                                      const float* __restrict__ shD, float* __restrict__ Y, float* __restrict__ sums,
-                                                      const float* __restrict__ Wr, int se, float* __restrict__ separt, int Btot) {
-  constexpr int H = kInH, W = kInW, Ho = 25, Wo = 20, C = 32;
-  constexpr int TH = H + 2, TW = W + 1;                 // input tile with halo: rows -1..49, cols 0..40
-  constexpr int EH = Ho + 2, EW = Wo + 2;               // stem-output tile with a 1-pixel zero halo
-  extern __shared__ __attribute__((aligned(16))) float s_sd[];
-  float* s_in = s_sd;                                   // [TH][TW]
-  float* s_E = s_in + ((TH * TW + 3) & ~3);             // [EH][EW][C]
-  f32x4* s_red = reinterpret_cast<f32x4*>(s_E + EH * EW * C);   // [256]
-  const int tid = threadIdx.x;
-  const size_t b = blockIdx.x;
-  const float* img = spec + b * H * W;
-  for (int i = tid; i < TH * TW; i += 256) {
-    const int r = i / TW - 1, cc = i % TW;
-    float v = 0.0f;
-    if (r >= 0 && r < H && cc < W) v = __fdiv_rn(img[r * W + cc] * (1.0f / 255.0f) - norm_mean, norm_std);
-    s_in[i] = v;
-  }
-  for (int i = tid; i < EH * EW * C / 4; i += 256) {     // zero the halo (interior is overwritten below)
-    const int pix = i / (C / 4);
-    const int r = pix / EW, cc = pix % EW;
-    if (r == 0 || r == EH - 1 || cc == 0 || cc == EW - 1) reinterpret_cast<f32x4*>(s_E)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  const int q = tid & 7;                                 // channel quad of this thread (256 % 8 == 0: fixed)
-  {
-    f32x4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(w + t * C + q * 4);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
-    for (int pix = tid >> 3; pix < Ho * Wo; pix += 32) {
-      const int oh = pix / Wo, ow = pix % Wo;
-      const float* in0 = s_in + (2 * oh) * TW + 2 * ow;   // tile row 2*oh == image row 2*oh - 1
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc += wk[i * 3 + j] * in0[i * TW + j];
-      f32x4 y = acc * sc + sh;
-      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
-      *reinterpret_cast<f32x4*>(s_E + ((size_t)(oh + 1) * EW + (ow + 1)) * C + q * 4) = y;
-    }
-  }
-  __syncthreads();
-  f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
-  {
-    f32x4 wk[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const f32x4*>(Wd + t * C + q * 4);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scD + q * 4);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shD + q * 4);
-    float* yout = Y + b * Ho * Wo * C + q * 4;
-    for (int pix = tid >> 3; pix < Ho * Wo; pix += 32) {
-      const int oh = pix / Wo, ow = pix % Wo;
-      const float* e0 = s_E + ((size_t)oh * EW + ow) * C + q * 4;     // top-left tap (halo offset cancels the -1)
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc += *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + j) * C) * wk[i * 3 + j];
-      f32x4 y = acc * sc + sh;
-      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
-      *reinterpret_cast<f32x4*>(yout + (size_t)pix * C) = y;
-      ssum += y;
-    }
-  }
-  s_red[tid] = ssum;
-  __syncthreads();
-  float* s_sumc = s_in;                                  // input tile is dead by now: reuse for the 32 channel sums
-  if (tid < 8) {
-    f32x4 t = s_red[tid];
-    for (int k = 1; k < 32; ++k) t += s_red[k * 8 + tid];
-    *reinterpret_cast<f32x4*>(sums + b * C + tid * 4) = t;
-    *reinterpret_cast<f32x4*>(s_sumc + tid * 4) = t;
-  }
-  __syncthreads();
-  if (separt && tid < 48) {                              // SE reduce-FC partial (the only chunk of block 1a)
-    float v = 0.0f;
-    if (tid < se)
-    {
-#pragma unroll 32
-      for (int cc = 0; cc < C; ++cc) v += s_sumc[cc] * (1.0f / (Ho * Wo)) * Wr[cc * se + tid];
-    }
-    separt[b * 48 + tid] = v;
-  }
-  (void)Btot;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Stem + the whole of block 1a (no expand conv: depthwise 3x3 -> SE -> gated 32->16 projection) for one clip
 // per workgroup.  Spectrogram [49,40] in, block-1a output [25,20,16] out; the 64 KB stem output and the 64 KB
 // depthwise output stay in LDS, so the network's two largest activations never reach HBM.
@@ -519,289 +423,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Gated projection conv of the big-image MBConv blocks (1a .. 4a): K = Cexp <= 240, N = Cout <= 80, M = B*H*W
-// up to 512 000.  The activation matrix is the only large operand, so it must cross HBM exactly once:
-//   * the whole packed weight matrix (<= 75 KB) is staged in LDS once per workgroup;
-//   * a wave owns ALL n-tiles of its rows (pw_gemm_kernel splits N over waves and re-reads X per split);
-//   * waves grid-stride over groups of MT row tiles; the (group, K chunk) sequence is flattened into one
-//     stream with a D-deep register ring (X and SE-gate fragments), so the next group's first chunks are in
-//     flight while this group finishes -- K is only 2..15 chunks, a per-group prologue would dominate;
-//   * residual rows ride the same stream (requested D chunks into their group, consumed at its epilogue),
-//     so the epilogue issues no loads and the ring never drains.
-// Same accumulation order per output row as pw_gemm_kernel (K chunks ascending): results are bit-identical.
-template <int NT, int MT>
-__global__ __launch_bounds__(512) void pw_proj_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_pw[];
-  constexpr int NWAVES = 8, D = 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  const int KC = a.KC;
-  float* s_sc = s_pw + (size_t)KC * NT * 256;                  // [NT*16] scale, [NT*16] shift
-  float* s_sh = s_sc + NT * 16;
-  for (int i = tid; i < KC * NT * 64; i += NWAVES * 64)
-    reinterpret_cast<f32x4*>(s_pw)[i] = reinterpret_cast<const f32x4*>(a.Wp)[i];
-  if (tid < NT * 16) { s_sc[tid] = a.scale[tid]; s_sh[tid] = a.shift[tid]; }
-  __syncthreads();
-
-  const int ngroups = (a.M + 16 * MT - 1) / (16 * MT);
-  const int wid = blockIdx.x * NWAVES + wave, nw = gridDim.x * NWAVES;
-  const int nmy = (ngroups > wid) ? (ngroups - wid + nw - 1) / nw : 0;
-  const int T = nmy * KC;
-  if (T == 0) return;
-  const bool hasR = a.R != nullptr;
-
-  struct Slot { f32x4 x[MT], gt[MT]; };
-  Slot ring[D];
-  f32x4 rq[MT][NT];                                            // residual fragments of the group being computed
-  // load cursor
-  int lgi = 0, lj = 0;
-  const float* xp[MT]; const float* gp[MT]; const float* rp[MT];
-  auto set_ptrs = [&](int gi) {
-    int grp = wid + nw * gi;
-    if (grp >= ngroups) grp = ngroups - 1;                     // past the end: harmless re-read, never consumed
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      int row = (grp * MT + m) * 16 + c;
-      if (row >= a.M) row = a.M - 1;
-      xp[m] = a.X + (size_t)row * a.ldx + 4 * g;
-      gp[m] = a.gate + (size_t)(row / a.HW) * a.K + 4 * g;
-      rp[m] = hasR ? a.R + (size_t)row * a.ldr + 4 * g : nullptr;
-    }
-  };
-  set_ptrs(0);
-  const int jr = (KC > D) ? D : KC - 1;                        // chunk at which a group's residual rows are requested
-  auto load = [&](Slot& sl) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      sl.x[m] = *reinterpret_cast<const f32x4*>(xp[m] + 16 * lj);
-      sl.gt[m] = *reinterpret_cast<const f32x4*>(gp[m] + 16 * lj);
-    }
-    if (hasR && lj == jr && KC > D) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) rq[m][nt] = *reinterpret_cast<const f32x4*>(rp[m] + (nt * 16 < a.N ? nt * 16 : 0));
-    }
-    if (++lj == KC) { lj = 0; ++lgi; set_ptrs(lgi); }
-  };
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int cgi = 0, cj = 0;
-  auto compute = [&](const Slot& sl) {
-    f32x4 w[NT], xv[MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const f32x4*>(s_pw + (((size_t)cj * NT + nt) * 4 + g) * 64 + c * 4);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) xv[m] = sl.x[m] * sl.gt[m];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt][s], xv[m][s], acc[m][nt], 0, 0, 0);
-    if (++cj == KC) {
-      const int grp = wid + nw * cgi;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int row = (grp * MT + m) * 16 + c;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int n = nt * 16 + 4 * g;
-          f32x4 y = acc[m][nt] * *reinterpret_cast<const f32x4*>(s_sc + n) + *reinterpret_cast<const f32x4*>(s_sh + n);
-          if (hasR) {
-            if (KC > D) y += rq[m][nt];
-            else if (row < a.M && n < a.N) y += *reinterpret_cast<const f32x4*>(a.R + (size_t)row * a.ldr + n);
-          }
-          if (row < a.M && n < a.N) *reinterpret_cast<f32x4*>(a.Y + (size_t)row * a.ldy + n) = y;
-          acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      cj = 0; ++cgi;
-    }
-  };
-  if (T >= D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) load(ring[d]);
-    int it = 0;
-    for (; it + 2 * D <= T; it += D) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        compute(ring[d]);
-        load(ring[d]);
-        __builtin_amdgcn_sched_barrier(0);     // keep the reload behind its slot's MFMAs (see pw_gemm_kernel)
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      compute(ring[d]);
-      if (it + D + d < T) load(ring[d]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    it += D;
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (it + d < T) compute(ring[d]);
-  } else {
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (d < T) { load(ring[d]); compute(ring[d]); }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-staged variant of the 1x1-conv / dense GEMM (same math, same packed weights, same epilogue).
-// pw_gemm_kernel fetches every operand fragment straight into registers; that path is bounded by the
-// vector L1: an X fragment load touches 16 cache lines for 1 KB, and the waves of a block re-fetch
-// operands they share.  Here a block of WM x WN waves stages a (BM rows x 32 k) X tile and the matching
-// weight fragments in LDS once per 32-k stage:
-//   * X is read from global with 8 lanes per row = whole 128-byte lines, gated (SE) on the way, and written
-//     to LDS in MFMA-fragment order, so every wave then pulls its fragments with lane-linear ds_read_b128;
-//   * weights are already fragment-ordered in global (pack_gemm) and are copied as they are;
-//   * two LDS buffers, one __syncthreads per stage, next stage's global loads in flight during the MFMAs.
-template <int WM, int WN, int MT, int NT, bool GATE>
-__global__ __launch_bounds__(256) void pw_gemm_lds_kernel(GemmArgs a) {
-  static_assert(WM * WN == 4, "4 waves per block");
-  constexpr int BMT = WM * MT;             // m-tiles per block
-  constexpr int BM = BMT * 16;             // rows per block
-  constexpr int BNT = WN * NT;             // n-tiles per block
-  constexpr int XF4 = BM * 8 / 256;        // float4 per thread per stage for X
-  constexpr int WF4 = (2 * BNT * 64 + 255) / 256;   // float4 per thread per stage for W
-  extern __shared__ __attribute__((aligned(16))) float s_g[];
-  float* s_X = s_g;                               // [2 buffers][2 chunks][BMT][64][4]
-  float* s_W = s_g + 2 * 2 * BMT * 256;           // [2 buffers][2 chunks][BNT][64][4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM;
-  const int nt0 = blockIdx.y * BNT;
-  // K range (in 32-k stages) of this block
-  const int nstages_all = (a.KC + 1) / 2;
-  int sbeg = 0, send = nstages_all;
-  if (a.splitk > 1) {
-    const int per = (nstages_all + a.splitk - 1) / a.splitk;
-    sbeg = blockIdx.z * per;
-    send = (sbeg + per < nstages_all) ? sbeg + per : nstages_all;
-  }
-  // staging assignments
-  const float* xsrc[XF4]; const float* gsrc[XF4]; int xdst[XF4]; int xk[XF4];
-#pragma unroll
-  for (int i = 0; i < XF4; ++i) {
-    const int idx = tid + 256 * i;
-    const int row = idx >> 3, part = idx & 7;
-    int m = m0 + row; if (m >= a.M) m = a.M - 1;
-    xsrc[i] = a.X + (size_t)m * a.ldx + 4 * part;
-    gsrc[i] = GATE ? (a.gate + (size_t)(m / a.HW) * a.K + 4 * part) : nullptr;
-    xk[i] = 4 * part;
-    xdst[i] = (((part >> 2) * BMT + (row >> 4)) * 64 + (part & 3) * 16 + (row & 15)) * 4;
-  }
-  f32x4 xr[XF4], wr[WF4];
-  auto gload = [&](int st) {
-    const int kb = 32 * st;
-#pragma unroll
-    for (int i = 0; i < XF4; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kb + xk[i] < a.K) {
-        v = *reinterpret_cast<const f32x4*>(xsrc[i] + kb);
-        if (GATE) v *= *reinterpret_cast<const f32x4*>(gsrc[i] + kb);
-      }
-      xr[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < WF4; ++i) {
-      const int idx = tid + 256 * i;              // (chunk jl, tile t, lane l)
-      const int jl = idx / (BNT * 64), rem = idx - jl * (BNT * 64);
-      int t = nt0 + rem / 64; if (t >= a.NTtot) t = a.NTtot - 1;
-      const int j = 2 * st + jl;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < 2 * BNT * 64 && j < a.KC) v = *reinterpret_cast<const f32x4*>(a.Wp + ((size_t)j * a.NTtot + t) * 256 + (rem & 63) * 4);
-      wr[i] = v;
-    }
-  };
-  auto lstore = [&](int buf) {
-    float* xs = s_X + buf * (2 * BMT * 256);
-    float* ws = s_W + buf * (2 * BNT * 256);
-#pragma unroll
-    for (int i = 0; i < XF4; ++i) *reinterpret_cast<f32x4*>(xs + xdst[i]) = xr[i];
-#pragma unroll
-    for (int i = 0; i < WF4; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < 2 * BNT * 64) *reinterpret_cast<f32x4*>(ws + (size_t)idx * 4) = wr[i];
-    }
-  };
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (sbeg < send) {
-    gload(sbeg);
-    lstore(0);
-    __syncthreads();
-    for (int st = sbeg; st < send; ++st) {
-      const int buf = (st - sbeg) & 1;
-      if (st + 1 < send) gload(st + 1);
-      const float* xs = s_X + buf * (2 * BMT * 256);
-      const float* ws = s_W + buf * (2 * BNT * 256);
-#pragma unroll
-      for (int jl = 0; jl < 2; ++jl) {
-        f32x4 xf[MT], wf[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f32x4*>(xs + ((jl * BMT + wm * MT + mt) * 64 + lane) * 4);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4*>(ws + ((jl * BNT + wn * NT + nt) * 64 + lane) * 4);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s4], xf[mt][s4], acc[mt][nt], 0, 0, 0);
-      }
-      if (st + 1 < send) lstore(buf ^ 1);
-      __syncthreads();
-    }
-  }
-  // epilogue (identical to pw_gemm_kernel's): lane (g, c) holds rows m, channels n .. n+3
-  const int mw = m0 + wm * MT * 16;
-  const int ntw = nt0 + wn * NT;
-  if (a.splitk > 1) {
-    float* P = a.part + (size_t)blockIdx.z * a.M * a.ldp;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = (ntw + nt) * 16 + 4 * g;
-      if (n >= a.N) continue;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m = mw + mt * 16 + c;
-        if (m < a.M) *reinterpret_cast<f32x4*>(P + (size_t)m * a.ldp + n) = acc[mt][nt];
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = (ntw + nt) * 16 + 4 * g;
-    if (n >= a.N) continue;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const size_t m = (size_t)(mw + mt * 16 + c);
-      if (m >= (size_t)a.M) continue;
-      f32x4 y = acc[mt][nt] * sc + sh;
-      if (a.act != ACT_NONE) {
-        y.x = apply_act(y.x, a.act); y.y = apply_act(y.y, a.act); y.z = apply_act(y.z, a.act); y.w = apply_act(y.w, a.act);
-      }
-      if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
-      *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = y;
-    }
-  }
-}
-
 // split-K epilogue: Y = act(sum_z part[z] * scale + shift) + R, one float4 per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splitk, int M, int N, int ldp,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, int act,
@@ -885,8 +506,6 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X, co
 //            a time, SE sums reduced through LDS;  otherwise (tiny images): thread = (clip, channel quad)
 //            walks all output pixels itself and owns its SE sums.
 struct FrontArgs {
-  // fused SE squeeze -> reduce-FC partials: separt[chunk][clip][48] = sum_{c in chunk} mean[clip][c] * Wr[c][n]
-  const float* Wr; int se; float* separt; float inv_hw;
   const float* X; int Cin;
   const float* WpE; const float* scE; const float* shE; int KC; int NTtotE;
   const float* Wd; const float* scD; const float* shD;
@@ -1168,27 +787,6 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
         *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = t;
       }
     }
-    if (a.separt) {
-      __syncthreads();
-      const int nc = nt_valid * 16;
-      for (int o = tid; o < gvalid * 48; o += NTHREADS) {
-        const int gi = o / 48, n = o - gi * 48;
-        float v = 0.0f;
-        if (n < a.se) {
-          const float* wr = a.Wr + (size_t)ch0 * a.se + n;
-          float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-#pragma unroll 8
-          for (int cc = 0; cc < nc; cc += 4) {
-            v0 += s_sumc[gi * CC + cc] * wr[(size_t)cc * a.se];
-            v1 += s_sumc[gi * CC + cc + 1] * wr[(size_t)(cc + 1) * a.se];
-            v2 += s_sumc[gi * CC + cc + 2] * wr[(size_t)(cc + 2) * a.se];
-            v3 += s_sumc[gi * CC + cc + 3] * wr[(size_t)(cc + 3) * a.se];
-          }
-          v = ((v0 + v1) + (v2 + v3)) * a.inv_hw;
-        }
-        a.separt[((size_t)blockIdx.y * a.B + (b0 + gi)) * 48 + n] = v;
-      }
-    }
   } else {
     // image size is a template constant here: the tap loops unroll completely and taps that fall outside
     // the 4x3 / 2x2 image disappear at compile time (most of a 5x5 kernel does)
@@ -1244,27 +842,6 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
       }
       *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + cq) = ssum;
       *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = ssum;
-    }
-    if (a.separt) {
-      __syncthreads();
-      const int nc = nt_valid * 16;
-      for (int o = tid; o < gvalid * 48; o += NTHREADS) {
-        const int gi = o / 48, n = o - gi * 48;
-        float v = 0.0f;
-        if (n < a.se) {
-          const float* wr = a.Wr + (size_t)ch0 * a.se + n;
-          float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-#pragma unroll 8
-          for (int cc = 0; cc < nc; cc += 4) {       // nc is a multiple of 16; 4 independent chains, 32 loads in flight
-            v0 += s_sumc[gi * CC + cc] * wr[(size_t)cc * a.se];
-            v1 += s_sumc[gi * CC + cc + 1] * wr[(size_t)(cc + 1) * a.se];
-            v2 += s_sumc[gi * CC + cc + 2] * wr[(size_t)(cc + 2) * a.se];
-            v3 += s_sumc[gi * CC + cc + 3] * wr[(size_t)(cc + 3) * a.se];
-          }
-          v = ((v0 + v1) + (v2 + v3)) * a.inv_hw;
-        }
-        a.separt[((size_t)blockIdx.y * a.B + (b0 + gi)) * 48 + n] = v;
-      }
     }
   }
 #ifdef MKWS_FRONT_TIMING
@@ -2197,8 +1774,7 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict_
     dst[t] = (s_part[t] + s_part[NTR * 256 + t]) + (s_part[2 * NTR * 256 + t] + s_part[3 * NTR * 256 + t]);
 }
 
-// PARTS_BY_CLIP: partials come from the producing kernels (mbconv_front / stem_dw) as [chunk][clip][48]
-template <int NTR, bool PARTS_BY_CLIP = false>
+template <int NTR>
 __global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict__ part, int nslices, const float* __restrict__ br,
                                                         const float* __restrict__ WeP, const float* __restrict__ be,
                                                         float* __restrict__ gate, int B, int C, int se, int NTe, int nsplit) {
@@ -2211,12 +1787,7 @@ __global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict_
     const int n = t >> 4, clip = t & 15;
     float v = 0.0f;
     if (n < se) {
-      if (PARTS_BY_CLIP) {
-        if (b0 + clip < B)
-          for (int z = 0; z < nslices; ++z) v += part[((size_t)z * B + (b0 + clip)) * 48 + n];
-      } else {
-        for (int z = 0; z < nslices; ++z) v += part[((size_t)z * gridDim.x + blockIdx.x) * NTR * 256 + t];
-      }
+      for (int z = 0; z < nslices; ++z) v += part[((size_t)z * gridDim.x + blockIdx.x) * NTR * 256 + t];
       v = swishf_(v + br[n]);
     }
     s_r[clip * LDR + n] = v;
@@ -2313,11 +1884,7 @@ struct mkws_embed {
   float norm_mean = 0.f, norm_std = 1.f;
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
   int fuse_gap = 1;                // global average pool fused into the top conv's epilogue (2x2 image: 4 rows per clip)
-  int proj_stream = 0;             // gated projection convs of blocks 2a..4a: 1 = pw_proj_kernel (X streamed once, weights in LDS; measured equal), 0 = pw_gemm_kernel
-  int gemm_lds = 0;                // 1x1-conv/dense GEMM: 0 = direct-to-register kernel (faster on MI355X, profiles/r01_notes.md), 1 = planner may pick the LDS-staged kernel
-  bool fuse_se = false;            // SE squeeze -> reduce-FC partials inside the producing kernel (saves the se_reduce launch, but the
-                                   // serial tails cost more than the launch on MI355X: 624k vs 643k clips/s; kept for A/B)
-  int fuse_stem = 2;               // 2: stem + whole block 1a in one kernel (stem_block1a_kernel); 1: stem + block-1a depthwise (stem_dw_kernel); 0: separate
+  int fuse_stem = 1;               // 1: stem + whole block 1a in one kernel (stem_block1a_kernel); 0: separate kernels (parity taps)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 3a and 4a (where it measured faster), 2 = 2a..4a, 0 = never
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   BlockPlan blocks[kNumBlocks];
@@ -2472,63 +2039,6 @@ TileChoice pick_tile(int M, int NTtot, int KC) {
   return {1, 2, 1};
 }
 
-// LDS-staged kernel configurations (WM, WN, MT, NT) -> block tile (WM*MT*16) x (WN*NT*16)
-struct LdsCfg { int id, WM, WN, MT, NT; };
-static const LdsCfg kLdsCfgs[] = {
-    {0, 4, 1, 1, 5},   //  64 x  80
-    {1, 4, 1, 1, 7},   //  64 x 112
-    {2, 2, 2, 2, 3},   //  64 x  96
-    {3, 2, 2, 2, 4},   //  64 x 128
-    {4, 2, 2, 4, 4},   // 128 x 128
-    {5, 4, 1, 2, 5},   // 128 x  80
-    {6, 4, 1, 2, 7},   // 128 x 112
-    {7, 1, 4, 4, 3},   //  64 x 192
-};
-constexpr int kNumLdsCfgs = sizeof(kLdsCfgs) / sizeof(kLdsCfgs[0]);
-static thread_local int g_proj_stream = 0;        // gated projections through pw_proj_kernel (option proj_stream)
-static thread_local int g_gemm_lds_mode = 0;      // 0: never, 1: planner decides, >= 100: force config (mode - 100)
-
-template <bool GATE>
-void launch_gemm_lds(int id, dim3 grid, size_t lds, hipStream_t s, const GemmArgs& a) {
-#define MKWS_L(WM, WN, MT, NT) hipLaunchKernelGGL((pw_gemm_lds_kernel<WM, WN, MT, NT, GATE>), grid, dim3(256), lds, s, a)
-  switch (id) {
-    case 0: MKWS_L(4, 1, 1, 5); break;
-    case 1: MKWS_L(4, 1, 1, 7); break;
-    case 2: MKWS_L(2, 2, 2, 3); break;
-    case 3: MKWS_L(2, 2, 2, 4); break;
-    case 4: MKWS_L(2, 2, 4, 4); break;
-    case 5: MKWS_L(4, 1, 2, 5); break;
-    case 6: MKWS_L(4, 1, 2, 7); break;
-    default: MKWS_L(1, 4, 4, 3); break;
-  }
-#undef MKWS_L
-}
-
-// Picks an LDS config for a layer (or -1 to use the direct kernel): the narrowest block that covers N with
-// little padding, row tile sized so the grid still has >= 512 blocks when possible; split-K for long K.
-int pick_lds(int M, int NTtot, int KC, int* splitk) {
-  *splitk = 1;
-  if (NTtot < 4 || KC < 4) return -1;
-  int best = -1; double best_cost = 1e30; int best_sk = 1;
-  for (int i = 0; i < kNumLdsCfgs; ++i) {
-    const LdsCfg& c = kLdsCfgs[i];
-    const int bnt = c.WN * c.NT, bm = c.WM * c.MT * 16;
-    const long nb = (NTtot + bnt - 1) / bnt, mb = (M + bm - 1) / bm;
-    const double pad = (double)(nb * bnt) / NTtot;
-    for (int sk = 1; sk <= 4; sk *= 2) {
-      if (sk > 1 && KC / (2 * sk) < 4) break;
-      const long blocks = nb * mb * sk;
-      // cost ~ padded work / parallel efficiency; prefer >= 512 blocks, mild penalty for split-K and tiny wave tiles
-      const double par = blocks >= 512 ? 1.0 : (double)blocks / 512.0;
-      const double tile_eff = (c.MT * c.NT >= 8) ? 1.0 : (c.MT * c.NT >= 5 ? 0.9 : 0.75);
-      const double cost = pad / (par * tile_eff) * (sk == 1 ? 1.0 : (sk == 2 ? 1.1 : 1.2));
-      if (cost < best_cost) { best_cost = cost; best = i; best_sk = sk; }
-    }
-  }
-  *splitk = best_sk;
-  return best;
-}
-
 void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const float* X, int ldx, int M, int Mplan, int act, const float* gate, int HW,
                  const float* R, int ldr, float* Y, int ldy, int pool4 = 0) {
   GemmArgs a;
@@ -2540,53 +2050,6 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
   if (const char* f = getenv("MKWS_GEMM_FORCE")) {       // experiment hook: "Mmax,MT,NT,SK" applies to layers with Mplan <= Mmax
     int mmax = 0, fmt = 0, fnt = 0, fsk = 0;
     if (sscanf(f, "%d,%d,%d,%d", &mmax, &fmt, &fnt, &fsk) == 4 && Mplan <= mmax && fnt <= L.NTtot) tc = {fmt, fnt, fsk};
-  }
-  // gated projection of a big-image block: stream X once, weights in LDS (pw_proj_kernel)
-  if (g_proj_stream && gate && L.NTtot <= 5 && (L.K & 15) == 0 && (size_t)L.KC * L.NTtot * 1024 <= 80 * 1024) {
-    const int groups2 = (Mplan + 31) / 32;
-    const int MT = (groups2 >= 2048) ? 2 : 1;                  // planned on max_batch: same choice for every batch size
-    const int ngroups = (M + 16 * MT - 1) / (16 * MT);
-    const size_t lds = ((size_t)L.KC * L.NTtot * 256 + 2 * L.NTtot * 16) * sizeof(float);
-    int per_cu = (int)((150 * 1024) / (lds + 1024)); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
-    int nblk = (ngroups + 7) / 8; if (nblk > 256 * per_cu) nblk = 256 * per_cu;
-    ProfScope ps(stage, std::string("pw_proj_kernel<") + std::to_string(L.NTtot) + "," + std::to_string(MT) + ">");
-#define MKWS_PJ(NT_, MT_) do { \
-      (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&pw_proj_kernel<NT_, MT_>), 96 * 1024); \
-      hipLaunchKernelGGL((pw_proj_kernel<NT_, MT_>), dim3(nblk), dim3(512), lds, s, a); } while (0)
-    if (MT == 2) {
-      switch (L.NTtot) { case 1: MKWS_PJ(1, 2); break; case 2: MKWS_PJ(2, 2); break; case 3: MKWS_PJ(3, 2); break; case 4: MKWS_PJ(4, 2); break; default: MKWS_PJ(5, 2); break; }
-    } else {
-      switch (L.NTtot) { case 1: MKWS_PJ(1, 1); break; case 2: MKWS_PJ(2, 1); break; case 3: MKWS_PJ(3, 1); break; case 4: MKWS_PJ(4, 1); break; default: MKWS_PJ(5, 1); break; }
-    }
-#undef MKWS_PJ
-    return;
-  }
-  // LDS-staged kernel?
-  int lds_sk = 1;
-  int lds_id = (g_gemm_lds_mode == 0) ? -1 : (g_gemm_lds_mode >= 100 ? g_gemm_lds_mode - 100 : pick_lds(Mplan, L.NTtot, L.KC, &lds_sk));
-  if (lds_id >= kNumLdsCfgs || L.NTtot < 4 || (L.K & 3)) lds_id = -1;
-  if (lds_id >= 0) {
-    const LdsCfg& c = kLdsCfgs[lds_id];
-    const int bnt = c.WN * c.NT, bm = c.WM * c.MT * 16;
-    a.splitk = lds_sk; a.part = nullptr; a.ldp = L.NTtot * 16;
-    if (a.splitk > 1) {
-      if (!g_splitk_ws || (size_t)a.splitk * Mplan * a.ldp > g_splitk_ws_floats) a.splitk = 1;   // decided on the planned M: same path for every batch size
-      else a.part = g_splitk_ws;
-    }
-    const size_t lds = (size_t)(2 * 2 * c.WM * c.MT * 256 + 2 * 2 * bnt * 256) * sizeof(float);
-    dim3 grid((M + bm - 1) / bm, (L.NTtot + bnt - 1) / bnt, a.splitk);
-    {
-      ProfScope ps(stage, std::string("pw_gemm_lds_kernel<") + std::to_string(c.WM) + "," + std::to_string(c.WN) + "," + std::to_string(c.MT) + "," +
-                              std::to_string(c.NT) + (gate ? ",true>" : ",false>"));
-      if (gate) launch_gemm_lds<true>(lds_id, grid, lds, s, a); else launch_gemm_lds<false>(lds_id, grid, lds, s, a);
-    }
-    if (a.splitk > 1) {
-      ProfScope ps(std::string(stage) + "#reduce", "splitk_reduce_kernel");
-      const long total = (long)M * (L.N / 4);
-      int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, a.part, a.splitk, M, L.N, a.ldp, L.scale, L.shift, act, R, ldr, Y, ldy);
-    }
-    return;
   }
   const int MT = tc.MT, NT = tc.NT;
   a.splitk = tc.splitk; a.part = nullptr; a.ldp = L.NTtot * 16;
@@ -2639,9 +2102,8 @@ bool front_supported(const BlockPlan& b) {
   return false;
 }
 
-void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, float* separt, int B) {
+void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
   FrontArgs a;
-  a.Wr = b.se.Wr; a.se = b.se.se; a.separt = separt; a.inv_hw = 1.0f / (float)(b.Ho * b.Wo);
   a.X = X; a.Cin = b.spec.in_ch; a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KC = b.expand.KC;
   a.NTtotE = b.expand.NTtot;
   a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift; a.Y = Y; a.sums = sums;
@@ -2839,21 +2301,8 @@ void launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const floa
   else launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 1, 512, 4>(s, stage, a);                              // 4a
 }
 
-void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B, int se_chunks) {
+void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B) {
   const SeLayer& L = b.se;
-  if (se_chunks > 0) {           // reduce-FC partials already written by the producing kernel as [chunk][clip][48]
-    int nsp2 = L.NTe / 4; if (nsp2 < 1) nsp2 = 1; if (nsp2 > 8) nsp2 = 8;
-    const int nb2 = (B + 15) / 16;
-    ProfScope ps(stage, std::string("se_expand_kernel<") + std::to_string(L.NTR) + ",true>");
-#define MKWS_SE2(N) hipLaunchKernelGGL((se_expand_kernel<N, true>), dim3(nb2, nsp2), dim3(256), 0, s, part, se_chunks, L.br, L.WeP, L.be, gate, B, b.ce, L.se, L.NTe, nsp2)
-    switch (L.NTR) {
-      case 1: MKWS_SE2(1); break;
-      case 2: MKWS_SE2(2); break;
-      default: MKWS_SE2(3); break;
-    }
-#undef MKWS_SE2
-    return;
-  }
   int nsl = L.KCr / 4; if (nsl < 1) nsl = 1; if (nsl > 8) nsl = 8;       // K slices of the reduce FC
   int nsp = L.NTe / 4; if (nsp < 1) nsp = 1; if (nsp > 8) nsp = 8;       // column slices of the expand FC
   const int nb = (B + 15) / 16;
@@ -2883,17 +2332,14 @@ void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float
 int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStream_t s, const char* stop,
                 const float** tap_src, size_t* tap_count) {
   g_splitk_ws = em->splitk_ws; g_splitk_ws_floats = em->splitk_floats;
-  g_gemm_lds_mode = em->gemm_lds;
-  g_proj_stream = em->proj_stream;
   auto hit = [&](const std::string& name, const float* p, size_t n) {
     if (stop && name == stop) { *tap_src = p; *tap_count = n; return true; }
     return false;
   };
   const bool want_stem_tap = stop && strcmp(stop, "stem") == 0;
-  const bool fused_stem = em->fuse_stem && !want_stem_tap;
   const BlockPlan& blk1a = em->blocks[0];
-  // whole block 1a with the stem (its inner taps come from the two-kernel path); SE is at most 8 units wide there
-  const bool fused_1a = fused_stem && em->fuse_stem >= 2 && blk1a.se.se <= 8 && !blk1a.has_expand && blk1a.spec.out_ch == 16 &&
+  // whole block 1a with the stem (its inner taps come from the separate kernels); SE is at most 8 units wide there
+  const bool fused_1a = em->fuse_stem && !want_stem_tap && blk1a.se.se <= 8 && !blk1a.has_expand && blk1a.spec.out_ch == 16 &&
                         !(stop && (strcmp(stop, "block1a_dw") == 0 || strcmp(stop, "block1a_gate") == 0));
   if (fused_1a) {
     ProfScope ps("block1a", "stem_block1a_kernel");
@@ -2902,14 +2348,6 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     hipLaunchKernelGGL(stem_block1a_kernel, dim3(B), dim3(512), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
                        em->norm_std, blk1a.dw.Wd, blk1a.dw.scale, blk1a.dw.shift, blk1a.se.Wr, blk1a.se.br, blk1a.se.We, blk1a.se.be,
                        blk1a.se.se, blk1a.project.Wp, blk1a.project.scale, blk1a.project.shift, em->bufB);
-  } else if (fused_stem) {
-    // stem + block-1a depthwise in one launch: bufD <- dw output, sums <- SE sums (bufA is not produced)
-    const BlockPlan& b1 = em->blocks[0];
-    ProfScope ps("block1a_dw", "stem_dw_kernel");
-    const size_t lds = ((size_t)((51 * 41 + 3) & ~3) + 27 * 22 * 32 + 256 * 4) * sizeof(float);
-    hipLaunchKernelGGL(stem_dw_kernel, dim3(B), dim3(256), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
-                       em->norm_std, b1.dw.Wd, b1.dw.scale, b1.dw.shift, em->bufD, em->sums, b1.se.Wr, b1.se.se,
-                       em->fuse_se ? em->se_part : nullptr, B);
   } else {
     const long pix = (long)B * 500;
     int grid = (int)((pix + 31) / 32);
@@ -2931,7 +2369,6 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       continue;
     }
     const bool want_expand_tap = stop && (p + "_expand") == stop;
-    int se_chunks = 0;            // > 0: SE reduce partials were already produced by the upstream kernel
     if (mid_enabled(b, em->fuse_mid) && !want_expand_tap) {
       // big-image blocks: one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
@@ -2958,18 +2395,15 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       if (hit(p + "_expand", em->bufE, (size_t)Min * b.ce)) return MKWS_OK;
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else if (b.has_expand && front_supported(b)) {
-      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, em->fuse_se ? em->se_part : nullptr, B);
-      se_chunks = em->fuse_se ? (b.ce + (b.H * b.W <= 16 ? 128 : 32) - 1) / (b.H * b.W <= 16 ? 128 : 32) : 0;
+      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
     } else if (b.has_expand) {
       launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
-    } else if (!(i == 0 && fused_stem)) {
+    } else {
       launch_dw(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
-    } else if (em->fuse_se) {
-      se_chunks = 1;
     }
     if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
-    launch_se(s, (p + "_gate").c_str(), b, em->sums, em->se_part, em->gate, B, se_chunks);
+    launch_se(s, (p + "_gate").c_str(), b, em->sums, em->se_part, em->gate, B);
     if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
     launch_gemm(s, p.c_str(), b.project, em->bufD, b.ce, Mout, em->max_batch * b.Ho * b.Wo, ACT_NONE, em->gate, b.Ho * b.Wo, b.residual ? cur : nullptr,
                 b.spec.out_ch, nxt, b.spec.out_ch);
@@ -2977,7 +2411,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     float* t = cur; cur = nxt; nxt = t;
   }
   const int HWt = em->topH * em->topW;
-  const bool fuse_gap = em->fuse_gap && HWt == 4 && em->gemm_lds == 0 && !(stop && strcmp(stop, "top") == 0);
+  const bool fuse_gap = em->fuse_gap && HWt == 4 && !(stop && strcmp(stop, "top") == 0);
   if (fuse_gap) {
     // top conv + BN + swish + global average pool in one launch: the [B*4, 1280] tensor never reaches HBM
     launch_gemm(s, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->gap, kTopCh, 1);
@@ -3183,10 +2617,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
-  if (strcmp(name, "gemm_lds") == 0) { em->gemm_lds = value; return MKWS_OK; }
-  if (strcmp(name, "proj_stream") == 0) { em->proj_stream = value; return MKWS_OK; }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
-  if (strcmp(name, "fuse_se") == 0) { em->fuse_se = value != 0; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

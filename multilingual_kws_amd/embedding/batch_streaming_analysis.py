@@ -39,7 +39,25 @@ def window_offsets(data_samples, clip_duration_samples, clip_stride_samples):
     return list(range(0, data_samples - clip_duration_samples, clip_stride_samples))
 
 
-def stream_spectrograms(model_settings, audio, clip_duration_samples, clip_stride_samples, max_chunk_samples=None):
+def chunk_audio(audio, max_chunk_samples):
+    """The reference's chunking of a long recording (:72-86), AS SHIPPED: recordings shorter than max_chunk_samples are
+    one chunk; otherwise, for offset in range(0, n, max_chunk_samples), a chunk that would run past the end is cut to
+    [offset, offset + max) and every OTHER chunk is the whole remainder audio[offset:] (the condition is inverted in the
+    reference, so all chunks but the last overlap everything after them).  Each chunk is windowed on its own and the
+    inferences are concatenated, which is what callers of the reference get back."""
+    n = audio.shape[0]
+    if max_chunk_samples is None or n < max_chunk_samples:
+        return [audio]
+    chunks = []
+    for offset in range(0, n, int(max_chunk_samples)):
+        if offset + max_chunk_samples > n:
+            chunks.append(audio[offset:offset + int(max_chunk_samples)])
+        else:
+            chunks.append(audio[offset:])
+    return chunks
+
+
+def stream_spectrograms(model_settings, audio, clip_duration_samples, clip_stride_samples):
     """float32 audio [n] -> CUDA tensor [num_windows, frames, channels], windows as window_offsets()."""
     import torch
     audio_t = torch.as_tensor(np.asarray(audio, dtype=np.float32)) if not torch.is_tensor(audio) else audio
@@ -59,7 +77,7 @@ def stream_spectrograms(model_settings, audio, clip_duration_samples, clip_strid
 
 
 def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_duration_ms=1000, clip_stride_ms=20,
-                         batch_windows=4096):
+                         batch_windows=4096, max_chunk_length_sec=None):
     """Softmax outputs for every window.  `models`: one TransferLearnedModel or a list sharing one embedding
     (multi-keyword serving: the EfficientNet forward runs once, each keyword adds only its 18.5 k-parameter
     head).  Returns [num_windows, 3] (or a list of them)."""
@@ -68,15 +86,18 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
     mlist = [models] if single else list(models)
     clip = int(clip_duration_ms * sample_rate / 1000)
     stride = int(clip_stride_ms * sample_rate / 1000)
-    specs = stream_spectrograms(model_settings, audio, clip, stride)
     outs = [[] for _ in mlist]
     emb_model = mlist[0].embedding
     from ..head import Head
-    for s in range(0, specs.shape[0], batch_windows):
-        emb = emb_model.forward(specs[s:s + batch_windows])
-        probs = Head.forward_many([m.head for m in mlist], emb)          # [N, windows, 3] in one launch
-        for k in range(len(mlist)):
-            outs[k].append(probs[k])
+    audio_arr = audio if torch.is_tensor(audio) else np.asarray(audio, dtype=np.float32)
+    max_chunk = None if max_chunk_length_sec is None else int(max_chunk_length_sec * sample_rate)
+    for chunk in chunk_audio(audio_arr, max_chunk):
+        specs = stream_spectrograms(model_settings, chunk, clip, stride)
+        for s in range(0, specs.shape[0], batch_windows):
+            emb = emb_model.forward(specs[s:s + batch_windows])
+            probs = Head.forward_many([m.head for m in mlist], emb)          # [N, windows, 3] in one launch
+            for k in range(len(mlist)):
+                outs[k].append(probs[k])
     res = [torch.cat(o).cpu().numpy() if o else np.zeros((0, 3), np.float32) for o in outs]
     return res[0] if single else res
 
@@ -113,7 +134,7 @@ def calculate_streaming_accuracy(model, model_settings, flag_list, existing_infe
         inferences = existing_inferences
     else:
         inferences = streaming_inferences(model, model_settings, audio, sample_rate, flag_list[0].clip_duration_ms,
-                                          flag_list[0].clip_stride_ms)
+                                          flag_list[0].clip_stride_ms, max_chunk_length_sec=flag_list[0].max_chunk_length_sec)
     results = []
     for FLAGS in flag_list:
         res_thresh = {}

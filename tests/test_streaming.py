@@ -77,6 +77,17 @@ def test_detector_matches_reference_golden_vectors(golden_dir):
     assert n_events > 50
 
 
+def test_chunking_matches_the_reference_as_shipped():
+    """batch_streaming_analysis.py:72-86 restated by hand for n = 10, max = 4 (and the single-chunk case)."""
+    a = np.arange(10)
+    assert [c.tolist() for c in bsa.chunk_audio(a, 11)] == [a.tolist()]                      # n < max: one chunk
+    got = [c.tolist() for c in bsa.chunk_audio(a, 4)]
+    # offsets 0, 4, 8: 0+4 > 10? no -> audio[0:];  4+4 > 10? no -> audio[4:];  8+4 > 10? yes -> audio[8:12]
+    assert got == [list(range(10)), list(range(4, 10)), [8, 9]]
+    assert [c.tolist() for c in bsa.chunk_audio(a, 10)] == [a.tolist()]                      # n == max: range gives offset 0 only, 0+10 > 10 false
+    assert bsa.chunk_audio(a, None)[0] is a
+
+
 def test_window_offsets_and_flags():
     assert bsa.window_offsets(16000, 16000, 320) == []                       # the reference evaluates NO window here
     assert bsa.window_offsets(16000 + 640, 16000, 320) == [0, 320]
@@ -116,3 +127,11 @@ def test_streaming_inferences_match_per_window_predict(tmp_path):
     sp = bsa.stream_spectrograms(ms, audio, 16000, 500)
     ref = input_data.to_micro_spectrogram(ms, np.stack([audio[o:o + 16000] for o in bsa.window_offsets(len(pcm), 16000, 500)]))
     assert np.array_equal(sp.cpu().numpy(), ref)
+    # max_chunk_length_sec (reference :72-86, as shipped): 3.5 s with 2 s chunks -> chunks audio[0:], then audio[32000:64000]
+    flags2 = bsa.StreamFlags(wav=wav, ground_truth="", target_keyword="kw", detection_thresholds=[0.3], max_chunk_length_sec=2)
+    _, inf_chunked = bsa.calculate_streaming_accuracy(models[0], ms, [flags2])
+    tail_offs = bsa.window_offsets(len(pcm) - 32000, 16000, 320)
+    assert inf_chunked.shape == (len(offs) + len(tail_offs), 3)
+    assert np.array_equal(inf_chunked[:len(offs)], inf[0])
+    tail = np.stack([audio[32000 + o:32000 + o + 16000] for o in tail_offs])
+    assert np.array_equal(inf_chunked[len(offs):], models[0].predict(input_data.to_micro_spectrogram(ms, tail)[..., None]))
