@@ -307,6 +307,6 @@ def test_bucketed_gradient_allreduce_over_rccl():
         spans.sort()
         assert spans[0][0] == 0 and spans[-1][1] == tr2.grads.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         # atomics make gradients order-dependent in the last bits: equal within fp32 round-off, not bit for bit
-        assert float((tr2.grads - plain).abs().max() / plain.abs().max()) < 1e-5
+        assert float((tr2.grads - plain).abs().max() / plain.abs().max()) < 1e-4
     finally:
         dist.destroy_process_group()
