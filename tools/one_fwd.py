@@ -2,7 +2,7 @@
 phase-timing runs wrap (tools/pmc_traffic.sh, tools/gpu_round.sh, MKWS_LIB=...timing.so)."""
 import os
 import sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multilingual_kws_amd import synth, weights
 from multilingual_kws_amd.embedding_model import EmbeddingModel
