@@ -1304,6 +1304,151 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Back half of a big-image MBConv block (2a, 2b, 3b, after mbconv_front_kernel): squeeze-excite + gated projection
+// (+ BN, residual) in ONE launch, one clip per workgroup, 2-4 workgroups per CU.  The clip's depthwise output
+// (34-75 KB) is read from HBM exactly once into LDS; the channel means are fixed-order column sums of that tile, the SE
+// FCs run in the workgroup (weights requested at kernel start, consumed after the staging), and the projection reads its
+// gated operand rows from LDS while its weight fragments stream through a register ring that was requested at kernel
+// start.  Replaces se_reduce_kernel + se_expand_kernel + the gated pw_gemm_kernel (three launches, a [B, C] gate round
+// trip and a second pass over D per N split).  Same arithmetic order per output as mbconv_mid_kernel's tail.
+struct BackArgs {
+  const float* D; const float* X; int Cin;
+  const float* Wr; const float* br; const float* We; const float* be; int se;
+  const float* WpP; const float* scP; const float* shP;
+  float* Y; int Cout; int residual;
+  float* dbg_gate;
+  int B;
+};
+
+template <int HOWO, int CEXP, int NTP, int RS, int NTHR, int WPE>
+__global__ __launch_bounds__(NTHR, WPE) void mbconv_back_kernel(BackArgs a) {
+  constexpr int LDD = CEXP + 4, CQ = CEXP / 4, KC = CEXP / 16, MTO = (HOWO + 15) / 16, NW = NTHR / 64;
+  constexpr int SE_MAX = 10;                                     // SE units of blocks 2a..4a: 4, 6, 6, 10, 10
+  constexpr int NSL = NTHR / 16, CPS = (CEXP + NSL - 1) / NSL;
+  constexpr int NLD = (HOWO * CQ + NTHR - 1) / NTHR;             // float4 per thread of the clip's D tile
+  constexpr int NWP = NW / NTP, MTW = (MTO + NWP - 1) / NWP;
+  constexpr int PD = (KC >= 8) ? 8 : 4;
+  constexpr int SCR = (RS * CEXP > NTHR) ? RS * CEXP : NTHR;     // column-sum partials, then SE partials
+  static_assert(RS * CQ <= NTHR && NTHR >= CEXP && NWP >= 1, "thread roles");
+  extern __shared__ __attribute__((aligned(16))) float s_bk[];
+  float* s_D = s_bk;                                             // [HOWO][LDD]
+  float* s_mean = s_D + HOWO * LDD;                              // [CEXP]
+  float* s_gate = s_mean + CEXP;                                 // [CEXP]
+  float* s_r = s_gate + CEXP;                                    // [16]
+  float* s_scr = s_r + 16;                                       // [SCR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const size_t b = blockIdx.x;
+  const float* Dc = a.D + b * HOWO * CEXP;
+  // everything this workgroup will need from global memory is requested up front: the D tile, the SE weights of this
+  // thread's role and the head of the projection weight stream of this wave's n-tile
+  f32x4 dreg[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int e = tid + k * NTHR;
+    dreg[k] = *reinterpret_cast<const f32x4*>(Dc + 4 * (size_t)(e < HOWO * CQ ? e : HOWO * CQ - 1));
+  }
+  float wr_pre[CPS], we_pre[SE_MAX];
+  {
+    const int n = tid & 15, sl = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < CPS; ++i) {
+      const int ch = sl * CPS + i;
+      wr_pre[i] = (ch < CEXP && n < a.se) ? a.Wr[(size_t)ch * a.se + n] : 0.0f;
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < SE_MAX; ++n2) we_pre[n2] = (tid < CEXP && n2 < a.se) ? a.We[(size_t)n2 * CEXP + tid] : 0.0f;
+  }
+  const float br_pre = (tid < 16 && tid < a.se) ? a.br[tid] : 0.0f;
+  const float be_pre = (tid < CEXP) ? a.be[tid] : 0.0f;
+  const int ntp = wave % NTP, rlp = wave / NTP;
+  const float* p_w = a.WpP + (size_t)g * 64 + c * 4;
+  f32x4 wqp[PD][1];
+  if (rlp < NWP) stream_mfma_prefetch<1, PD>(wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC);
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int e = tid + k * NTHR;
+    if (e < HOWO * CQ) { const int r = e / CQ, q = e - r * CQ; *reinterpret_cast<f32x4*>(s_D + (size_t)r * LDD + 4 * q) = dreg[k]; }
+  }
+  __syncthreads();
+  // ---- SE squeeze: column sums of D in two fixed-order steps (row slices, then slices) ----
+  f32x4* s_csum = reinterpret_cast<f32x4*>(s_scr);
+  if (tid < RS * CQ) {
+    const int q = tid % CQ, rs = tid / CQ;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int r = rs; r < HOWO; r += RS) t += *reinterpret_cast<const f32x4*>(s_D + (size_t)r * LDD + 4 * q);
+    s_csum[tid] = t;
+  }
+  __syncthreads();
+  if (tid < CQ) {
+    f32x4 t = s_csum[tid];
+#pragma unroll
+    for (int rs = 1; rs < RS; ++rs) t += s_csum[rs * CQ + tid];
+    *reinterpret_cast<f32x4*>(s_mean + 4 * tid) = t * (1.0f / (float)HOWO);
+  }
+  __syncthreads();
+  // ---- SE reduce (thread = (unit, channel slice), slices folded in fixed order), expand, gate ----
+  {
+    const int n = tid & 15, sl = tid >> 4;
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CPS; ++i) {
+      const int ch = sl * CPS + i;
+      v += s_mean[ch < CEXP ? ch : 0] * wr_pre[i];
+    }
+    s_scr[sl * 16 + n] = v;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float v = 0.0f;
+#pragma unroll 8
+    for (int sl = 0; sl < NSL; ++sl) v += s_scr[sl * 16 + tid];
+    s_r[tid] = (tid < a.se) ? swishf_(v + br_pre) : 0.0f;
+  }
+  __syncthreads();
+  if (tid < CEXP) {
+    float v = be_pre;
+#pragma unroll
+    for (int n2 = 0; n2 < SE_MAX; ++n2) v += s_r[n2] * we_pre[n2];
+    const float gt = sigmoidf_(v);
+    s_gate[tid] = gt;
+    if (a.dbg_gate) a.dbg_gate[b * CEXP + tid] = gt;
+  }
+  __syncthreads();
+  // ---- gated projection (+ BN, residual) ----
+  if (rlp < NWP) {
+    const float* erow[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      int r = (rlp + NWP * m) * 16 + c;
+      if (r >= HOWO) r = HOWO - 1;                               // padding rows / tiles past the end: any finite row, never stored
+      erow[m] = s_D + (size_t)r * LDD + 4 * g;
+    }
+    const float* grow = s_gate + 4 * g;
+    struct EG { f32x4 e, g; };
+    auto xload = [&](int j, int m) { return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow + 16 * j)}; };
+    auto xmake = [](const EG& v) { return v.e * v.g; };
+    f32x4 acc[1][MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) acc[0][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stream_mfma<1, PD, MTW, true>(acc, wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC, xload, xmake);
+    const int n = ntp * 16 + 4 * g;
+    if (n < a.Cout) {
+      const f32x4 scp = *reinterpret_cast<const f32x4*>(a.scP + n), shp = *reinterpret_cast<const f32x4*>(a.shP + n);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int r = (rlp + NWP * m) * 16 + c;
+        if (r < HOWO) {
+          f32x4 y = acc[0][m] * scp + shp;
+          if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (b * HOWO + r) * a.Cin + n);
+          *reinterpret_cast<f32x4*>(a.Y + (b * HOWO + r) * a.Cout + n) = y;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Whole-MBConv kernel for the tiny-image blocks (4x3 and 2x2 inputs: blocks 4b..7a).
 // One workgroup owns one 16-row MFMA tile of activations (4 clips of 2x2, or 1 clip of 4x3) and carries it
 // through expand -> depthwise -> SE -> gated project entirely in LDS; every weight of the block streams
@@ -1885,6 +2030,7 @@ struct mkws_embed {
   bool fuse_front = true;          // expand + depthwise in one kernel (mbconv_front_kernel)
   int fuse_gap = 1;                // global average pool fused into the top conv's epilogue (2x2 image: 4 rows per clip)
   int fuse_stem = 1;               // 1: stem + whole block 1a in one kernel (stem_block1a_kernel); 0: separate kernels (parity taps)
+  int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 3a and 4a (where it measured faster), 2 = 2a..4a, 0 = never
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   BlockPlan blocks[kNumBlocks];
@@ -2301,6 +2447,35 @@ void launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const floa
   else launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 1, 512, 4>(s, stage, a);                              // 4a
 }
 
+// Back half (SE + gated projection in one launch) for the blocks that keep mbconv_front_kernel: 2a, 2b, 3b.
+bool back_supported(const BlockPlan& b) {
+  if (!b.has_expand || b.se.se > 10) return false;
+  const int hw = b.Ho * b.Wo;
+  return (hw == 130 && b.ce == 96 && b.spec.out_ch == 24) || (hw == 130 && b.ce == 144 && b.spec.out_ch == 24) || (hw == 35 && b.ce == 240 && b.spec.out_ch == 40);
+}
+
+template <int HOWO, int CEXP, int NTP, int RS, int NTHR, int WPE>
+void launch_back_inst(hipStream_t s, const char* stage, const BackArgs& a) {
+  constexpr int SCR = (RS * CEXP > NTHR) ? RS * CEXP : NTHR;
+  constexpr size_t lds = ((size_t)HOWO * (CEXP + 4) + 2 * CEXP + 16 + SCR) * sizeof(float);
+  auto* fn = &mbconv_back_kernel<HOWO, CEXP, NTP, RS, NTHR, WPE>;
+  if (ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024) != MKWS_OK) return;
+  ProfScope ps(stage, std::string("mbconv_back_kernel<") + std::to_string(HOWO) + "," + std::to_string(CEXP) + "," + std::to_string(NTP) + "," + std::to_string(NTHR) + ">");
+  hipLaunchKernelGGL(fn, dim3(a.B), dim3(NTHR), lds, s, a);
+}
+
+void launch_back(hipStream_t s, const char* stage, const BlockPlan& b, const float* D, const float* X, float* Y, float* dbg_gate, int B) {
+  BackArgs a;
+  a.D = D; a.X = X; a.Cin = b.spec.in_ch;
+  a.Wr = b.se.Wr; a.br = b.se.br; a.We = b.se.We; a.be = b.se.be; a.se = b.se.se;
+  a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift;
+  a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0; a.dbg_gate = dbg_gate; a.B = B;
+  //                          HOWO CEXP NTP RS NTHR WPE
+  if (b.ce == 96) launch_back_inst<130, 96, 2, 8, 512, 4>(s, stage, a);          // 2a: 52 KB of LDS -> 3 workgroups per CU
+  else if (b.ce == 144) launch_back_inst<130, 144, 2, 4, 512, 4>(s, stage, a);   // 2b: 80.5 KB -> 2 per CU
+  else launch_back_inst<35, 240, 3, 4, 512, 4>(s, stage, a);                      // 3b: 39 KB -> 4 per CU
+}
+
 void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B) {
   const SeLayer& L = b.se;
   int nsl = L.KCr / 4; if (nsl < 1) nsl = 1; if (nsl > 8) nsl = 8;       // K slices of the reduce FC
@@ -2403,6 +2578,15 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       launch_dw(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
     }
     if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
+    if (em->fuse_back && back_supported(b)) {
+      // SE + gated projection of this block in one launch, the clip's depthwise output staged in LDS once
+      const bool tap_gate = stop && (p + "_gate") == stop;
+      launch_back(s, p.c_str(), b, em->bufD, cur, nxt, tap_gate ? em->gate : nullptr, B);
+      if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
+      if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
+      float* t = cur; cur = nxt; nxt = t;
+      continue;
+    }
     launch_se(s, (p + "_gate").c_str(), b, em->sums, em->se_part, em->gate, B);
     if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
     launch_gemm(s, p.c_str(), b.project, em->bufD, b.ce, Mout, em->max_batch * b.Ho * b.Wo, ACT_NONE, em->gate, b.Ho * b.Wo, b.residual ? cur : nullptr,
@@ -2488,6 +2672,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // bit-identical across the batch sizes one handle sees.
   em->fuse_block = (max_batch >= 384) ? 2 : 0;
   em->fuse_mid = (max_batch >= 384) ? 1 : 0;
+  em->fuse_back = (max_batch >= 384) ? 1 : 0;
   (void)hipGetDevice(&em->device);
   Packer pk;
   std::vector<float> sc, sh;
@@ -2616,6 +2801,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);

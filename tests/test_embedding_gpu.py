@@ -57,6 +57,7 @@ def test_execution_options_agree(ctx):
             ctx["em"].set_option("fuse_front", front)
             ctx["em"].set_option("fuse_block", block)
             ctx["em"].set_option("fuse_mid", mid)
+            ctx["em"].set_option("fuse_back", 1 if mid != 2 else 0)
             ctx["em"].set_option("fuse_stem", front)
             ctx["em"].set_option("fuse_gap", front)
             assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block, mid)
@@ -70,6 +71,7 @@ def test_execution_options_agree(ctx):
         ctx["em"].set_option("fuse_front", 1)
         ctx["em"].set_option("fuse_block", 2)
         ctx["em"].set_option("fuse_mid", 1)
+        ctx["em"].set_option("fuse_back", 1)
         ctx["em"].set_option("fuse_stem", 1)
         ctx["em"].set_option("fuse_gap", 1)
 
