@@ -49,25 +49,50 @@ class EmbeddingTrainer:
         self.norm_std = max(float(np.sqrt(blob[self.tensors["normalization/variance"]["offset"]])), 1e-7)
         self.tape = None
         self._pending = []
+        # host-side caches: the tape allocates the same sequence of buffers every step, and parameter / gradient views are
+        # fixed slices of the flat buffers -- re-creating either costs more host time than the small kernels take
+        self._views = {}
+        self._pool, self._pool_pos, self._pool_B = [], 0, None
+        self._stream = None
 
     # ---- plumbing -----------------------------------------------------------------------------------------------------
     def _s(self):
-        return _lib.current_stream_ptr()
+        return self._stream          # bound once per forward_train() / backward() / adam_step(): torch's current stream
+
+    def _bind_stream(self):
+        self._stream = _lib.current_stream_ptr()
 
     @staticmethod
     def _p(t):
         return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
     def P(self, name):
-        t = self.tensors[name]
-        return self.params[t["offset"]:t["offset"] + t["count"]]
+        v = self._views.get(("p", name))
+        if v is None:
+            t = self.tensors[name]
+            v = self._views[("p", name)] = self.params[t["offset"]:t["offset"] + t["count"]]
+        return v
 
     def G(self, name):
-        t = self.tensors[name]
-        return self.grads[t["offset"]:t["offset"] + t["count"]]
+        v = self._views.get(("g", name))
+        if v is None:
+            t = self.tensors[name]
+            v = self._views[("g", name)] = self.grads[t["offset"]:t["offset"] + t["count"]]
+        return v
 
     def new(self, *shape):
-        return self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
+        """Scratch / tape buffer.  Buffers are handed out from a pool in call order: one step's forward + backward makes the
+        same sequence of requests as the previous one (same batch size), so after the first step nothing is allocated."""
+        i = self._pool_pos
+        self._pool_pos += 1
+        if i < len(self._pool) and tuple(self._pool[i].shape) == tuple(shape):
+            return self._pool[i]
+        buf = self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
+        if i < len(self._pool):
+            self._pool[i] = buf
+        else:
+            self._pool.append(buf)
+        return buf
 
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, acc=0, ksplit=1):
         _lib.check(self.L.mkws_op_gemm(self._p(A), self._p(B), self._p(C), M, N, K, lda, ldb, ldc, ta, tb, acc, ksplit, self._s()))
@@ -128,11 +153,15 @@ class EmbeddingTrainer:
         """spec CUDA [B,49,40(,1)] -> embedding CUDA [B,1024] in TRAINING mode; keeps the tape for backward().
         drop_masks: {block name: bool [B] of KEPT samples} for the residual blocks, or None (no drop-connect)."""
         torch = self.torch
+        self._bind_stream()
         spec = spec.to(self.device, dtype=torch.float32)
         if spec.dim() == 4:
             spec = spec[..., 0]
         spec = spec.contiguous()
         B = spec.shape[0]
+        if self._pool_B != B:
+            self._pool, self._pool_B = [], B
+        self._pool_pos = 0
         tape = {"spec": spec, "B": B, "blocks": []}
         H, W = 25, 20
         Z = self.new(B * H * W, 32)
@@ -168,7 +197,9 @@ class EmbeddingTrainer:
             Pj, rec["project_bn"] = self._bn_fwd(Zp, Mout, cout, p + "_project_bn", ACT_NONE)
             rec["residual"] = (s == 1 and cin == cout)
             if rec["residual"]:
-                scale = torch.ones(B, dtype=torch.float32, device=self.device)
+                scale = self._views.get(("ones", B))
+                if scale is None:
+                    scale = self._views[("ones", B)] = torch.ones(B, dtype=torch.float32, device=self.device)
                 if drop_masks is not None and name in drop_masks:
                     rate = DROP_CONNECT_RATE * bi / len(BLOCKS)
                     scale = torch.as_tensor(np.asarray(drop_masks[name]), device=self.device).to(torch.float32) / (1.0 - rate)
@@ -201,6 +232,7 @@ class EmbeddingTrainer:
         if tape is None:
             raise RuntimeError("backward() needs a forward_train() first")
         B = tape["B"]
+        self._bind_stream()
         self.grads.zero_()
         self._pending = []
         d = d_emb.to(self.device, dtype=torch.float32).contiguous().clone()
@@ -210,7 +242,8 @@ class EmbeddingTrainer:
             self._allreduce_range(self.tensors["dense_1/kernel"]["offset"], self.grads.shape[0])
         d = self._fc_bwd(tape["dense"], d)
         HW = tape["HW"]
-        dAt = torch.zeros((B * HW, 1280), dtype=torch.float32, device=self.device)
+        dAt = self.new(B * HW, 1280)
+        dAt.zero_()
         _lib.check(self.L.mkws_op_add_bcast(self._p(dAt), self._p(d), 1.0 / HW, B, HW, 1280, self._s()))
         dZt = self._bn_bwd(tape["top_bn"], dAt)
         d = self._conv_bwd(tape["top_in"], dZt, B * HW, 320, 1280, "top_conv/kernel")
@@ -262,6 +295,7 @@ class EmbeddingTrainer:
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         """Keras Adam over the whole blob (moving statistics / Normalization constants have zero gradient and stay put)."""
         self.step_t += 1
+        self._bind_stream()
         _lib.check(self.L.mkws_op_adam(self._p(self.params), self._p(self.grads), self._p(self.m), self._p(self.v), self.params.shape[0], lr, beta1, beta2, eps,
                                        self.step_t, grad_scale, self._s()))
 
