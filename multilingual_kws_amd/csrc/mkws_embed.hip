@@ -1328,14 +1328,13 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_back_kernel(BackArgs a) {
   constexpr int NLD = (HOWO * CQ + NTHR - 1) / NTHR;             // float4 per thread of the clip's D tile
   constexpr int NWP = NW / NTP, MTW = (MTO + NWP - 1) / NWP;
   constexpr int PD = (KC >= 8) ? 8 : 4;
-  constexpr int SCR = (RS * CEXP > NTHR) ? RS * CEXP : NTHR;     // column-sum partials, then SE partials
   static_assert(RS * CQ <= NTHR && NTHR >= CEXP && NWP >= 1, "thread roles");
   extern __shared__ __attribute__((aligned(16))) float s_bk[];
   float* s_D = s_bk;                                             // [HOWO][LDD]
   float* s_mean = s_D + HOWO * LDD;                              // [CEXP]
   float* s_gate = s_mean + CEXP;                                 // [CEXP]
   float* s_r = s_gate + CEXP;                                    // [16]
-  float* s_scr = s_r + 16;                                       // [SCR]
+  float* s_scr = s_r + 16;                                       // [max(RS*CEXP, NTHR)]: column-sum partials, then SE partials
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const size_t b = blockIdx.x;

@@ -19,6 +19,7 @@
 #include "mkws_common.h"
 #include "mkws_frontend_tables.h"
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -30,9 +31,11 @@ struct FrontendParams {
   const int16_t* window_coef;   // [512], zero padded
   const uint32_t* tw;           // [256] packed (re | im<<16)
   const uint32_t* stw;          // [128] packed
-  const int16_t* out_start;     // [C]
-  const int16_t* out_len;       // [C]
-  const int16_t* out_off;       // [C]
+  const int16_t* out_start;     // [64] per-LANE filterbank tasks (see LaneConst)
+  const int16_t* out_len;       // [64]
+  const int16_t* out_off;       // [64]
+  const int16_t* task_ch;       // [64] channel a helper lane (>= C) adds to, else -1
+  const int16_t* task_helped;   // [64] 1 if a helper lane contributes to this lane's channel
   const int16_t* out_coef;      // [ncoef]
   const int16_t* pcan_lut;      // [128]
   const uint16_t* log_lut;      // [132]
@@ -64,13 +67,42 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 mk2(int r, int i) { s16x2 v; v.x = (short)r; v.y = (short)i; return v; }
 __device__ __forceinline__ uint32_t bits2(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ s16x2 from2(uint32_t u) { return __builtin_bit_cast(s16x2, u); }
-// C_FIXDIV: sround(v * (32767/div)) on both components (|result| <= |v|/div: no wrap)
-__device__ __forceinline__ s16x2 fixdiv_pk(s16x2 v, int k) { return mk2(((int)v.x * k + 16384) >> 15, ((int)v.y * k + 16384) >> 15); }
+// C_FIXDIV: sround(v * (32767/div)) on both components (|result| <= |v|/div: no wrap).
+// (c*k + 2^14) >> 15 == (c*2k + 2^15) >> 16, i.e. the HIGH half of a 32-bit multiply-add: v_mad_i32_i16 reads either 16-bit
+// half of the packed value directly (op_sel) and one v_perm_b32 packs the two high halves -- 3 instructions per complex value
+// instead of unpack (2) + mad (2) + shift (2) + pack (2).  2k = 16382 / 32766 still fits int16; |c*2k| < 2^31.
+__device__ __forceinline__ s16x2 fixdiv_pk(s16x2 v, int k) {
+  const uint32_t u = bits2(v);
+  const int k2 = 2 * k, half = 32768;
+  int lo, hi;
+  asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(lo) : "v"(u), "v"(k2), "v"(half));
+  asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(u), "v"(k2), "v"(half));
+  return from2(__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060302u));
+}
 // twiddle t as the two dot-product operands of C_MUL: (t.r, -t.i) and (t.i, t.r)   (|t| <= 32767: negation is exact)
 struct tw2 { s16x2 a, b; };
 __device__ __forceinline__ tw2 mktw(cpx t) { tw2 w; w.a = mk2(t.r, -t.i); w.b = mk2(t.i, t.r); return w; }
+// (v_dot2_i32_i16 with a separate addend operand: the builtin selects the accumulate form v_dot2c, which costs a v_mov of
+// the rounding constant per product)
+__device__ __forceinline__ int dot2_i16(s16x2 a, s16x2 b, int c) {
+  int d;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(bits2(a)), "v"(bits2(b)), "v"(c));
+  return d;
+}
 __device__ __forceinline__ s16x2 cmul_pk(s16x2 a, tw2 t) {
-  return mk2(__builtin_amdgcn_sdot2(a, t.a, 16384, false) >> 15, __builtin_amdgcn_sdot2(a, t.b, 16384, false) >> 15);
+  const int rnd = 16384;
+  return mk2(dot2_i16(a, t.a, rnd) >> 15, dot2_i16(a, t.b, rnd) >> 15);
+}
+// max over the 64 lanes of a non-negative value, on the VALU's DPP paths (no LDS round trips): quads, half rows, rows,
+// then rows 1,3 <- lane 15 of rows 0,2 and rows 2,3 <- lane 31; the result sits in lane 63
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));   // row_mirror
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));   // row_bcast15
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));   // row_bcast31
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // kissfft kf_bfly4 (forward), one butterfly, on packed values.
@@ -133,6 +165,9 @@ struct LaneConst {
   int n0;             // base-4 digit reversal of the lane id (3 digits)
   int toff[4];        // sample offset of pair j inside the frame, clamped into the window (loads are unconditional)
   int tsel[4];        // 2: both samples inside the window, 1: only the first (odd window), 0: none (zero padding)
+  // mel filterbank task of this lane: bins [fb_start, +fb_len) with coefficients from fb_off; lanes < C own channel = lane,
+  // lanes >= C may help the channel fb_ch (second half of a long tap list); fb_helped: a helper adds to this lane's channel
+  int fb_start, fb_len, fb_off, fb_ch, fb_helped;
 };
 
 __device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lane, LaneConst& L) {
@@ -161,6 +196,8 @@ __device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lan
   }
   L.st1 = mktw(unpack(p.stw[lane]));
   L.st2 = mktw(unpack(p.stw[lane + 64]));
+  L.fb_start = p.out_start[lane]; L.fb_len = p.out_len[lane]; L.fb_off = p.out_off[lane];
+  L.fb_ch = p.task_ch[lane]; L.fb_helped = p.task_helped[lane];
 }
 
 // window.c + fft.c + kiss_fftr + filterbank.c for ONE frame by ONE wave.
@@ -170,28 +207,26 @@ __device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lan
 __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const LaneConst& L, int lane,
                                              const int (&x)[8], uint32_t* fftbuf, uint32_t* ebuf,
                                              const int16_t* s_coef, uint32_t* sig_out) {
-  // ---- window (A.1) and block exponent (A.2) ----
-  int w[8];
-  int mx = 0;
+  // ---- window (A.1) and block exponent (A.2), on packed int16 pairs ----
+  // w = int16((x * coef) >> 12) is bits [12..27] of the product = the high half of (product << 4): one v_perm_b32 packs a pair
+  s16x2 W[4];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    w[q] = sext16((x[q] * L.coef[q]) >> 12);
-    const int a = (w[q] < 0) ? sext16(-w[q]) : w[q];   // int16 negate: -(-32768) stays negative
-    mx = (a > mx) ? a : mx;
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t lo = (uint32_t)(x[2 * j] * L.coef[2 * j]) << 4, hi = (uint32_t)(x[2 * j + 1] * L.coef[2 * j + 1]) << 4;
+    W[j] = from2(__builtin_amdgcn_perm(hi, lo, 0x07060302u));
   }
+  s16x2 m2 = mk2(0, 0);
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const int o = __shfl_xor(mx, off, 64);
-    mx = (o > mx) ? o : mx;
+  for (int j = 0; j < 4; ++j) {
+    const s16x2 neg = mk2(0, 0) - W[j];                // int16 negate: -(-32768) stays negative, as upstream
+    m2 = __builtin_elementwise_max(m2, __builtin_elementwise_max(W[j], neg));
   }
+  const int mx = wave_max_nonneg(max((int)m2.x, (int)m2.y));
   const int shift = (mx == 0) ? 15 : (15 - (32 - __clz(mx)));
   // ---- stage A (m = 1): butterflies on z[n0 + 64 j], twiddle (32767, 0) ----
-  // fft.c FftCompute: (int16)((uint16)w << shift)
-  auto shl = [shift](int v) { return sext16((int)((uint32_t)v << shift)); };
-  s16x2 F0 = mk2(shl(w[0]), shl(w[1]));
-  s16x2 F1 = mk2(shl(w[2]), shl(w[3]));
-  s16x2 F2 = mk2(shl(w[4]), shl(w[5]));
-  s16x2 F3 = mk2(shl(w[6]), shl(w[7]));
+  // fft.c FftCompute: (int16)((uint16)w << shift), both halves at once
+  const s16x2 sh2 = mk2(shift, shift);
+  s16x2 F0 = W[0] << sh2, F1 = W[1] << sh2, F2 = W[2] << sh2, F3 = W[3] << sh2;
   const tw2 one = mktw(cpx{32767, 0});
   bfly4(F0, F1, F2, F3, one, one, one);
   fftbuf[4 * lane + 0] = bits2(F0);
@@ -243,16 +278,23 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
     ebuf[256 - k] = (uint32_t)(br * br) + (uint32_t)(bi * bi);   // k == 128: the second write wins upstream
   }
   wave_lds_sync();
-  // ---- mel filterbank (uint64 sums) + rounded sqrt, one channel per lane ----
-  if (lane < p.num_channels) {
-    const int start = p.out_start[lane], len = p.out_len[lane], off = p.out_off[lane];
+  // ---- mel filterbank (uint64 sums) + rounded sqrt ----
+  // Lane c < C owns channel c; the tap lists of the longest channels are split in two and the lanes >= C take the second
+  // halves (the loop runs max-length iterations for the whole wave: 14 instead of 28 for the 40-channel configuration).
+  // uint64 sums wrap mod 2^64, so the split is exact.
+  {
     uint64_t acc = 0;
-    for (int j = 0; j < len; ++j) {
+    for (int j = 0; j < L.fb_len; ++j) {
       // upstream multiplies (uint64_t)(int32 energy): sign-extends the one value 2^31
-      const uint64_t e = (uint64_t)(int64_t)(int32_t)ebuf[start + j];
-      acc += (uint64_t)(int64_t)s_coef[off + j] * e;
+      const uint64_t e = (uint64_t)(int64_t)(int32_t)ebuf[L.fb_start + j];
+      acc += (uint64_t)(int64_t)s_coef[L.fb_off + j] * e;
     }
-    sig_out[lane] = sqrt64_round(acc) >> shift;
+    if (L.fb_ch >= 0) { fftbuf[2 * L.fb_ch] = (uint32_t)acc; fftbuf[2 * L.fb_ch + 1] = (uint32_t)(acc >> 32); }   // helper: FFT state is dead
+    wave_lds_sync();
+    if (lane < p.num_channels) {
+      if (L.fb_helped) acc += (uint64_t)fftbuf[2 * lane] | ((uint64_t)fftbuf[2 * lane + 1] << 32);
+      sig_out[lane] = sqrt64_round(acc) >> shift;
+    }
   }
 }
 
@@ -527,17 +569,35 @@ int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_fro
   const int C = cfg->num_channels;
   const size_t ncoef = t.out_coef.size();
   auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
-  size_t o_win = 0, o_tw = al(o_win + 512 * 2), o_stw = al(o_tw + 256 * 4), o_os = al(o_stw + 128 * 4), o_ol = al(o_os + C * 2),
-         o_oo = al(o_ol + C * 2), o_oc = al(o_oo + C * 2), o_pc = al(o_oc + (ncoef + 8) * 2), o_lg = al(o_pc + 128 * 2), total = al(o_lg + 132 * 2);
+  size_t o_win = 0, o_tw = al(o_win + 512 * 2), o_stw = al(o_tw + 256 * 4), o_os = al(o_stw + 128 * 4), o_ol = al(o_os + 64 * 2),
+         o_oo = al(o_ol + 64 * 2), o_tc = al(o_oo + 64 * 2), o_th = al(o_tc + 64 * 2), o_oc = al(o_th + 64 * 2), o_pc = al(o_oc + (ncoef + 8) * 2), o_lg = al(o_pc + 128 * 2), total = al(o_lg + 132 * 2);
   std::vector<unsigned char> h(total, 0);
   memcpy(h.data() + o_win, t.window_coef.data(), t.window_coef.size() * 2);
   uint32_t* tw = reinterpret_cast<uint32_t*>(h.data() + o_tw);
   for (int i = 0; i < 256; ++i) tw[i] = ((uint32_t)(uint16_t)t.twiddles[2 * i]) | ((uint32_t)(uint16_t)t.twiddles[2 * i + 1] << 16);
   uint32_t* stw = reinterpret_cast<uint32_t*>(h.data() + o_stw);
   for (int i = 0; i < 128; ++i) stw[i] = ((uint32_t)(uint16_t)t.super_twiddles[2 * i]) | ((uint32_t)(uint16_t)t.super_twiddles[2 * i + 1] << 16);
-  memcpy(h.data() + o_os, t.out_start.data(), C * 2);
-  memcpy(h.data() + o_ol, t.out_len.data(), C * 2);
-  memcpy(h.data() + o_oo, t.out_off.data(), C * 2);
+  {
+    // per-lane filterbank tasks: lanes < C their channel; the 64 - C spare lanes take the second half of the longest tap lists
+    int16_t* ts = reinterpret_cast<int16_t*>(h.data() + o_os);
+    int16_t* tl = reinterpret_cast<int16_t*>(h.data() + o_ol);
+    int16_t* to = reinterpret_cast<int16_t*>(h.data() + o_oo);
+    int16_t* tc = reinterpret_cast<int16_t*>(h.data() + o_tc);
+    int16_t* th = reinterpret_cast<int16_t*>(h.data() + o_th);
+    for (int l = 0; l < 64; ++l) { ts[l] = 0; tl[l] = 0; to[l] = 0; tc[l] = -1; th[l] = 0; }
+    for (int c = 0; c < C; ++c) { ts[c] = t.out_start[c]; tl[c] = t.out_len[c]; to[c] = t.out_off[c]; }
+    std::vector<int> order(C);
+    for (int c = 0; c < C; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t.out_len[a] > t.out_len[b]; });
+    for (int k = 0, l = C; k < C && l < 64; ++k, ++l) {
+      const int c = order[k], len = t.out_len[c];
+      if (len < 2) break;
+      const int first = (len + 1) / 2;
+      tl[c] = static_cast<int16_t>(first);
+      ts[l] = static_cast<int16_t>(t.out_start[c] + first); tl[l] = static_cast<int16_t>(len - first); to[l] = static_cast<int16_t>(t.out_off[c] + first);
+      tc[l] = static_cast<int16_t>(c); th[c] = 1;
+    }
+  }
   memcpy(h.data() + o_oc, t.out_coef.data(), ncoef * 2);
   memcpy(h.data() + o_pc, t.pcan_lut.data(), t.pcan_lut.size() * 2);
   memcpy(h.data() + o_lg, t.log_lut.data(), t.log_lut.size() * 2);
@@ -554,6 +614,8 @@ int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_fro
   p.out_len = reinterpret_cast<int16_t*>(d + o_ol);
   p.out_off = reinterpret_cast<int16_t*>(d + o_oo);
   p.out_coef = reinterpret_cast<int16_t*>(d + o_oc);
+  p.task_ch = reinterpret_cast<int16_t*>(d + o_tc);
+  p.task_helped = reinterpret_cast<int16_t*>(d + o_th);
   p.pcan_lut = reinterpret_cast<int16_t*>(d + o_pc);
   p.log_lut = reinterpret_cast<uint16_t*>(d + o_lg);
   p.ncoef = (int)ncoef;
