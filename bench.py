@@ -206,7 +206,7 @@ def embed_roofline(em, spec, B, reps, arch, extra=None):
             cost = costs["stem_block1a"]
         elif kernel.startswith("mbconv_front"):
             cost = costs[stage.replace("_dw", "_front")]
-        elif kernel.startswith("mbconv_block") or kernel.startswith("mbconv_mid"):
+        elif kernel.startswith("mbconv_block") or kernel.startswith("mbconv_mid") or kernel.startswith("mbconv_pair"):
             cost = costs[stage + "_block"]
         else:
             cost = costs[stage]

@@ -148,6 +148,9 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "fuse_block" (default 2 for handles with max_batch >= 384, else 0): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
  *                 ONE kernel, 4 clips per workgroup, activations resident in LDS; 1 = only the 2x2 blocks
  *                 (6b..7a); 0 = the multi-kernel path everywhere.
+ *   "fuse_pair" (default 1 for handles with max_batch >= 384, else 0; needs "fuse_block"): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a) run on
+ *                 the PAIRED whole-block kernel: two workgroups on two CUs of one XCD share 8 clips and split the expanded channels,
+ *                 so each CU streams half of the block's weights; two small in-kernel exchanges through L2.  0 = one workgroup per 4 clips.
  *   "fuse_back" (default 1 for handles with max_batch >= 384, else 0): blocks 2a, 2b, 3b run squeeze-excite + gated projection as
  *                 ONE kernel behind the fused expand+depthwise kernel (the clip's depthwise output is staged in LDS once);
  *                 0 = se_reduce + se_expand + projection GEMM launches.

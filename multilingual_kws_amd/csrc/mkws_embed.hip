@@ -271,8 +271,21 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int m0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
-  const int nt0 = blockIdx.y * NT;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs in linear-id order (x fastest), so with the plain
+  // (x = row block, y = tile group) grid XCD k would own row blocks k, k+8, ... for EVERY tile group and each of the 8 L2s
+  // would pull the whole weight matrix (dense_1: 125 MB fetched for 34 MB of operands).  Instead XCD k owns one rectangle
+  // of the 2 x 4 split of the (row block, tile group) plane: half of X and a quarter of W per L2.
+  int bx = blockIdx.x, by = blockIdx.y;
+#ifndef MKWS_GEMM_PLAIN_ORDER                      // dev aid: -DMKWS_GEMM_PLAIN_ORDER builds the A/B library without the remap
+  if ((gridDim.x & 1) == 0 && (gridDim.y & 3) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, idx = lin >> 3;
+    const int rx = gridDim.x >> 1, ry = gridDim.y >> 2;
+    bx = (xcd & 1) * rx + idx % rx;
+    by = (xcd >> 1) * ry + idx / rx;
+  }
+#endif
+  const int m0 = bx * (64 * MT) + wave * (16 * MT);
+  const int nt0 = by * NT;
   if (m0 >= a.M) return;
 
   // Operand pointers are CLAMPED instead of predicated (rows past M re-read row M-1, tiles past NTtot
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   // degenerated to depth 1).  So: unconditional prologue, a steady-state loop in which every slot does
   // exactly "MFMAs, then reload" (the compiler then emits counted vmcnt(N) and D-1 chunks stay in flight),
   // and a drain.
-  constexpr int D = (MT * NT >= 10) ? 3 : 4;
+  constexpr int D = (MT * NT >= 10) ? 3 : 4;   // deeper rings measured slower (6: +2 %, 8: +3 % on the dense layers, profiles/r02_notes.md)
   constexpr int XW = GATE ? 2 * MT : MT;        // the SE gate rides the ring as raw fragments next to X: multiplying it in at
   f32x4 xq[D][XW], wq[D][NT];                   // load time would touch the fresh registers and force an immediate wait
   auto load = [&](int j, f32x4 (&xv)[XW], f32x4 (&wv)[NT]) {
@@ -1865,6 +1878,381 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Paired whole-block kernel for the 2x2-image blocks (6b..7a).  mbconv_block_kernel gives every CU one 16-row tile and
+// makes it pull the whole block's weights (2.2 MB) from L2, and a CU's L2 stream tops out at ~41 GB/s whatever is kept in
+// flight (profiles/r02_notes.md): 54 us of the 59.  Here TWO workgroups on two CUs of one XCD share 8 clips (two row
+// tiles) and split the block's CHANNELS: half h owns expanded channels [h*Cexp/2, (h+1)*Cexp/2).
+//   A   expand: the half's n-tiles, both row tiles           -> each CU streams half of the expand weights, every
+//   B   depthwise + SE sums on the half's channels              fragment feeds two row tiles
+//   C1  SE reduce over the half's channels: PARTIAL r          -> exchange 1 (384 floats each way), r = swish(p0 + p1 + br)
+//   C2  SE gate for the half's channels
+//   D   projection over the half's K: PARTIAL output tiles     -> exchange 2: even tiles are finished by half 0, odd by
+//       half 1 (partial of the other half + own, BN, residual)
+// Exchanges go through a small global buffer (L2 of the shared XCD): plain stores, s_waitcnt vmcnt(0), barrier, a relaxed
+// agent-scope flag; the consumer polls the flag, reads the data with agent-scope (L1-bypassing) loads and resets the flag
+// (no epochs: hipGraph replay safe).  Measured with tools/microbench/pair_sync.hip: 1-3 us per exchange; the formal
+// agent-scope fences cost 13 us (buffer_inv sc1) + 4-16 us (buffer_wbl2 sc1) EACH and are not needed inside one XCD.
+// Workgroups are dealt round-robin over the XCDs, so blocks b and b ^ 8 share an XCD and are adjacent in its dispatch
+// order (no deadlock: an XCD's resident set is a prefix of its sequence, complete pairs always finish); both halves publish
+// their XCC id with the first flag and the kernel poisons its output with NaN if they differ or if a wait times out.
+// Reductions keep a fixed order (p0 + p1 commutes), so results are bit-identical across batch sizes.
+struct PairArgs {
+  BlockArgs b;
+  float* xc1;      // [pairs][2][384]
+  float* xd;       // [pairs][2][10][2][256]
+  int* flags;      // [pairs][2 exchanges][2 halves], zero between launches
+};
+static constexpr int kPairXc1 = 384, kPairXdTiles = 10;
+
+__device__ __forceinline__ f32x4 ld_agent_x4(const float* p) {
+  f32x4 v;
+  v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
+// Thread 0 of each half: publish `mine`, wait for the partner's flag, reset it.  Returns the partner's value (0 = timed out).
+__device__ __forceinline__ int pair_signal_wait(int* mine, int* theirs, int value) {
+  __hip_atomic_store(mine, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int got = 0, spins = 0;
+  while ((got = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 22)) return 0;
+  }
+  __hip_atomic_store(theirs, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return got;
+}
+
+struct PairLds { int U, E, Z; };
+__host__ __device__ inline PairLds pair_lds(int KCe, int CH) {
+  PairLds l;
+  const int xf = KCe * 2 * 256, sg = 8 * CH * 2;
+  l.U = xf > sg ? xf : sg;
+  l.E = 32 * (CH + 4);
+  const int z2 = 16 * 52 + CH;             // A: scale / shift [2][CH];  later r [16][52] + bias [CH];  last 4 words: the error flag
+  l.Z = ((2 * CH > z2) ? 2 * CH : z2) + 4;
+  return l;
+}
+
+template <int KS, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) float s_blk[];
+  const BlockArgs& a = pa.b;
+  constexpr int NTHR = NWAVES * 64;
+  constexpr int HT = 2, WT = 2, HW = 4, G = 8, MT = 2;
+  constexpr int PT = KS / 2, PLF = KS / 2;
+  constexpr int LDR = 52;
+  const int h = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+  const int b0 = pair * G;
+  if (b0 >= a.B) return;                                        // both halves of a padding pair leave together
+  const int Cexp = a.Cexp, CH = Cexp / 2, LDE = CH + 4;
+  const int KH = CH / 16;                                       // this half's 16-channel tiles / K chunks
+  const int KCx = Cexp / 16;
+  const PairLds L = pair_lds(a.KCe, CH);
+  float* s_X = s_blk;                                           // U, phase A: [KCe][2][256]
+  float* s_S = s_blk;                                           // U, later: [8][CH] SE means
+  float* s_G = s_S + G * CH;                                    //           [8][CH] gate; C1: [NWAVES][48][8] partials
+  float* s_P = s_G;
+  float* s_E = s_blk + L.U;                                     // [32][LDE]
+  float* s_scE = s_E + L.E;                                     // Z, phase A: expand BN scale / shift of the half
+  float* s_shE = s_scE + CH;
+  float* s_R = s_scE;                                           // Z, later: r [8][LDR], SE expand bias [CH]
+  float* s_be = s_R + 16 * LDR;
+  volatile int* s_bad = reinterpret_cast<volatile int*>(s_scE + L.Z - 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
+  const int rows = gvalid * HW;
+  const size_t row0 = (size_t)b0 * HW;
+  const int chan0 = h * CH;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 0xf;
+  int* flag_mine = pa.flags + (size_t)pair * 4 + h;
+  int* flag_theirs = pa.flags + (size_t)pair * 4 + (h ^ 1);
+  if (tid == 0) *s_bad = 0;
+
+#ifdef MKWS_FRONT_TIMING
+  const long long dbg_c0 = clock64();
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
+#endif
+  // phase A's weight ring is requested before the input is staged (its first fragments arrive during the staging)
+  constexpr int RDA = 4, NTWA = 3;                               // 3 n-tiles x 2 row tiles per run: 24 MFMAs per 3 + 2 operand fragments
+  const int a_groups = (KH + NTWA - 1) / NTWA;
+  const int a_nruns = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
+  const float* a_w = a.WpE + (size_t)(h * KH) * 256 + (size_t)g * 64 + c * 4;
+  f32x4 wqa[RDA][NTWA];
+  stream_mfma_runs_prefetch<NTWA, RDA>(wqa, a_w, (size_t)a.NTe * 256, KH, a_nruns, a.KCe, a_tile_of);
+  for (int jm = wave; jm < a.KCe * MT; jm += NWAVES) {
+    const int j = jm / MT, m = jm - j * MT;
+    const int r = m * 16 + c;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0 + r) * a.Cin + 16 * j + 4 * g);
+    *reinterpret_cast<f32x4*>(s_X + ((size_t)jm * 64 + lane) * 4) = v;
+  }
+  for (int i = tid; i < CH; i += NTHR) { s_scE[i] = a.scE[chan0 + i]; s_shE[i] = a.shE[chan0 + i]; }
+  __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
+#endif
+
+  // ---- phase A: expand, this half's KH n-tiles; every weight fragment feeds both row tiles ----
+  {
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
+    auto xmake = [](const f32x4& v) { return v; };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTWA][MT]) {
+#pragma unroll
+      for (int q = 0; q < NTWA; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < KH) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(s_scE + n), sh = *reinterpret_cast<const f32x4*>(s_shE + n);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 y = acc[q][m] * sc + sh;
+            y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+            if (m * 16 + c >= rows) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(s_E + (size_t)(m * 16 + c) * LDE + n) = y;
+          }
+        }
+      }
+    };
+    stream_mfma_runs<NTWA, RDA, MT, true>(wqa, a_w, (size_t)a.NTe * 256, KH, a_nruns, a.KCe, a_tile_of, xload, xmake, epi);
+  }
+  __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 2] = wall_clock64();
+#endif
+
+  // ---- phase B: depthwise + BN + swish in place, SE means (thread = clip x channel quad of the half) ----
+  for (int i = tid; i < CH; i += NTHR) s_be[i] = a.be[chan0 + i];
+  const int c1_per = (KH + NWAVES - 1) / NWAVES;
+  const int c1_j0 = wave * c1_per;
+  const int c1_kc = (c1_j0 + c1_per <= KH) ? c1_per : (KH > c1_j0 ? KH - c1_j0 : 0);
+  const float* c1_w = a.WrP + (size_t)g * 64 + c * 4 + (size_t)(h * KH + c1_j0) * a.NTR * 256;
+  f32x4 wq1[3][3];
+  stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  {
+    const int Q = CH / 4;
+    for (int task = tid; task < G * Q; task += NTHR) {
+      const int gi = task / Q, q4 = (task - gi * Q) * 4;
+      float* Eg = s_E + (size_t)gi * HW * LDE + q4;
+      f32x4 ein[HW];
+#pragma unroll
+      for (int pix = 0; pix < HW; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(Eg + (size_t)pix * LDE);
+      f32x4 acc[HW];
+#pragma unroll
+      for (int o = 0; o < HW; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) {
+          bool used = false;
+#pragma unroll
+          for (int oh = 0; oh < HT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WT; ++ow) {
+              const int ih = oh - PT + i, iw = ow - PLF + jx;
+              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+            }
+          if (!used) continue;
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + chan0 + q4);
+#pragma unroll
+          for (int oh = 0; oh < HT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WT; ++ow) {
+              const int ih = oh - PT + i, iw = ow - PLF + jx;
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WT + ow] += ein[ih * WT + iw] * wv;
+            }
+        }
+      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + chan0 + q4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + chan0 + q4);
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < HW; ++o) {
+        f32x4 y = acc[o] * sc + sh;
+        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+        if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Eg + (size_t)o * LDE) = y;
+        ssum += y;
+        if (a.dbg_dw && gi < gvalid) *reinterpret_cast<f32x4*>(a.dbg_dw + (row0 + gi * HW + o) * Cexp + chan0 + q4) = y;
+      }
+      *reinterpret_cast<f32x4*>(s_S + (size_t)gi * CH + q4) = ssum * (1.0f / (float)HW);
+    }
+  }
+  __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 3] = wall_clock64();
+#endif
+
+  // ---- phase C1: partial r^T[se, clips] over the half's channels (K split over the waves), then exchange 1 ----
+  constexpr int NTW2 = 3;
+  const int c2_groups = (KH + NTW2 - 1) / NTW2;
+  const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto c2_tile_of = [&](int r) { return (wave + NWAVES * r) * NTW2; };
+  const float* c2_w = a.We2P + (size_t)(h * KH) * 256 + (size_t)g * 64 + c * 4;
+  f32x4 wq2[3][NTW2];
+  {
+    f32x4 acc[3][1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* srow = s_S + (size_t)(c < G ? c : 0) * CH + 16 * c1_j0 + 4 * g;
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
+    stream_mfma_runs_prefetch<NTW2, 3>(wq2, c2_w, (size_t)KCx * 256, KH, c2_runs, a.NTR, c2_tile_of);
+    if (c < G) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+    }
+  }
+  const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
+  __syncthreads();
+  float c1_part = 0.0f;
+  float* xc1_mine = pa.xc1 + ((size_t)pair * 2 + h) * kPairXc1;
+  const float* xc1_theirs = pa.xc1 + ((size_t)pair * 2 + (h ^ 1)) * kPairXc1;
+  if (tid < 48 * G) {
+    if (tid / G < a.se) {
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) c1_part += s_P[(w * 48 + tid / G) * G + (tid % G)];
+    }
+    xc1_mine[tid] = c1_part;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int got = pair_signal_wait(flag_mine, flag_theirs, 1 + (int)xcc);
+    if (got != 1 + (int)xcc) *s_bad = 1;                         // timed out, or the halves sit on different XCDs
+  }
+  __syncthreads();
+  if (tid < 48 * G) {
+    const int n = tid / G, clip = tid - n * G;
+    float v = 0.0f;
+    if (n < a.se) {
+      const float other = __hip_atomic_load(xc1_theirs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = swishf_((h == 0 ? c1_part + other : other + c1_part) + br_pre);
+    }
+    s_R[clip * LDR + n] = v;
+  }
+  __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+#endif
+
+  // ---- phase C2: gate for the half's channels; phase D's weight stream is requested first ----
+  const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0;
+  const float* d_w = a.WpP + (size_t)g * 64 + c * 4 + (size_t)(h * KH) * a.NTp * 256;
+  f32x4 wqd[4][3];
+  if (d_ntw > 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KH);
+  {
+    const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
+#pragma unroll
+      for (int q = 0; q < NTW2; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < KH && c < G) {
+          f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
+          y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
+          *reinterpret_cast<f32x4*>(s_G + (size_t)c * CH + n) = y;
+          if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + chan0 + n) = y;
+        }
+      }
+    };
+    stream_mfma_runs<NTW2, 3, 1, true>(wq2, c2_w, (size_t)KCx * 256, KH, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
+  }
+  __syncthreads();
+#ifdef MKWS_FRONT_TIMING
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
+#endif
+
+  // ---- phase D: partial projection over the half's K; exchange 2; tiles of parity h are finished here ----
+  {
+    const size_t cstride = (size_t)a.NTp * 256;
+    const float* erow[MT];
+    const float* grow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int r = m * 16 + c;
+      erow[m] = s_E + (size_t)r * LDE + 4 * g;
+      grow[m] = s_G + (size_t)(r / HW) * CH + 4 * g;
+    }
+    struct EG { f32x4 e, g; };
+    auto xload = [&](int j, int m) {
+      return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow[m] + 16 * j)};
+    };
+    auto xmake = [](const EG& v) { return v.e * v.g; };
+    const bool finisher = ((wave & 1) == h);                    // tiles wave + NWAVES*q share the wave's parity
+    float* xd_mine = pa.xd + ((size_t)pair * 2 + h) * (kPairXdTiles * 2 * 256);
+    const float* xd_theirs = pa.xd + ((size_t)pair * 2 + (h ^ 1)) * (kPairXdTiles * 2 * 256);
+    auto run = [&](auto ntw_tag) {
+      constexpr int NTW = decltype(ntw_tag)::value;
+      f32x4 acc[NTW > 0 ? NTW : 1][MT];
+#pragma unroll
+      for (int q = 0; q < (NTW > 0 ? NTW : 1); ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (NTW > 0) {
+        stream_mfma<NTW, 4, MT, true>(acc, wqd, d_w, cstride, wave, NWAVES, a.NTp, KH, xload, xmake);
+        if (!finisher) {
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) {
+            const int t = wave + NWAVES * q;
+            if (t < a.NTp) {
+#pragma unroll
+              for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(xd_mine + ((size_t)((t >> 1) * 2 + m) * 64 + lane) * 4) = acc[q][m];
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int got = pair_signal_wait(flag_mine + 2, flag_theirs + 2, 1);
+        if (got != 1) *s_bad = 1;
+      }
+      __syncthreads();
+      if constexpr (NTW > 0) {
+        if (finisher) {
+          const bool bad = *s_bad != 0;
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) {
+            const int t = wave + NWAVES * q;
+            const int n = t * 16 + 4 * g;
+            if (t < a.NTp) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scP + n), sh = *reinterpret_cast<const f32x4*>(a.shP + n);
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                const int r = m * 16 + c;
+                const f32x4 other = ld_agent_x4(xd_theirs + ((size_t)((t >> 1) * 2 + m) * 64 + lane) * 4);
+                if (r < rows) {
+                  f32x4 y = ((h == 0) ? acc[q][m] + other : other + acc[q][m]) * sc + sh;
+                  if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0 + r) * a.Cin + n);
+                  if (bad) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                  *reinterpret_cast<f32x4*>(a.Y + (row0 + r) * a.Cout + n) = y;
+                }
+              }
+            }
+          }
+        }
+      }
+    };
+    if (d_ntw == 0) run(std::integral_constant<int, 0>{});
+    else if (d_ntw == 1) run(std::integral_constant<int, 1>{});
+    else if (d_ntw == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+  }
+#ifdef MKWS_FRONT_TIMING
+  __syncthreads();
+  if (threadIdx.x == 0) { a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64(); a.dbg_t[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - dbg_c0); }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // SE: mean = sums/HW; r = swish(mean @ Wr + br); gate = sigmoid(r @ We + be).
 // Both FCs run on the fp32 MFMA as (weights x 16 clips) tiles with pack_gemm-packed weights, and both are
 // spread over the whole chip (a single block per 16 clips would stream up to 442 KB of SE weights through
@@ -2032,6 +2420,8 @@ struct mkws_embed {
   int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 3a and 4a (where it measured faster), 2 = 2a..4a, 0 = never
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
+  int fuse_pair = 1;               // stride-1 2x2 blocks on mbconv_pair_kernel: two workgroups share 8 clips and split the channels
+  float* pair_xc1 = nullptr; float* pair_xd = nullptr; int* pair_flags = nullptr;   // exchange buffers of the paired kernel
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
   int topH = 0, topW = 0;
@@ -2311,6 +2701,31 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
 #endif
 }
 
+#ifdef MKWS_FRONT_TIMING
+// timing build: per-phase means of the wall_clock64 stamps the whole-block kernels leave (8 per workgroup)
+static unsigned long long* block_timing_buffer() {
+  static unsigned long long* d_bt = nullptr;
+  if (!d_bt) (void)hipMalloc(&d_bt, sizeof(unsigned long long) * 8 * 4096);
+  return d_bt;
+}
+static void report_block_timing(hipStream_t s, const char* stage, unsigned nblk, const unsigned long long* d_bt) {
+  (void)hipStreamSynchronize(s);
+  std::vector<unsigned long long> h((size_t)nblk * 8);
+  (void)hipMemcpy(h.data(), d_bt, h.size() * 8, hipMemcpyDeviceToHost);
+  double ph[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
+  for (size_t i = 0; i < nblk; ++i) {
+    for (int k = 0; k < 6; ++k) ph[k] += (double)(h[8 * i + k + 1] - h[8 * i + k]);
+    if (h[8 * i] < t0) t0 = h[8 * i];
+    if (h[8 * i + 6] > t1) t1 = h[8 * i + 6];
+  }
+  double clk = 0; for (size_t i = 0; i < nblk; ++i) clk += (double)h[8 * i + 7] / ((double)(h[8 * i + 6] - h[8 * i]) / 100.0);
+  fprintf(stderr, "[block-timing] shader clock %.0f MHz\n", clk / nblk);
+  fprintf(stderr, "[block-timing] %s blocks %u: stage %.2f  A %.2f  B %.2f  C1 %.2f  C2 %.2f  D %.2f us; span %.2f us\n", stage, nblk,
+          ph[0] / nblk / 100.0, ph[1] / nblk / 100.0, ph[2] / nblk / 100.0, ph[3] / nblk / 100.0, ph[4] / nblk / 100.0,
+          ph[5] / nblk / 100.0, (double)(t1 - t0) / 100.0);
+}
+#endif
+
 // Whole-block kernel for 4x3 / 2x2 images (blocks 4b..7a): 4 clips per workgroup either way.
 static constexpr int kBlockWaves = 8;
 static size_t block_lds_bytes(const BlockPlan& b) {
@@ -2342,8 +2757,7 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   const dim3 grid((B + G - 1) / G);
   const int ks = b.spec.kernel, st = b.spec.stride;
 #ifdef MKWS_FRONT_TIMING
-  static unsigned long long* d_bt = nullptr;
-  if (!d_bt) (void)hipMalloc(&d_bt, sizeof(unsigned long long) * 8 * 4096);
+  unsigned long long* d_bt = block_timing_buffer();
   a.dbg_t = d_bt;
 #endif
   ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," +
@@ -2361,22 +2775,51 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   }
 #undef MKWS_BLOCK
 #ifdef MKWS_FRONT_TIMING
-  {
-    (void)hipStreamSynchronize(s);
-    std::vector<unsigned long long> h((size_t)grid.x * 8);
-    (void)hipMemcpy(h.data(), d_bt, h.size() * 8, hipMemcpyDeviceToHost);
-    double ph[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
-    for (size_t i = 0; i < grid.x; ++i) {
-      for (int k = 0; k < 6; ++k) ph[k] += (double)(h[8 * i + k + 1] - h[8 * i + k]);
-      if (h[8 * i] < t0) t0 = h[8 * i];
-      if (h[8 * i + 6] > t1) t1 = h[8 * i + 6];
-    }
-    double clk = 0; for (size_t i = 0; i < grid.x; ++i) clk += (double)h[8 * i + 7] / ((double)(h[8 * i + 6] - h[8 * i]) / 100.0);
-    fprintf(stderr, "[block-timing] shader clock %.0f MHz\n", clk / grid.x);
-    fprintf(stderr, "[block-timing] %s blocks %u: stage %.2f  A %.2f  B %.2f  C1 %.2f  C2 %.2f  D %.2f us; span %.2f us\n", stage, grid.x,
-            ph[0] / grid.x / 100.0, ph[1] / grid.x / 100.0, ph[2] / grid.x / 100.0, ph[3] / grid.x / 100.0, ph[4] / grid.x / 100.0,
-            ph[5] / grid.x / 100.0, (double)(t1 - t0) / 100.0);
+  report_block_timing(s, stage, grid.x, d_bt);
+#endif
+}
+
+// Paired whole-block kernel (mbconv_pair_kernel): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a).
+struct PairWs { float* xc1 = nullptr; float* xd = nullptr; int* flags = nullptr; int pairs = 0; };
+static int pair_count(int B) { return ((B + 7) / 8 + 7) / 8 * 8; }          // padded to whole groups of 8 pairs (16 workgroups)
+static size_t pair_ws_floats(int max_batch) { return (size_t)pair_count(max_batch) * (2 * kPairXc1 + 2 * kPairXdTiles * 2 * 256 + 4); }
+bool pair_supported(const BlockPlan& b) {
+  if (!b.has_expand || b.H != 2 || b.W != 2 || b.spec.stride != 1 || (b.spec.kernel != 3 && b.spec.kernel != 5)) return false;
+  if (b.ce % 32 != 0 || b.spec.out_ch % 16 != 0 || b.project.NTtot > 2 * kPairXdTiles || b.se.NTR > 3 || b.se.se > 48) return false;
+  const PairLds L = pair_lds(b.expand.KC, b.ce / 2);
+  return ((size_t)L.U + L.E + L.Z) * sizeof(float) <= 160 * 1024;
+}
+
+void launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const PairWs& ws, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+  PairArgs pa;
+  BlockArgs& a = pa.b;
+  a.X = X; a.Cin = b.spec.in_ch;
+  a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KCe = b.expand.KC; a.NTe = b.expand.NTtot;
+  a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift;
+  a.WrP = b.se.WrP; a.br = b.se.br; a.NTR = b.se.NTR; a.We2P = b.se.WeP; a.be = b.se.be;
+  a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift; a.NTp = b.project.NTtot;
+  a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
+  a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
+  a.B = B; a.Cexp = b.ce; a.se = b.se.se;
+  pa.xc1 = ws.xc1; pa.xd = ws.xd; pa.flags = ws.flags;
+  const PairLds L = pair_lds(b.expand.KC, b.ce / 2);
+  const size_t lds = ((size_t)L.U + L.E + L.Z) * sizeof(float);
+  const dim3 grid(2 * pair_count(B));
+  const int ks = b.spec.kernel;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* d_bt = block_timing_buffer();
+  a.dbg_t = d_bt;
+#endif
+  ProfScope ps(stage, std::string("mbconv_pair_kernel<") + std::to_string(ks) + "," + std::to_string(kBlockWaves) + ">");
+  if (ks == 5) {
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_kernel<5, kBlockWaves>), 160 * 1024) != MKWS_OK) return;
+    hipLaunchKernelGGL((mbconv_pair_kernel<5, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa);
+  } else {
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_kernel<3, kBlockWaves>), 160 * 1024) != MKWS_OK) return;
+    hipLaunchKernelGGL((mbconv_pair_kernel<3, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa);
   }
+#ifdef MKWS_FRONT_TIMING
+  report_block_timing(s, stage, grid.x, d_bt);
 #endif
 }
 
@@ -2556,7 +2999,12 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
-      launch_block(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+      if (em->fuse_pair && pair_supported(b)) {
+        PairWs pw; pw.xc1 = em->pair_xc1; pw.xd = em->pair_xd; pw.flags = em->pair_flags;
+        launch_pair(s, p.c_str(), b, pw, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+      } else {
+        launch_block(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+      }
       if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
       if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
       if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
@@ -2672,6 +3120,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->fuse_block = (max_batch >= 384) ? 2 : 0;
   em->fuse_mid = (max_batch >= 384) ? 1 : 0;
   em->fuse_back = (max_batch >= 384) ? 1 : 0;
+  em->fuse_pair = (max_batch >= 384) ? 1 : 0;
   (void)hipGetDevice(&em->device);
   Packer pk;
   std::vector<float> sc, sh;
@@ -2762,7 +3211,8 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
 
   // workspace
   const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 20480 + 9 * 48;
-  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768;
+  const size_t pair_floats = pair_ws_floats(max_batch);
+  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
   }
@@ -2771,7 +3221,16 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->bufA = w; w += 16000 * mb; em->bufB = w; w += 16000 * mb; em->bufE = w; w += 48000 * mb; em->bufD = w; w += 18720 * mb;
   em->sums = w; w += 1152 * mb; em->gate = w; w += 1152 * mb; em->gap = w; w += 1280 * mb; em->d0 = w; w += 2048 * mb; em->d1 = w; w += 2048 * mb;
   em->splitk_ws = w; em->splitk_floats = 20480 * mb; w += 20480 * mb;
-  em->se_part = w;      // 8 slices x ceil(mb/16) groups x 768 floats <= 384*mb + 6144
+  em->se_part = w; w += 9 * 48 * mb + 8 * 768;      // 8 slices x ceil(mb/16) groups x 768 floats <= 384*mb + 6144
+  {
+    const size_t np = (size_t)pair_count(max_batch);
+    em->pair_xc1 = w; w += np * 2 * kPairXc1;
+    em->pair_xd = w; w += np * 2 * kPairXdTiles * 2 * 256;
+    em->pair_flags = reinterpret_cast<int*>(w); w += np * 4;
+    if (hipMemset(em->pair_flags, 0, np * 4 * sizeof(int)) != hipSuccess) {
+      (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "clearing the pair flags failed");
+    }
+  }
   *out = em;
   return MKWS_OK;
 }
@@ -2801,6 +3260,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
   if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);

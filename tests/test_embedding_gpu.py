@@ -48,26 +48,28 @@ def test_every_stage_matches_oracle(ctx):
 
 
 def test_execution_options_agree(ctx):
-    """fuse_front / fuse_block / fuse_mid are A/B switches: every combination must match the oracle."""
+    """fuse_front / fuse_block / fuse_mid / fuse_back / fuse_pair are A/B switches: every combination must match the oracle."""
     spec = _spec(np.random.default_rng(12), 9)
     x = torch.from_numpy(spec).to(ctx["dev"])
     ref = ctx["oracle"].forward(spec).numpy()
     try:
-        for front, block, mid in ((0, 0, 0), (1, 0, 0), (1, 2, 1), (0, 2, 0), (1, 1, 2), (0, 0, 1)):
+        for front, block, mid, pair in ((0, 0, 0, 0), (1, 0, 0, 1), (1, 2, 1, 1), (0, 2, 0, 0), (1, 1, 2, 1), (0, 0, 1, 0), (1, 2, 1, 0)):
+            ctx["em"].set_option("fuse_pair", pair)
             ctx["em"].set_option("fuse_front", front)
             ctx["em"].set_option("fuse_block", block)
             ctx["em"].set_option("fuse_mid", mid)
             ctx["em"].set_option("fuse_back", 1 if mid != 2 else 0)
             ctx["em"].set_option("fuse_stem", front)
             ctx["em"].set_option("fuse_gap", front)
-            assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block, mid)
+            assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block, mid, pair)
             for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block2a_dw", "block2a_gate", "block2a", "block2b_dw", "block2b", "block3a_gate",
-                         "block3a", "block3b_dw", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6c_dw", "block6c_gate", "block7a", "top", "gap"):
+                         "block3a", "block3b_dw", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6b", "block6c_dw", "block6c_gate", "block6d", "block7a_dw", "block7a", "top", "gap"):
                 taps = {}
                 ctx["oracle"].forward(spec[:3], taps)
                 got = ctx["em"].tap(x[:3], name).cpu().numpy().reshape(taps[name].shape)
-                assert _rel(got, taps[name]) < REL_TOL, (front, block, mid, name)
+                assert _rel(got, taps[name]) < REL_TOL, (front, block, mid, pair, name)
     finally:
+        ctx["em"].set_option("fuse_pair", 1)
         ctx["em"].set_option("fuse_front", 1)
         ctx["em"].set_option("fuse_block", 2)
         ctx["em"].set_option("fuse_mid", 1)

@@ -13,5 +13,5 @@ for v in sys.argv[2:]:
     d=json.load(open(f"{O}/bench_{v}.json"))
     print(v, d["value"], d["ms_per_step"])
     for k,x in d["kernels"].items():
-        if any(t in k for t in ("back","true>","se_")): print("   ", k, x)
+        if any(t in k for t in ("back","true>","se_","pair","2,2,1,8")): print("   ", k, x)
 PY
