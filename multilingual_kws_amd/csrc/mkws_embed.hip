@@ -1822,24 +1822,31 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 #ifdef MKWS_FRONT_TIMING
   if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
 #endif
+  // ---- gate the depthwise output in place, once: phase D then reads ONE operand fragment per row tile and chunk
+  //      (the gate as a second LDS operand plus a multiply per fragment cost the projection's MFMA issue) ----
+  {
+    const int Q = Cexp / 4;
+    for (int i = tid; i < G * HoWo * Q; i += NTHR) {
+      const int ro = i / Q, q4 = (i - ro * Q) * 4;
+      const int clip = ro / HoWo;
+      float* e = s_E + (size_t)(clip * HW + (ro - clip * HoWo)) * LDE + q4;
+      *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)clip * Cexp + q4);
+    }
+  }
+  __syncthreads();
   // ---- phase D: gated project (+ residual): output row r = 16m + c lives in E row (r / HoWo)*HW + r % HoWo ----
   {
     const size_t cstride = (size_t)a.NTp * 256;
     const float* erow[MTO];
-    const float* grow[MTO];
 #pragma unroll
     for (int m = 0; m < MTO; ++m) {
       int r = m * 16 + c;
       if (r >= G * HoWo) r = G * HoWo - 1;                   // padding rows of the last tile: any finite row
       const int clip = r / HoWo;
       erow[m] = s_E + (size_t)(clip * HW + (r - clip * HoWo)) * LDE + 4 * g;
-      grow[m] = s_G + (size_t)clip * Cexp + 4 * g;
     }
-    struct EG { f32x4 e, g; };
-    auto xload = [&](int j, int m) {
-      return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow[m] + 16 * j)};
-    };
-    auto xmake = [](const EG& v) { return v.e * v.g; };
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(erow[m] + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
     auto run = [&](auto ntw_tag) {
       constexpr int NTW = decltype(ntw_tag)::value;
       f32x4 acc[NTW][MTO];
@@ -2170,22 +2177,24 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
 #endif
 
+  // ---- gate the depthwise output in place, once (see mbconv_block_kernel) ----
+  {
+    const int Q = CH / 4;
+    for (int i = tid; i < G * HW * Q; i += NTHR) {
+      const int r = i / Q, q4 = (i - r * Q) * 4;
+      float* e = s_E + (size_t)r * LDE + q4;
+      *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)(r / HW) * CH + q4);
+    }
+  }
+  __syncthreads();
   // ---- phase D: partial projection over the half's K; exchange 2; tiles of parity h are finished here ----
   {
     const size_t cstride = (size_t)a.NTp * 256;
     const float* erow[MT];
-    const float* grow[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int r = m * 16 + c;
-      erow[m] = s_E + (size_t)r * LDE + 4 * g;
-      grow[m] = s_G + (size_t)(r / HW) * CH + 4 * g;
-    }
-    struct EG { f32x4 e, g; };
-    auto xload = [&](int j, int m) {
-      return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow[m] + 16 * j)};
-    };
-    auto xmake = [](const EG& v) { return v.e * v.g; };
+    for (int m = 0; m < MT; ++m) erow[m] = s_E + (size_t)(m * 16 + c) * LDE + 4 * g;
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(erow[m] + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
     const bool finisher = ((wave & 1) == h);                    // tiles wave + NWAVES*q share the wave's parity
     float* xd_mine = pa.xd + ((size_t)pair * 2 + h) * (kPairXdTiles * 2 * 256);
     const float* xd_theirs = pa.xd + ((size_t)pair * 2 + (h ^ 1)) * (kPairXdTiles * 2 * 256);
