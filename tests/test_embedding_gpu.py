@@ -157,3 +157,25 @@ def test_small_batch_handle_plan(ctx):
     assert _rel(out.cpu().numpy(), ctx["em"].forward(x).cpu().numpy()) < REL_TOL
     for b in (1, 3, 5):
         assert torch.equal(small.forward(x[:b]), out[:b]), b
+
+
+def test_whole_block_plan_replays_in_a_hip_graph(ctx):
+    """The paired whole-block kernel hands partial sums between two workgroups through flags in global memory; the consumer
+    resets them, so a captured launch (fixed kernel arguments, no host-side epoch) must replay any number of times."""
+    rng = np.random.default_rng(5)
+    xs = [torch.from_numpy(_spec(rng, 21)).to(ctx["dev"]) for _ in range(3)]      # 21 clips: two full pairs + a ragged one
+    refs = [ctx["em"].forward(x).clone() for x in xs]
+    static_in = xs[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ctx["em"].forward(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ctx["em"].forward(static_in)
+    for k in (0, 1, 2, 1, 0):
+        static_in.copy_(xs[k])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, refs[k]), k
