@@ -1608,14 +1608,15 @@ __host__ __device__ inline BlockLds block_lds(int KCe, int Cexp, int MT, int G, 
 }
 
 // MT = 16-row activation tiles per workgroup: 1 for 2x2 images (4 clips), 3 for 4x3 images (4 clips = 48 rows;
-// every streamed weight fragment then feeds 3 MFMAs per n-tile instead of 1).
+// every streamed weight fragment then feeds 3 MFMAs per n-tile instead of 1); 2 for 4x3 images in handles of at most 512
+// clips (2 clips = 24 of 32 rows: twice the workgroups, so that every CU still gets one).
 template <int KS, int S, int HT, int WT, int MT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_blk[];
   constexpr int NTHR = NWAVES * 64;
   constexpr int HW = HT * WT;
   constexpr int G = MT * 16 / HW;                              // clips per workgroup
-  static_assert(G * HW == MT * 16, "clips must fill the row tiles exactly");
+  static_assert(G >= 1 && G * HW <= MT * 16, "G whole clips per workgroup; rows past G*HW of the last tile are padding (zeroed / never stored)");
   constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1);
   constexpr int HoWo = HoT * WoT;
   constexpr int MTO = (G * HoWo + 15) / 16;                    // output row tiles (stride 2 shrinks them)
@@ -1931,22 +1932,24 @@ __device__ __forceinline__ int pair_signal_wait(int* mine, int* theirs, int valu
 }
 
 struct PairLds { int U, E, Z; };
-__host__ __device__ inline PairLds pair_lds(int KCe, int CH) {
+__host__ __device__ inline PairLds pair_lds(int KCe, int CH, int MT) {
   PairLds l;
-  const int xf = KCe * 2 * 256, sg = 8 * CH * 2;
+  const int xf = KCe * MT * 256, sg = 4 * MT * CH * 2;
   l.U = xf > sg ? xf : sg;
-  l.E = 32 * (CH + 4);
+  l.E = MT * 16 * (CH + 4);
   const int z2 = 16 * 52 + CH;             // A: scale / shift [2][CH];  later r [16][52] + bias [CH];  last 4 words: the error flag
   l.Z = ((2 * CH > z2) ? 2 * CH : z2) + 4;
   return l;
 }
 
-template <int KS, int NWAVES>
+// MT = row tiles per pair: 2 (8 clips) at full batch; 1 (4 clips) for handles whose batch would otherwise leave half of the
+// CUs without a workgroup (max_batch <= 512 on 256 CUs).
+template <int KS, int MT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   extern __shared__ __attribute__((aligned(16))) float s_blk[];
   const BlockArgs& a = pa.b;
   constexpr int NTHR = NWAVES * 64;
-  constexpr int HT = 2, WT = 2, HW = 4, G = 8, MT = 2;
+  constexpr int HT = 2, WT = 2, HW = 4, G = 4 * MT;
   constexpr int PT = KS / 2, PLF = KS / 2;
   constexpr int LDR = 52;
   const int h = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
@@ -1955,8 +1958,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   const int Cexp = a.Cexp, CH = Cexp / 2, LDE = CH + 4;
   const int KH = CH / 16;                                       // this half's 16-channel tiles / K chunks
   const int KCx = Cexp / 16;
-  const PairLds L = pair_lds(a.KCe, CH);
-  float* s_X = s_blk;                                           // U, phase A: [KCe][2][256]
+  const PairLds L = pair_lds(a.KCe, CH, MT);
+  float* s_X = s_blk;                                           // U, phase A: [KCe][MT][256]
   float* s_S = s_blk;                                           // U, later: [8][CH] SE means
   float* s_G = s_S + G * CH;                                    //           [8][CH] gate; C1: [NWAVES][48][8] partials
   float* s_P = s_G;
@@ -2431,6 +2434,8 @@ struct mkws_embed {
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   int fuse_pair = 1;               // stride-1 2x2 blocks on mbconv_pair_kernel: two workgroups share 8 clips and split the channels
   float* pair_xc1 = nullptr; float* pair_xd = nullptr; int* pair_flags = nullptr;   // exchange buffers of the paired kernel
+  int pair_mt = 2;                 // row tiles per pair (2 = 8 clips, 1 = 4 clips): pair_row_tiles(max_batch)
+  int block_mt43 = 3;              // row tiles per workgroup of the 4x3 whole-block kernels (3 = 4 clips, 2 = 2 clips): same rule
   BlockPlan blocks[kNumBlocks];
   GemmLayer top, dense0, dense1, dense2;
   int topH = 0, topW = 0;
@@ -2737,8 +2742,9 @@ static void report_block_timing(hipStream_t s, const char* stage, unsigned nblk,
 
 // Whole-block kernel for 4x3 / 2x2 images (blocks 4b..7a): 4 clips per workgroup either way.
 static constexpr int kBlockWaves = 8;
-static size_t block_lds_bytes(const BlockPlan& b) {
-  const int HW = b.H * b.W, MT = (HW == 4) ? 1 : 3, G = MT * 16 / HW;
+static int block_row_tiles(const BlockPlan& b, int mt43) { return (b.H * b.W == 4) ? 1 : mt43; }
+static size_t block_lds_bytes(const BlockPlan& b, int mt43 = 3) {
+  const int HW = b.H * b.W, MT = block_row_tiles(b, mt43), G = MT * 16 / HW;
   const BlockLds L = block_lds(b.expand.KC, b.ce, MT, G, kBlockWaves);
   return ((size_t)L.U + L.E + L.Z) * sizeof(float);
 }
@@ -2751,7 +2757,7 @@ bool block_supported(const BlockPlan& b, int mode) {
   return (ks == 5 && st == 1) || (ks == 3 && st == 1);
 }
 
-void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
   BlockArgs a;
   a.X = X; a.Cin = b.spec.in_ch;
   a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KCe = b.expand.KC; a.NTe = b.expand.NTtot;
@@ -2761,8 +2767,8 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
-  const int HW = b.H * b.W, MT = (HW == 4) ? 1 : 3, G = MT * 16 / HW;
-  const size_t lds = block_lds_bytes(b);
+  const int HW = b.H * b.W, MT = block_row_tiles(b, mt43), G = MT * 16 / HW;
+  const size_t lds = block_lds_bytes(b, mt43);
   const dim3 grid((B + G - 1) / G);
   const int ks = b.spec.kernel, st = b.spec.stride;
 #ifdef MKWS_FRONT_TIMING
@@ -2774,10 +2780,14 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
 #define MKWS_BLOCK(KS, S, H_, W_, MT_) do { \
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), 160 * 1024) != MKWS_OK) return; \
     hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, a); } while (0)
-  if (b.H == 4 && b.W == 3) {
+  if (b.H == 4 && b.W == 3 && MT == 3) {
     if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 3);
     else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 3);
     else MKWS_BLOCK(5, 2, 4, 3, 3);
+  } else if (b.H == 4 && b.W == 3) {
+    if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 2);
+    else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 2);
+    else MKWS_BLOCK(5, 2, 4, 3, 2);
   } else {
     if (ks == 5) MKWS_BLOCK(5, 1, 2, 2, 1);
     else MKWS_BLOCK(3, 1, 2, 2, 1);
@@ -2789,13 +2799,16 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, const fl
 }
 
 // Paired whole-block kernel (mbconv_pair_kernel): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a).
-struct PairWs { float* xc1 = nullptr; float* xd = nullptr; int* flags = nullptr; int pairs = 0; };
-static int pair_count(int B) { return ((B + 7) / 8 + 7) / 8 * 8; }          // padded to whole groups of 8 pairs (16 workgroups)
-static size_t pair_ws_floats(int max_batch) { return (size_t)pair_count(max_batch) * (2 * kPairXc1 + 2 * kPairXdTiles * 2 * 256 + 4); }
+struct PairWs { float* xc1 = nullptr; float* xd = nullptr; int* flags = nullptr; int mt = 2; };
+static int pair_count(int B, int mt) { const int G = 4 * mt; return ((B + G - 1) / G + 7) / 8 * 8; }   // padded to whole groups of 8 pairs (16 workgroups)
+static size_t pair_ws_floats(int max_batch, int mt) { return (size_t)pair_count(max_batch, mt) * (2 * kPairXc1 + 2 * kPairXdTiles * 2 * 256 + 4); }
+// Row tiles per pair for a handle: 8 clips per pair fill the chip from ~1024 clips up; smaller handles use 4-clip pairs so
+// that twice as many workgroups exist (512 clips: 256 instead of 128).  Per handle, like every other plan decision.
+static int pair_row_tiles(int max_batch) { return (2 * ((max_batch + 3) / 4) <= device_cu_count()) ? 1 : 2; }   // 4-clip pairs while they still fit in one round
 bool pair_supported(const BlockPlan& b) {
   if (!b.has_expand || b.H != 2 || b.W != 2 || b.spec.stride != 1 || (b.spec.kernel != 3 && b.spec.kernel != 5)) return false;
   if (b.ce % 32 != 0 || b.spec.out_ch % 16 != 0 || b.project.NTtot > 2 * kPairXdTiles || b.se.NTR > 3 || b.se.se > 48) return false;
-  const PairLds L = pair_lds(b.expand.KC, b.ce / 2);
+  const PairLds L = pair_lds(b.expand.KC, b.ce / 2, 2);
   return ((size_t)L.U + L.E + L.Z) * sizeof(float) <= 160 * 1024;
 }
 
@@ -2811,22 +2824,21 @@ void launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const Pai
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
   pa.xc1 = ws.xc1; pa.xd = ws.xd; pa.flags = ws.flags;
-  const PairLds L = pair_lds(b.expand.KC, b.ce / 2);
+  const PairLds L = pair_lds(b.expand.KC, b.ce / 2, ws.mt);
   const size_t lds = ((size_t)L.U + L.E + L.Z) * sizeof(float);
-  const dim3 grid(2 * pair_count(B));
+  const dim3 grid(2 * pair_count(B, ws.mt));
   const int ks = b.spec.kernel;
 #ifdef MKWS_FRONT_TIMING
   unsigned long long* d_bt = block_timing_buffer();
   a.dbg_t = d_bt;
 #endif
-  ProfScope ps(stage, std::string("mbconv_pair_kernel<") + std::to_string(ks) + "," + std::to_string(kBlockWaves) + ">");
-  if (ks == 5) {
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_kernel<5, kBlockWaves>), 160 * 1024) != MKWS_OK) return;
-    hipLaunchKernelGGL((mbconv_pair_kernel<5, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa);
-  } else {
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_kernel<3, kBlockWaves>), 160 * 1024) != MKWS_OK) return;
-    hipLaunchKernelGGL((mbconv_pair_kernel<3, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa);
-  }
+  ProfScope ps(stage, std::string("mbconv_pair_kernel<") + std::to_string(ks) + "," + std::to_string(ws.mt) + "," + std::to_string(kBlockWaves) + ">");
+#define MKWS_PAIR(KS, MT_) do { \
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_kernel<KS, MT_, kBlockWaves>), 160 * 1024) != MKWS_OK) return; \
+    hipLaunchKernelGGL((mbconv_pair_kernel<KS, MT_, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa); } while (0)
+  if (ks == 5) { if (ws.mt == 2) MKWS_PAIR(5, 2); else MKWS_PAIR(5, 1); }
+  else         { if (ws.mt == 2) MKWS_PAIR(3, 2); else MKWS_PAIR(3, 1); }
+#undef MKWS_PAIR
 #ifdef MKWS_FRONT_TIMING
   report_block_timing(s, stage, grid.x, d_bt);
 #endif
@@ -3009,10 +3021,10 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
       if (em->fuse_pair && pair_supported(b)) {
-        PairWs pw; pw.xc1 = em->pair_xc1; pw.xd = em->pair_xd; pw.flags = em->pair_flags;
+        PairWs pw; pw.xc1 = em->pair_xc1; pw.xd = em->pair_xd; pw.flags = em->pair_flags; pw.mt = em->pair_mt;
         launch_pair(s, p.c_str(), b, pw, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
       } else {
-        launch_block(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+        launch_block(s, p.c_str(), b, em->block_mt43, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
       }
       if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
       if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
@@ -3130,6 +3142,8 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->fuse_mid = (max_batch >= 384) ? 1 : 0;
   em->fuse_back = (max_batch >= 384) ? 1 : 0;
   em->fuse_pair = (max_batch >= 384) ? 1 : 0;
+  em->pair_mt = pair_row_tiles(max_batch);
+  em->block_mt43 = (em->pair_mt == 1) ? 2 : 3;
   (void)hipGetDevice(&em->device);
   Packer pk;
   std::vector<float> sc, sh;
@@ -3220,7 +3234,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
 
   // workspace
   const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 20480 + 9 * 48;
-  const size_t pair_floats = pair_ws_floats(max_batch);
+  const size_t pair_floats = pair_ws_floats(max_batch, em->pair_mt);
   const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
@@ -3232,7 +3246,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->splitk_ws = w; em->splitk_floats = 20480 * mb; w += 20480 * mb;
   em->se_part = w; w += 9 * 48 * mb + 8 * 768;      // 8 slices x ceil(mb/16) groups x 768 floats <= 384*mb + 6144
   {
-    const size_t np = (size_t)pair_count(max_batch);
+    const size_t np = (size_t)pair_count(max_batch, em->pair_mt);
     em->pair_xc1 = w; w += np * 2 * kPairXc1;
     em->pair_xd = w; w += np * 2 * kPairXdTiles * 2 * 256;
     em->pair_flags = reinterpret_cast<int*>(w); w += np * 4;

@@ -92,6 +92,16 @@ def test_consumers_on_device(tmp_path):
     settings = input_data.standard_microspeech_model_settings(3)
     one = emb.predict(input_data.file2spec(settings, files[7])[None])
     assert np.allclose(vec[7], one[0], rtol=1e-5, atol=1e-6)                        # batching does not change a clip's vector
+    # the vectors themselves, against the oracle chain (WAV decode on the host, C micro-frontend, fp32 EfficientNet-B0)
+    from multilingual_kws_amd import weights
+    from oracle.efficientnet_oracle import EmbeddingOracle
+    from oracle.frontend_oracle import FrontendOracle
+    pick = [0, 7, 23]
+    audio = np.stack([input_data.decode_wav(open(files[i], "rb").read(), 16000)[0] for i in pick]).astype(np.float32)
+    ref_spec = FrontendOracle().run_batch_f32(audio)
+    assert np.array_equal(np.stack([input_data.file2spec(settings, files[i]) for i in pick]), ref_spec)      # frontend: bit-exact
+    ref = EmbeddingOracle(weights.synthetic_blob()).forward(ref_spec).numpy()
+    assert np.abs(vec[pick] - ref).max() / np.abs(ref).max() < 1e-4
     r = dfl.cluster_and_sort(np.array(files), emb, seed=1, n_train=15, n_clusters=3)
     assert len(r["sorted_clips"]) == 9 and np.all(np.diff(r["distances"]) >= 0)
     try:

@@ -159,6 +159,28 @@ def test_small_batch_handle_plan(ctx):
         assert torch.equal(small.forward(x[:b]), out[:b]), b
 
 
+def test_mid_batch_handle_plan(ctx):
+    """A 512-clip handle (BASELINE configs[3]) keeps the whole-block kernels but pairs 4 clips instead of 8 (2x2 images) and
+    gives a workgroup 2 clips instead of 4 (4x3 images), so that every CU still gets a workgroup: taps of the paired blocks and the embedding against the oracle, batch-size invariance, B = 512."""
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    rng = np.random.default_rng(22)
+    spec = _spec(rng, 512)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    mid = EmbeddingModel(ctx["blob"], max_batch=512)
+    out = mid.forward(x)
+    idx = np.arange(0, 512, 41)
+    ref = ctx["oracle"].forward(spec[idx]).numpy()
+    assert torch.isfinite(out).all() and _rel(out[idx].cpu().numpy(), ref) < REL_TOL
+    taps = {}
+    ctx["oracle"].forward(spec[:5], taps)
+    for name in ("block4b", "block4c_dw", "block5a", "block5b_gate", "block5c", "block6a_dw", "block6a",        # 2 clips per workgroup
+                 "block6b_dw", "block6b_gate", "block6b", "block6d", "block7a_gate", "block7a"):              # 4 clips per pair
+        got = mid.tap(x[:5], name).cpu().numpy().reshape(taps[name].shape)
+        assert _rel(got, taps[name]) < REL_TOL, name
+    for b in (1, 3, 4, 5, 37):
+        assert torch.equal(mid.forward(x[:b]), out[:b]), b
+
+
 def test_whole_block_plan_replays_in_a_hip_graph(ctx):
     """The paired whole-block kernel hands partial sums between two workgroups through flags in global memory; the consumer
     resets them, so a captured launch (fixed kernel arguments, no host-side epoch) must replay any number of times."""
