@@ -151,6 +151,9 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "fuse_pair" (default 1 for handles with max_batch >= 384, else 0; needs "fuse_block"): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a) run on
  *                 the PAIRED whole-block kernel: two workgroups on two CUs of one XCD share 8 clips and split the expanded channels,
  *                 so each CU streams half of the block's weights; two small in-kernel exchanges through L2.  0 = one workgroup per 4 clips.
+ *                 mkws_embed_create turns it on only after a probe launch has shown that workgroups b and b^8 share an XCD on this device.
+ *                 Handles with max_batch <= 512 pair 4 clips (and give the 4x3-image whole-block kernels 2 clips per workgroup) so that
+ *                 every CU still gets a workgroup.
  *   "fuse_back" (default 1 for handles with max_batch >= 384, else 0): blocks 2a, 2b, 3b run squeeze-excite + gated projection as
  *                 ONE kernel behind the fused expand+depthwise kernel (the clip's depthwise output is staged in LDS once);
  *                 0 = se_reduce + se_expand + projection GEMM launches.

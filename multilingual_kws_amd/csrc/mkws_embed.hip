@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <new>
 #include <set>
@@ -1931,6 +1932,13 @@ __device__ __forceinline__ int pair_signal_wait(int* mine, int* theirs, int valu
   return got;
 }
 
+// Probe for mkws_embed_create: every workgroup records the XCC it runs on (see pair_layout_ok).
+__global__ void xcc_probe_kernel(int* out) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(xcc & 0xf);
+}
+
 struct PairLds { int U, E, Z; };
 __host__ __device__ inline PairLds pair_lds(int KCe, int CH, int MT) {
   PairLds l;
@@ -2805,6 +2813,33 @@ static size_t pair_ws_floats(int max_batch, int mt) { return (size_t)pair_count(
 // Row tiles per pair for a handle: 8 clips per pair fill the chip from ~1024 clips up; smaller handles use 4-clip pairs so
 // that twice as many workgroups exist (512 clips: 256 instead of 128).  Per handle, like every other plan decision.
 static int pair_row_tiles(int max_batch) { return (2 * ((max_batch + 3) / 4) <= device_cu_count()) ? 1 : 2; }   // 4-clip pairs while they still fit in one round
+// The paired kernel wants blocks b and b ^ 8 on ONE XCD (their exchange goes through that XCD's L2 without agent-scope
+// cache maintenance).  True for the round-robin dispatch of an 8-XCD device in SPX mode; checked once per device instead of
+// assumed (other partition modes / future parts), and the kernel re-checks every pair at run time.
+static bool pair_layout_ok() {
+  static std::mutex mu;
+  static std::map<int, bool> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(dev);
+  if (it != cache.end()) return it->second;
+  bool ok = false;
+  const int n = 4 * device_cu_count() / 16 * 16;
+  int* d = nullptr;
+  if (n >= 16 && hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(int)) == hipSuccess) {
+    std::vector<int> h(n, -1);
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, nullptr, d);
+    if (hipMemcpy(h.data(), d, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+      ok = true;
+      for (int b = 0; b < n; ++b) ok = ok && h[b] >= 0 && h[b] == h[b ^ 8];
+    }
+    (void)hipFree(d);
+  }
+  cache[dev] = ok;
+  return ok;
+}
+
 bool pair_supported(const BlockPlan& b) {
   if (!b.has_expand || b.H != 2 || b.W != 2 || b.spec.stride != 1 || (b.spec.kernel != 3 && b.spec.kernel != 5)) return false;
   if (b.ce % 32 != 0 || b.spec.out_ch % 16 != 0 || b.project.NTtot > 2 * kPairXdTiles || b.se.NTR > 3 || b.se.se > 48) return false;
@@ -3141,7 +3176,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->fuse_block = (max_batch >= 384) ? 2 : 0;
   em->fuse_mid = (max_batch >= 384) ? 1 : 0;
   em->fuse_back = (max_batch >= 384) ? 1 : 0;
-  em->fuse_pair = (max_batch >= 384) ? 1 : 0;
+  em->fuse_pair = (max_batch >= 384 && pair_layout_ok()) ? 1 : 0;
   em->pair_mt = pair_row_tiles(max_batch);
   em->block_mt43 = (em->pair_mt == 1) ? 2 : 3;
   (void)hipGetDevice(&em->device);
