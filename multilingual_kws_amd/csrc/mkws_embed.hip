@@ -2832,7 +2832,7 @@ static bool pair_layout_ok() {
     hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, nullptr, d);
     if (hipMemcpy(h.data(), d, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
       ok = true;
-      for (int b = 0; b < n; ++b) ok = ok && h[b] >= 0 && h[b] == h[b ^ 8];
+      for (int b = 0; b < n; ++b) ok = ok && h[b] >= 0 && h[b] == h[b & 7];    // the XCD is a function of (linear id mod 8) only
     }
     (void)hipFree(d);
   }
