@@ -43,8 +43,8 @@ CONFIGS = ("embed", "frontend", "finetune", "stream")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=CONFIGS, default="embed", help="BASELINE.json configuration (default: configs[2])")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default: the config's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
