@@ -46,6 +46,18 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// Four at once, written on the vector so that the multiply / add around the two transcendentals become packed instructions
+// (v_pk_mul_f32 / v_pk_add_f32: half the VALU issue of the scalar form; MFMA and VALU work serialize on a SIMD,
+// tools/microbench/mfma_valu_overlap.hip, so every VALU instruction saved in an epilogue is MFMA time gained).  Same operations
+// in the same order as sigmoidf_ / swishf_: bit-identical.
+__device__ __forceinline__ f32x4 sigmoid4_(f32x4 v) {
+  f32x4 t = v * -1.4426950408889634f;
+  t.x = __builtin_amdgcn_exp2f(t.x); t.y = __builtin_amdgcn_exp2f(t.y); t.z = __builtin_amdgcn_exp2f(t.z); t.w = __builtin_amdgcn_exp2f(t.w);
+  t = t + 1.0f;
+  t.x = __builtin_amdgcn_rcpf(t.x); t.y = __builtin_amdgcn_rcpf(t.y); t.z = __builtin_amdgcn_rcpf(t.z); t.w = __builtin_amdgcn_rcpf(t.w);
+  return t;
+}
+__device__ __forceinline__ f32x4 swish4_(f32x4 v) { return v * sigmoid4_(v); }
 // value the optimizer cannot see through (stops loop-invariant hoisting of cheap index arithmetic into spilled registers)
 __device__ __forceinline__ int opaque_(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -56,6 +68,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case ACT_SIGMOID: return sigmoidf_(v);
     default: return v;
   }
+}
+__device__ __forceinline__ f32x4 apply_act4(f32x4 v, int act) {
+  if (act == ACT_SWISH) return swish4_(v);
+  if (act == ACT_SIGMOID) return sigmoid4_(v);
+  v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ spe
       }
     }
     f32x4 y = acc * sc + sh;
-    y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+    y = swish4_(y);
     *reinterpret_cast<f32x4*>(out + pix * 32 + q * 4) = y;
   }
 }
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc += wk[i * 3 + j] * in0[i * TW + j];
       f32x4 y = acc * sc + sh;
-      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+      y = swish4_(y);
       *reinterpret_cast<f32x4*>(s_E + ((size_t)(oh + 1) * EW + (ow + 1)) * C + q * 4) = y;
     }
   }
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc += *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + j) * C) * wkd[i * 3 + j];
       f32x4 y = acc * sc + sh;
-      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+      y = swish4_(y);
       *reinterpret_cast<f32x4*>(s_D + (size_t)pix * LDD + q * 4) = y;
       ssum += y;
     }
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
       const size_t m = (size_t)(m0 + mt * 16 + c);
       f32x4 y = acc[mt][nt] * sc + sh;
       if (a.act != ACT_NONE) {
-        y.x = apply_act(y.x, a.act); y.y = apply_act(y.y, a.act); y.z = apply_act(y.z, a.act); y.w = apply_act(y.w, a.act);
+        y = apply_act4(y, a.act);
       }
       if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
       if (a.pool4) {
@@ -449,7 +467,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)m * ldp + n);
     for (int z = 1; z < splitk; ++z) v += *reinterpret_cast<const f32x4*>(part + ((size_t)z * M + m) * ldp + n);
     f32x4 y = v * *reinterpret_cast<const f32x4*>(scale + n) + *reinterpret_cast<const f32x4*>(shift + n);
-    if (act != ACT_NONE) { y.x = apply_act(y.x, act); y.y = apply_act(y.y, act); y.z = apply_act(y.z, act); y.w = apply_act(y.w, act); }
+    if (act != ACT_NONE) y = apply_act4(y, act);
     if (R) y += *reinterpret_cast<const f32x4*>(R + (size_t)m * ldr + n);
     *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + n) = y;
   }
@@ -494,7 +512,7 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X, co
         }
       }
       f32x4 y = acc * sc + sh;
-      y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+      y = swish4_(y);
       *reinterpret_cast<f32x4*>(yout + (size_t)p * C) = y;
       ssum += y;
       oh += dh; ow += dwo;
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
           for (int nt = 0; nt < NT; ++nt) {
             if (nt < nt_valid) {
               f32x4 y = acc[nt] * scr[nt] + shr[nt];
-              y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+              y = swish4_(y);
               *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + nt * 16 + 4 * g) = y;
             }
           }
@@ -710,12 +728,12 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
           if (nt < nt_valid) {
             if (row0 < rows) {
               f32x4 y = acc0[q] * scr[q] + shr[q];
-              y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+              y = swish4_(y);
               *reinterpret_cast<f32x4*>(s_E + (size_t)row0 * LDE + nt * 16 + 4 * g) = y;
             }
             if (row1 < rows) {
               f32x4 y = acc1[q] * scr[q] + shr[q];
-              y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+              y = swish4_(y);
               *reinterpret_cast<f32x4*>(s_E + (size_t)row1 * LDE + nt * 16 + 4 * g) = y;
             }
           }
@@ -783,7 +801,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #pragma unroll
         for (int o = 0; o < SEG; ++o) {
           f32x4 y = acc[o] * sc + sh;
-          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+          y = swish4_(y);
           *reinterpret_cast<f32x4*>(yout + (size_t)o * a.Cexp) = y;
           ssum += y;
         }
@@ -850,7 +868,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #pragma unroll
       for (int o = 0; o < HoT * WoT; ++o) {
         f32x4 y = acc[o] * sc + sh;
-        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+        y = swish4_(y);
         *reinterpret_cast<f32x4*>(yout + (size_t)o * a.Cexp) = y;
         ssum += y;
       }
@@ -1135,7 +1153,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
         const int row = rt * 16 + c;
         if (row < rows) {
           f32x4 y = acc * *reinterpret_cast<const f32x4*>(s_scE + ntl * 16 + 4 * g) + *reinterpret_cast<const f32x4*>(s_scE + CC + ntl * 16 + 4 * g);
-          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+          y = swish4_(y);
           *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + ntl * 16 + 4 * g) = y;
         }
       }
@@ -1186,7 +1204,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
 #pragma unroll
         for (int o = 0; o < SEG; ++o) {
           f32x4 y = acc[o] * scd + shd;
-          y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+          y = swish4_(y);
           *reinterpret_cast<f32x4*>(dout + (size_t)o * LDD) = y;
         }
       }
@@ -1677,7 +1695,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             f32x4 y = acc[q][m] * sc + sh;
-            y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+            y = swish4_(y);
             if (m * 16 + c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(s_E + (size_t)(m * 16 + c) * LDE + n) = y;
           }
@@ -1743,7 +1761,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 #pragma unroll
       for (int o = 0; o < HoWo; ++o) {
         f32x4 y = acc[o] * sc + sh;
-        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+        y = swish4_(y);
         if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(Eg + (size_t)o * LDE) = y;
         ssum += y;
@@ -1811,7 +1829,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
         const int n = (t0 + q) * 16 + 4 * g;
         if (t0 + q < KCx && c < G) {
           f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
-          y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
+          y = sigmoid4_(y);
           *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
           if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + n) = y;
         }
@@ -2028,7 +2046,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             f32x4 y = acc[q][m] * sc + sh;
-            y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+            y = swish4_(y);
             if (m * 16 + c >= rows) y = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(s_E + (size_t)(m * 16 + c) * LDE + n) = y;
           }
@@ -2090,7 +2108,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
 #pragma unroll
       for (int o = 0; o < HW; ++o) {
         f32x4 y = acc[o] * sc + sh;
-        y.x = swishf_(y.x); y.y = swishf_(y.y); y.z = swishf_(y.z); y.w = swishf_(y.w);
+        y = swish4_(y);
         if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(Eg + (size_t)o * LDE) = y;
         ssum += y;
@@ -2175,7 +2193,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
         const int n = (t0 + q) * 16 + 4 * g;
         if (t0 + q < KH && c < G) {
           f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
-          y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
+          y = sigmoid4_(y);
           *reinterpret_cast<f32x4*>(s_G + (size_t)c * CH + n) = y;
           if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + chan0 + n) = y;
         }
@@ -2374,7 +2392,7 @@ __global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict_
       const int n = t * 16 + 4 * g;
       if (t < t1 && n < C && b0 + c < B) {
         f32x4 y = acc + bias[u];
-        y.x = sigmoidf_(y.x); y.y = sigmoidf_(y.y); y.z = sigmoidf_(y.z); y.w = sigmoidf_(y.w);
+        y = sigmoid4_(y);
         *reinterpret_cast<f32x4*>(gate + (size_t)(b0 + c) * C + n) = y;
       }
     }
