@@ -310,23 +310,31 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   // Operand pointers are CLAMPED instead of predicated (rows past M re-read row M-1, tiles past NTtot
   // re-read the last tile; their results are never stored), so the K loop has no per-load branches.
   // Only the K tail (K % 16 == 8: lane groups 2,3 of the last chunk) needs a zero, done by a select.
-  const float* xrow[MT];
-  const float* grow[MT];
+  // Addressing: buffer descriptors of the three operands (uniform), a 32-bit byte offset per lane, and the K-chunk offset in an
+  // SGPR (buffer_load_dwordx4 v, voffset, rsrc, soffset offen): the steady state issues NO VALU instruction per load.  With
+  // per-lane 64-bit pointers every load cost a v_lshl_add_u64 / v_mad_u64_u32, and VALU work takes MFMA issue time
+  // (tools/microbench/mfma_valu_overlap.hip).
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? a.gate : a.X), 0, 0x7fffffff, 0x00020000);
+  unsigned xoff[MT], goff[MT];
   bool rowok[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + mt * 16 + c;
     rowok[mt] = m < a.M;
     const int mm = rowok[mt] ? m : (a.M - 1);
-    xrow[mt] = a.X + (size_t)mm * a.ldx + 4 * g;
-    grow[mt] = GATE ? (a.gate + (size_t)(mm / a.HW) * a.K + 4 * g) : nullptr;
+    xoff[mt] = (unsigned)(((size_t)mm * a.ldx + 4 * g) * sizeof(float));
+    goff[mt] = GATE ? (unsigned)(((size_t)(mm / a.HW) * a.K + 4 * g) * sizeof(float)) : 0u;
   }
-  const float* wrow[NT];
+  const unsigned woff = (unsigned)((g * 64 + c * 4) * sizeof(float));
+  unsigned wtile[NT];                              // uniform: byte offset of this block's n-tiles inside a K chunk
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int t = (nt0 + nt < a.NTtot) ? nt0 + nt : a.NTtot - 1;
-    wrow[nt] = a.Wp + ((size_t)t * 4 + g) * 64 + c * 4;
+    wtile[nt] = (unsigned)t * 1024u;
   }
+  const unsigned wchunk = (unsigned)a.NTtot * 1024u;   // bytes per K chunk of the packed weights
   // K range of this block (split-K over blockIdx.z)
   int jbeg = 0, jend = a.KC;
   if (a.splitk > 1) {
@@ -354,13 +362,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   constexpr int XW = GATE ? 2 * MT : MT;        // the SE gate rides the ring as raw fragments next to X: multiplying it in at
   f32x4 xq[D][XW], wq[D][NT];                   // load time would touch the fresh registers and force an immediate wait
   auto load = [&](int j, f32x4 (&xv)[XW], f32x4 (&wv)[NT]) {
+    const unsigned kx = 64u * (unsigned)j;         // 16 floats of K per chunk
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      xv[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + 16 * j);
-      if (GATE) xv[MT + mt] = *reinterpret_cast<const f32x4*>(grow[mt] + 16 * j);
+      xv[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, xoff[mt], kx, 0));
+      if (GATE) xv[MT + mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rG, goff[mt], kx, 0));
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const f32x4*>(wrow[nt] + (size_t)j * a.NTtot * 256);
+    for (int nt = 0; nt < NT; ++nt) wv[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, woff, wtile[nt] + wchunk * (unsigned)j, 0));
   };
   auto compute = [&](const f32x4 (&xv)[XW], const f32x4 (&wv)[NT]) {
     f32x4 x[MT];
@@ -882,11 +891,29 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 #endif
 }
 
+// Where a weight stream comes from.  The stream helpers below only call ld(idx) (idx = float index of the fragment: tile and
+// chunk offsets) through wload(), so a kernel chooses the addressing:
+//   const float*  a per-lane pointer; hipcc addresses every load with a 64-bit VALU add (v_lshl_add_u64)
+//   WBuf  a UNIFORM base as a buffer descriptor + a 32-bit per-lane byte offset; the fragment offset rides in an SGPR
+//         (buffer_load_dwordx4 v, voffset, rsrc, soffset offen): NO VALU instruction per load.  That matters because VALU and MFMA
+//         work of a SIMD serialize (tools/microbench/mfma_valu_overlap.hip).  idx must be wave-uniform: kernels that use WBuf take
+//         their wave index through readfirstlane.
+struct WBuf {
+  __amdgpu_buffer_rsrc_t r; unsigned voff;
+  __device__ __forceinline__ WBuf(const float* base, unsigned lane_off_floats)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)), voff(lane_off_floats * 4u) {}
+  __device__ __forceinline__ f32x4 ld(size_t idx) const {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (unsigned)(idx * 4u), 0));
+  }
+};
+__device__ __forceinline__ f32x4 wload(const float* p, size_t idx) { return *reinterpret_cast<const f32x4*>(p + idx); }
+__device__ __forceinline__ f32x4 wload(const WBuf& b, size_t idx) { return b.ld(idx); }
+
 // acc[q][m] += sum_j W(j, tile0 + tstride*q) . xfrag(j, m) for j in [0, KC): weight fragments via a
 // DEPTH-deep register ring (prologue / branch-free steady state / drain, so hipcc emits counted vmcnt
 // waits); every weight fragment feeds MT activation tiles.
-template <int NTWR, int DEPTH>
-__device__ __forceinline__ void stream_mfma_prefetch(f32x4 (&wq)[DEPTH][NTWR], const float* __restrict__ wlane, size_t chunk_stride, int tile0,
+template <int NTWR, int DEPTH, typename WP>
+__device__ __forceinline__ void stream_mfma_prefetch(f32x4 (&wq)[DEPTH][NTWR], WP wlane, size_t chunk_stride, int tile0,
                                                      int tstride, int ntiles, int KC) {
   if (KC >= DEPTH) {
 #pragma unroll
@@ -895,7 +922,7 @@ __device__ __forceinline__ void stream_mfma_prefetch(f32x4 (&wq)[DEPTH][NTWR], c
       for (int q = 0; q < NTWR; ++q) {
         int t = tile0 + tstride * q;
         if (t >= ntiles) t = ntiles - 1;
-        wq[d][q] = *reinterpret_cast<const f32x4*>(wlane + (size_t)t * 256 + (size_t)d * chunk_stride);
+        wq[d][q] = wload(wlane, (size_t)t * 256 + (size_t)d * chunk_stride);
       }
   }
 }
@@ -904,19 +931,19 @@ __device__ __forceinline__ void stream_mfma_prefetch(f32x4 (&wq)[DEPTH][NTWR], c
 // their latency hides behind other work); wq is the caller's ring (NTWR >= NTW columns).
 // Activation fragments come from LDS in two steps so that they can be software-pipelined: xload(j, m) issues the
 // ds_reads of chunk j (called one chunk ahead), xmake(raw) turns them into the MFMA operand at use.
-template <int NTW, int DEPTH, int MT, bool PRE, int NTWR, typename XL, typename XM>
-__device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[DEPTH][NTWR], const float* __restrict__ wlane, size_t chunk_stride,
+template <int NTW, int DEPTH, int MT, bool PRE, int NTWR, typename WP, typename XL, typename XM>
+__device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[DEPTH][NTWR], WP wlane, size_t chunk_stride,
                                             int tile0, int tstride, int ntiles, int KC, XL xload, XM xmake) {
-  const float* wp[NTW];
+  size_t wt[NTW];
 #pragma unroll
   for (int q = 0; q < NTW; ++q) {
     int t = tile0 + tstride * q;
     if (t >= ntiles) t = ntiles - 1;             // clamped: result unused
-    wp[q] = wlane + (size_t)t * 256;
+    wt[q] = (size_t)t * 256;
   }
   auto load = [&](int j, f32x4 (&wv)[NTWR]) {
 #pragma unroll
-    for (int q = 0; q < NTW; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wp[q] + (size_t)j * chunk_stride);
+    for (int q = 0; q < NTW; ++q) wv[q] = wload(wlane, wt[q] + (size_t)j * chunk_stride);
   };
   // fragment buffers alternate with the ring slot (distinct registers, so the next chunk's ds_reads really
   // issue before this chunk's MFMAs instead of waiting for their operands to die)
@@ -1508,8 +1535,8 @@ struct BlockArgs {
 // [tile_of(r), +NTW), each KC chunks long.  The weight ring keeps DEPTH chunks in flight ACROSS runs, so a
 // run's first loads are already issued while the previous run computes (no per-run latency bubble).  The
 // epilogue must not issue global loads (they would drain the in-order vmcnt ring): constants come from LDS.
-template <int NTW, int DEPTH, typename TOF>
-__device__ __forceinline__ void stream_mfma_runs_prefetch(f32x4 (&wq)[DEPTH][NTW], const float* __restrict__ wlane, size_t chunk_stride, int ntiles,
+template <int NTW, int DEPTH, typename WP, typename TOF>
+__device__ __forceinline__ void stream_mfma_runs_prefetch(f32x4 (&wq)[DEPTH][NTW], WP wlane, size_t chunk_stride, int ntiles,
                                                           int nruns, int KC, TOF tile_of) {
   if (nruns * KC >= DEPTH) {
     int lr = 0, lj = 0;
@@ -1520,15 +1547,15 @@ __device__ __forceinline__ void stream_mfma_runs_prefetch(f32x4 (&wq)[DEPTH][NTW
       for (int q = 0; q < NTW; ++q) {
         int t = t0 + q;
         if (t >= ntiles) t = ntiles - 1;
-        wq[d][q] = *reinterpret_cast<const f32x4*>(wlane + (size_t)t * 256 + (size_t)lj * chunk_stride);
+        wq[d][q] = wload(wlane, (size_t)t * 256 + (size_t)lj * chunk_stride);
       }
       if (++lj == KC) { lj = 0; ++lr; }
     }
   }
 }
 
-template <int NTW, int DEPTH, int MT, bool PRE, typename XL, typename XM, typename TOF, typename EPI>
-__device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const float* __restrict__ wlane, size_t chunk_stride, int ntiles, int nruns,
+template <int NTW, int DEPTH, int MT, bool PRE, typename WP, typename XL, typename XM, typename TOF, typename EPI>
+__device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], WP wlane, size_t chunk_stride, int ntiles, int nruns,
                                                  int KC, TOF tile_of, XL xload, XM xmake, EPI epilogue) {
   const int T = nruns * KC;
   if (T <= 0) return;
@@ -1540,7 +1567,7 @@ __device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], const 
     for (int q = 0; q < NTW; ++q) {
       int t = t0 + q;
       if (t >= ntiles) t = ntiles - 1;
-      wv[q] = *reinterpret_cast<const f32x4*>(wlane + (size_t)t * 256 + (size_t)lj * chunk_stride);
+      wv[q] = wload(wlane, (size_t)t * 256 + (size_t)lj * chunk_stride);
     }
     if (++lj == KC) { lj = 0; ++lr; }
   };
@@ -1653,8 +1680,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   float* s_shE = s_scE + Cexp;
   float* s_R = s_scE;                                          // Z, phase B onwards: [16][LDR], then SE expand bias [Cexp]
   float* s_be = s_R + 16 * LDR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: tile / chunk offsets of the weight streams stay on the scalar unit (WBuf)
   const int g = lane >> 4, c = lane & 15;
+  const unsigned loff = (unsigned)(g * 64 + c * 4);                 // this lane's float4 inside a packed weight fragment
   const int b0 = blockIdx.x * G;
   const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
   const int rows_in = gvalid * HW, rows_out = gvalid * HoWo;
@@ -1703,7 +1732,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
       }
     };
     f32x4 wqa[4][NTW];
-    stream_mfma_runs<NTW, 4, MT, false>(wqa, a.WpE + (size_t)g * 64 + c * 4, (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
+    stream_mfma_runs<NTW, 4, MT, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
   }
   __syncthreads();
 
@@ -1718,7 +1747,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   const int c1_per = (KCx + NWAVES - 1) / NWAVES;
   const int c1_j0 = wave * c1_per;
   const int c1_kc = (c1_j0 + c1_per <= KCx) ? c1_per : (KCx > c1_j0 ? KCx - c1_j0 : 0);
-  const float* c1_w = a.WrP + (size_t)g * 64 + c * 4 + (size_t)c1_j0 * a.NTR * 256;
+  const WBuf c1_w(a.WrP + (size_t)c1_j0 * a.NTR * 256, loff);
   f32x4 wq1[3][3];
   stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   {
@@ -1789,7 +1818,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
     auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
     auto xmake = [](const f32x4& v) { return v; };
     if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
-    stream_mfma_runs_prefetch<NTW2, 3>(wq2, a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);   // C2's stream
+    stream_mfma_runs_prefetch<NTW2, 3>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);   // C2's stream
     if (c < G) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
@@ -1816,7 +1845,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   // ---- phase C2: gate^T[Cexp, clips] = We2^T . r^T, tiles over waves (columns c >= G are don't-care) ----
   // phase D's weight stream is requested first: this wave owns project tiles wave, wave + NWAVES, ...
   const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0;
-  const float* d_w = a.WpP + (size_t)g * 64 + c * 4;
+  const WBuf d_w(a.WpP, loff);
   f32x4 wqd[4][3];
   if (d_ntw > 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);
   {
@@ -1835,7 +1864,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
         }
       }
     };
-    stream_mfma_runs<NTW2, 3, 1, true>(wq2, a.We2P + (size_t)g * 64 + c * 4, (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
+    stream_mfma_runs<NTW2, 3, 1, true>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
   }
   __syncthreads();
 
@@ -1995,7 +2024,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   float* s_R = s_scE;                                           // Z, later: r [8][LDR], SE expand bias [CH]
   float* s_be = s_R + 16 * LDR;
   volatile int* s_bad = reinterpret_cast<volatile int*>(s_scE + L.Z - 4);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: wave-dependent tile / chunk offsets stay on the scalar unit
   const int g = lane >> 4, c = lane & 15;
   const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
   const int rows = gvalid * HW;
@@ -2017,7 +2047,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   const int a_groups = (KH + NTWA - 1) / NTWA;
   const int a_nruns = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
   auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
-  const float* a_w = a.WpE + (size_t)(h * KH) * 256 + (size_t)g * 64 + c * 4;
+  const unsigned loff = (unsigned)(g * 64 + c * 4);                 // this lane's float4 inside a packed weight fragment
+  const WBuf a_w(a.WpE + (size_t)(h * KH) * 256, loff);
   f32x4 wqa[RDA][NTWA];
   stream_mfma_runs_prefetch<NTWA, RDA>(wqa, a_w, (size_t)a.NTe * 256, KH, a_nruns, a.KCe, a_tile_of);
   for (int jm = wave; jm < a.KCe * MT; jm += NWAVES) {
@@ -2065,7 +2096,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   const int c1_per = (KH + NWAVES - 1) / NWAVES;
   const int c1_j0 = wave * c1_per;
   const int c1_kc = (c1_j0 + c1_per <= KH) ? c1_per : (KH > c1_j0 ? KH - c1_j0 : 0);
-  const float* c1_w = a.WrP + (size_t)g * 64 + c * 4 + (size_t)(h * KH + c1_j0) * a.NTR * 256;
+  const WBuf c1_w(a.WrP + (size_t)(h * KH + c1_j0) * a.NTR * 256, loff);
   f32x4 wq1[3][3];
   stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   {
@@ -2127,7 +2158,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   const int c2_groups = (KH + NTW2 - 1) / NTW2;
   const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
   auto c2_tile_of = [&](int r) { return (wave + NWAVES * r) * NTW2; };
-  const float* c2_w = a.We2P + (size_t)(h * KH) * 256 + (size_t)g * 64 + c * 4;
+  const WBuf c2_w(a.We2P + (size_t)(h * KH) * 256, loff);
   f32x4 wq2[3][NTW2];
   {
     f32x4 acc[3][1];
@@ -2180,7 +2211,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
 
   // ---- phase C2: gate for the half's channels; phase D's weight stream is requested first ----
   const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0;
-  const float* d_w = a.WpP + (size_t)g * 64 + c * 4 + (size_t)(h * KH) * a.NTp * 256;
+  const WBuf d_w(a.WpP + (size_t)(h * KH) * a.NTp * 256, loff);
   f32x4 wqd[4][3];
   if (d_ntw > 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KH);
   {
