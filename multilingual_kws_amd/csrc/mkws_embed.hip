@@ -140,7 +140,8 @@ __global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restri
   float* s_mean = reinterpret_cast<float*>(s_red + 64);  // [32] means, [16] r, [32] gate
   float* s_r = s_mean + C;
   float* s_gate = s_r + 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform by construction: keeps wave-dependent offsets / branches on the scalar unit
   const size_t b = blockIdx.x;
   const float* img = spec + b * H * W;
   for (int i = tid; i < TH * TW; i += NTHR) {
@@ -572,7 +573,8 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   f32x4* s_red = reinterpret_cast<f32x4*>(s_front + ((size_t)a.G * HW + 1) * LDE);   // [256], after the zero row
   float* s_sumc = reinterpret_cast<float*>(s_red + 256);                              // [G][CC] channel sums (SE squeeze)
   float* s_wd = s_sumc + (size_t)a.G * CC;                                           // [KS*KS][CC] depthwise taps (big-image mode)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform by construction: keeps wave-dependent offsets / branches on the scalar unit
   const int g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * a.G;
   const int gvalid = (a.B - b0 < a.G) ? (a.B - b0) : a.G;
@@ -1103,7 +1105,8 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
   float* s_mean = s_mid + GM::oMean;                             // [G][CEXP]
   float* s_gate = s_mid + GM::oGate;                             // [G][CEXP]
   float* s_r = s_mid + GM::oR;                                   // [G][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform by construction: keeps wave-dependent offsets / branches on the scalar unit
   const int g = lane >> 4, c = lane & 15;
   const int b0 = blockIdx.x * G;
   const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
@@ -1261,7 +1264,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
   constexpr int MTW = (MTO + NWP - 1) / NWP;                     // row tiles per wave
   constexpr int PD = (KC >= 8) ? 8 : 4;                          // depth of the projection weight ring
   const int ntp = wave % NTP, rlp = wave / NTP;
-  const float* p_w = a.WpP + (size_t)g * 64 + c * 4;
+  const WBuf p_w(a.WpP, (unsigned)(g * 64 + c * 4));
   f32x4 wqp[PD][1];
   if (rlp < NWP) stream_mfma_prefetch<1, PD>(wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC);
   if (a.dbg_dw) {
@@ -1394,7 +1397,8 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_back_kernel(BackArgs a) {
   float* s_gate = s_mean + CEXP;                                 // [CEXP]
   float* s_r = s_gate + CEXP;                                    // [16]
   float* s_scr = s_r + 16;                                       // [max(RS*CEXP, NTHR)]: column-sum partials, then SE partials
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform by construction: keeps wave-dependent offsets / branches on the scalar unit
   const int g = lane >> 4, c = lane & 15;
   const size_t b = blockIdx.x;
   const float* Dc = a.D + b * HOWO * CEXP;
@@ -1420,7 +1424,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_back_kernel(BackArgs a) {
   const float br_pre = (tid < 16 && tid < a.se) ? a.br[tid] : 0.0f;
   const float be_pre = (tid < CEXP) ? a.be[tid] : 0.0f;
   const int ntp = wave % NTP, rlp = wave / NTP;
-  const float* p_w = a.WpP + (size_t)g * 64 + c * 4;
+  const WBuf p_w(a.WpP, (unsigned)(g * 64 + c * 4));
   f32x4 wqp[PD][1];
   if (rlp < NWP) stream_mfma_prefetch<1, PD>(wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC);
 #pragma unroll
@@ -2335,7 +2339,8 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict_
                                                         float* __restrict__ part, int B, int C, int KCr, int nslices) {
   __shared__ float s_part[4 * NTR * 256];
   const int b0 = blockIdx.x * 16, z = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform by construction: keeps wave-dependent offsets / branches on the scalar unit
   const int g = lane >> 4, c = lane & 15;
   const int per = (KCr + nslices - 1) / nslices;
   const int j0 = z * per;
@@ -2382,7 +2387,8 @@ __global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict_
   constexpr int LDR = NTR * 16 + 4;
   __shared__ __attribute__((aligned(16))) float s_r[16 * LDR];
   const int b0 = blockIdx.x * 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform by construction: keeps wave-dependent offsets / branches on the scalar unit
   const int g = lane >> 4, c = lane & 15;
   for (int t = tid; t < NTR * 256; t += 256) {
     const int n = t >> 4, clip = t & 15;
