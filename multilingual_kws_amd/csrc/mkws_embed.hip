@@ -4,19 +4,23 @@
 // multilingual_kws/train_multilingual_embedding.py:58-83 (cut at "dense_2" by
 // multilingual_kws/embedding/transfer_learning.py:36-43).  Layer table: SURVEY.md Appendix B.
 //
-// Layout: activations NHWC fp32, viewed as row-major [M = B*H*W, C].  Kernels:
-//   stem_kernel      3x3 s2 conv on the 1-channel spectrogram (+Rescaling, Normalization, BN, swish)
-//   pw_gemm_kernel   every 1x1 conv and Dense layer: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) GEMM
-//                    computed TRANSPOSED (weights are the MFMA "A" operand, activation rows the "B"
-//                    operand) so each lane ends up with 4 consecutive output channels of one row and
-//                    stores a float4.  Operands go HBM/L2 -> registers directly as float4: the
-//                    reduction index k is permuted (lane group g of chunk j owns k = 16j+4g..+3) and
-//                    the weights are pre-packed on the host in exactly that order, so no LDS
-//                    transpose is needed.  Epilogue fuses BN scale/shift (or bias), activation,
-//                    the SE excite gate on the input side, and the residual add.
-//   dw_kernel        depthwise kxk (explicit TF/Keras padding) + BN + swish + SE squeeze sums
-//   se_kernel        SE reduce FC + swish + expand FC + sigmoid -> per-(clip, channel) gate
-//   mean_hw_kernel   global average pool
+// Layout: activations NHWC fp32, viewed as row-major [M = B*H*W, C].  Every contraction with K >= 16 runs on the exact-fp32
+// MFMA (v_mfma_f32_16x16x4_f32) TRANSPOSED: packed weights are the "A" operand, activation rows the "B" operand, so a lane ends
+// up with 4 consecutive output channels of one row (float4 stores).  The reduction index is permuted (lane group g of chunk j
+// owns k = 16j+4g..+3) and the weights are pre-packed on the host in exactly that order: operands go memory -> registers as
+// float4 without an LDS transpose.  Kernels (DESIGN.md section 4 has the measured numbers):
+//   stem_block1a_kernel   stem conv + whole block 1a, one clip per workgroup            (B >= 1)
+//   mbconv_front_kernel   expand (MFMA) + BN + swish -> LDS -> depthwise + BN + swish, SE sums        (blocks 2a, 2b, 3b; all
+//                         blocks of small-batch handles)
+//   mbconv_back_kernel    SE FCs + gated projection + BN (+ residual) behind the front kernel         (2a, 2b, 3b)
+//   mbconv_mid_kernel     whole block, big images, depthwise output resident in LDS                  (3a, 4a)
+//   mbconv_block_kernel   whole block, 4x3 / 2x2 images, 4 (or 2) clips per workgroup                 (4b .. 6a)
+//   mbconv_pair_kernel    whole block, 2x2 images, two workgroups of one XCD share the clips and split the channels (6b .. 7a)
+//   pw_gemm_kernel        top conv (+ global average pool), dense layers; every 1x1 conv of the unfused / small-batch paths;
+//                         epilogue = BN or bias, activation, SE gate on the input side, residual
+//   se_reduce / se_expand, dw_kernel, stem_kernel, mean_hw_kernel, splitk_reduce_kernel: the unfused chain (parity taps, small batches)
+// Streaming loops address their operands as buffer descriptor + per-lane 32-bit offset + SGPR chunk offset (WBuf): VALU and MFMA
+// work serialize on a SIMD of this part, so the MFMA loops contain no VALU instructions.
 #include "mkws_common.h"
 #include "mkws_embed_arch.h"
 

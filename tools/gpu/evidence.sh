@@ -4,9 +4,11 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/evidence
 rm -rf $O; mkdir -p $O
+if [ -z "$SKIP_BENCH" ]; then
 for c in embed frontend finetune stream; do
   timeout 400 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; echo "bench $c rc=$?"
 done
+fi
 export TMPDIR=/tmp
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch -o f -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_fetch.log 2>&1 )
