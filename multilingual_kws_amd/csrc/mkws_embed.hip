@@ -2647,6 +2647,9 @@ struct TileChoice { int MT, NT, splitk; };
 TileChoice pick_tile(int M, int NTtot, int KC) {
   if (NTtot == 1) return {2, 1, 1};
   auto waves = [&](int mt, int nt, int sk) { return (long)((M + 16 * mt - 1) / (16 * mt)) * ((NTtot + nt - 1) / nt) * sk; };
+  // dense layers of a 1024-clip handle: 1 x 4 tiles put two waves on every SIMD (N = 2048) and measured 154 us for the three
+  // layers against 170 us with 2 x 4 (+ 1 x 2 for dense_2) once the K loop was free of VALU instructions (tools/gpu/sweep1024.sh)
+  if (NTtot >= 64 && KC >= 64 && M >= 1024 && M < 2048 && waves(1, 4, 1) >= 1024) return {1, 4, 1};
   if (NTtot >= 64 && KC >= 64 && waves(2, 4, 1) >= 1024) return {2, 4, 1};
   if (waves(2, 2, 1) >= kWantWaves) return {2, 2, 1};
   if (waves(1, 2, 1) >= kWantWaves) return {1, 2, 1};
