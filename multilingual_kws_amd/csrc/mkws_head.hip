@@ -16,7 +16,7 @@ namespace mkws {
 
 constexpr int kMaxHidden = 32;
 constexpr int kMaxClasses = 8;
-constexpr int kGradSplits = 8;
+constexpr int kGradSplits = 32;     // row slices of the dW1 partial sums: 4 x 32 workgroups (8 slices left 7 of 8 CUs idle: 64 us per step)
 
 struct HeadDims { int in, hid, cls; };
 
@@ -26,15 +26,17 @@ struct HeadDims { int in, hid, cls; };
 constexpr int kHeadsPerLaunch = 64;
 struct HeadTable { const float* p[kHeadsPerLaunch]; };
 
-template <bool TRAIN, bool MULTI = false>
+// R rows per wave: every W1 value a lane loads is used for R rows (the 50-head serving launch re-read each head's 73 KB of W1 once
+// per row and wave: 121 us per 256 windows).  The arithmetic of one row does not depend on R, so the results are bit-identical.
+template <bool TRAIN, bool MULTI = false, int R = 1>
 __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float* __restrict__ params, const float* __restrict__ x,
                                                         const int32_t* __restrict__ labels, int B, float* __restrict__ probs,
                                                         float* __restrict__ hbuf /*[B,hid]*/, float* __restrict__ dz /*[B,cls]*/,
                                                         float* __restrict__ dpre /*[B,hid]*/, float* __restrict__ rowstat /*[B,2]*/,
                                                         HeadTable table = HeadTable()) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= B) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= B) return;
   if (MULTI) {                      // head blockIdx.y: its own parameters, its own [B, cls] slab of the output
     params = table.p[blockIdx.y];
     probs += (size_t)blockIdx.y * B * d.cls;
@@ -43,24 +45,54 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float*
   const float* b1 = W1 + (size_t)d.in * d.hid;
   const float* W2 = b1 + d.hid;
   const float* b2 = W2 + (size_t)d.hid * d.cls;
-  float acc[kMaxHidden];
+  float accs[R][kMaxHidden];
 #pragma unroll
-  for (int j = 0; j < kMaxHidden; ++j) acc[j] = 0.0f;
-  const float* xr = x + (size_t)row * d.in;
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < kMaxHidden; ++j) accs[r][j] = 0.0f;
+  const float* xr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) xr[r] = x + (size_t)((row0 + r < B) ? row0 + r : B - 1) * d.in;
+  const bool even = (d.hid & 1) == 0;              // rows of W1 are then 8-byte aligned: float2 loads
+  constexpr int KU = (R == 1) ? 4 : 2;             // k steps in flight (their loads issue together)
+#pragma unroll KU
   for (int k = lane; k < d.in; k += 64) {
-    const float xv = xr[k];
+    float xv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) xv[r] = xr[r][k];
     const float* w = W1 + (size_t)k * d.hid;
+    float wv[kMaxHidden];
+    if (even) {
+      const float2* w2 = reinterpret_cast<const float2*>(w);
 #pragma unroll
-    for (int j = 0; j < kMaxHidden; ++j)
-      if (j < d.hid) acc[j] += xv * w[j];
-  }
+      for (int j = 0; j < kMaxHidden / 2; ++j) {
+        const float2 t = (2 * j < d.hid) ? w2[j] : make_float2(0.0f, 0.0f);
+        wv[2 * j] = t.x; wv[2 * j + 1] = t.y;
+      }
+    } else {
 #pragma unroll
-  for (int j = 0; j < kMaxHidden; ++j) {
-    if (j < d.hid) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+      for (int j = 0; j < kMaxHidden; ++j) wv[j] = (j < d.hid) ? w[j] : 0.0f;
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < kMaxHidden; ++j)
+        if (j < d.hid) accs[r][j] += xv[r] * wv[j];
   }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < kMaxHidden; ++j) {
+      if (j < d.hid) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) accs[r][j] += __shfl_xor(accs[r][j], off, 64);
+      }
+    }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+  const int row = row0 + r;
+  const float (&acc)[kMaxHidden] = accs[r];
+  if (row >= B) break;
   // every lane now holds the full sums; lane 0 finishes the row
   if (lane == 0) {
     float h[kMaxHidden];
@@ -127,6 +159,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float*
       }
     }
   }
+  }
 }
 
 // partial dW1: block (kx, split) handles 256 input features x rows [split*rows_per, +rows_per)
@@ -170,30 +203,37 @@ __global__ __launch_bounds__(256) void head_grad_finish_kernel(HeadDims d, const
                                                                float* __restrict__ grads, float* __restrict__ stats) {
   const int nW1 = d.in * d.hid;
   const int nsmall = d.hid + d.hid * d.cls + d.cls;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nW1) {
-    float s = 0.0f;
-    for (int p = 0; p < splits; ++p) s += partial[(size_t)p * nW1 + i];
-    grads[i] = s;
-  } else if (i < nW1 + nsmall) {
-    const int t = i - nW1;
-    float s = 0.0f;
-    if (t < d.hid) {                                  // db1[j] = sum_b dpre[b][j]
-      for (int b = 0; b < B; ++b) s += dpre[(size_t)b * d.hid + t];
-    } else if (t < d.hid + d.hid * d.cls) {            // dW2[j][c] = sum_b h[b][j] dz[b][c]
-      const int j = (t - d.hid) / d.cls, c = (t - d.hid) % d.cls;
-      for (int b = 0; b < B; ++b) s += hbuf[(size_t)b * d.hid + j] * dz[(size_t)b * d.cls + c];
-    } else {                                          // db2[c]
-      const int c = t - d.hid - d.hid * d.cls;
-      for (int b = 0; b < B; ++b) s += dz[(size_t)b * d.cls + c];
+  const int nbW1 = (nW1 + 255) / 256;
+  if ((int)blockIdx.x < nbW1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nW1) {
+      float s = 0.0f;
+      for (int p = 0; p < splits; ++p) s += partial[(size_t)p * nW1 + i];
+      grads[i] = s;
     }
-    grads[i] = s;
-  } else if (i < nW1 + nsmall + 2) {
-    const int t = i - nW1 - nsmall;
-    float s = 0.0f;
-    for (int b = 0; b < B; ++b) s += rowstat[2 * b + t];
-    grads[i] = s;
-    if (stats) stats[t] = s;
+    return;
+  }
+  // the nsmall + 2 sums over the batch: one WAVE each, lanes stride the rows, fixed-order butterfly (one THREAD each walked
+  // the 512 rows with dependent loads: 181 us per step)
+  const int t = ((int)blockIdx.x - nbW1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= nsmall + 2) return;
+  float s = 0.0f;
+  if (t < d.hid) {                                    // db1[j] = sum_b dpre[b][j]
+    for (int b = lane; b < B; b += 64) s += dpre[(size_t)b * d.hid + t];
+  } else if (t < d.hid + d.hid * d.cls) {              // dW2[j][c] = sum_b h[b][j] dz[b][c]
+    const int j = (t - d.hid) / d.cls, c = (t - d.hid) % d.cls;
+    for (int b = lane; b < B; b += 64) s += hbuf[(size_t)b * d.hid + j] * dz[(size_t)b * d.cls + c];
+  } else if (t < nsmall) {                            // db2[c]
+    const int c = t - d.hid - d.hid * d.cls;
+    for (int b = lane; b < B; b += 64) s += dz[(size_t)b * d.cls + c];
+  } else {                                            // loss sum, correct count
+    for (int b = lane; b < B; b += 64) s += rowstat[2 * b + (t - nsmall)];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) {
+    grads[nW1 + t] = s;
+    if (t >= nsmall && stats) stats[t - nsmall] = s;
   }
 }
 
@@ -330,7 +370,7 @@ int mkws_heads_forward(mkws_head* const* heads, int n_heads, const float* d_emb,
     const int n = (n_heads - h0 < kHeadsPerLaunch) ? n_heads - h0 : kHeadsPerLaunch;
     HeadTable t;
     for (int i = 0; i < kHeadsPerLaunch; ++i) t.p[i] = heads[h0 + (i < n ? i : 0)]->params;
-    hipLaunchKernelGGL((head_rows_kernel<false, true>), dim3((B + 3) / 4, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb,
+    hipLaunchKernelGGL((head_rows_kernel<false, true, 4>), dim3((B + 15) / 16, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb,
                        nullptr, B, d_probs + (size_t)h0 * B * d.cls, nullptr, nullptr, nullptr, nullptr, t);
   }
   MKWS_HIP(hipGetLastError());
@@ -348,7 +388,8 @@ int mkws_head_loss_grad(mkws_head* hd, const float* d_emb, const int32_t* d_labe
   const int splits = (B + rows_per - 1) / rows_per;
   hipLaunchKernelGGL(head_dw1_partial_kernel, dim3((hd->d.in + 255) / 256, splits), dim3(256), 0, s, hd->d, d_emb, hd->dpre, B, rows_per, hd->partial);
   const int total = hd->nparams + 2;
-  hipLaunchKernelGGL(head_grad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, hd->d, hd->partial, splits, hd->hbuf, hd->dz, hd->dpre,
+  const int fin_blocks = (hd->d.in * hd->d.hid + 255) / 256 + (total - hd->d.in * hd->d.hid + 3) / 4;
+  hipLaunchKernelGGL(head_grad_finish_kernel, dim3(fin_blocks), dim3(256), 0, s, hd->d, hd->partial, splits, hd->hbuf, hd->dz, hd->dpre,
                      hd->rowstat, B, hd->grads, d_stats);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
