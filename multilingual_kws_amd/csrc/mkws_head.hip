@@ -88,26 +88,30 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float*
         for (int off = 32; off >= 1; off >>= 1) accs[r][j] += __shfl_xor(accs[r][j], off, 64);
       }
     }
+  // every lane now holds the full sums.  The row is finished IN PARALLEL: lane j takes hidden unit j (one tanhf per lane instead
+  // of hid serial ones on lane 0), the logits are butterfly sums over the lanes, every lane evaluates the softmax of the few classes.
+  const bool hj = lane < d.hid;
+  const float b1l = hj ? b1[lane] : 0.0f;
+  float w2l[kMaxClasses];
+#pragma unroll
+  for (int c = 0; c < kMaxClasses; ++c) w2l[c] = (hj && c < d.cls) ? W2[lane * d.cls + c] : 0.0f;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-  const int row = row0 + r;
-  const float (&acc)[kMaxHidden] = accs[r];
-  if (row >= B) break;
-  // every lane now holds the full sums; lane 0 finishes the row
-  if (lane == 0) {
-    float h[kMaxHidden];
+    const int row = row0 + r;
+    if (row >= B) break;
+    float a = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kMaxHidden; ++j) h[j] = (j < d.hid) ? tanhf(acc[j] + b1[j]) : 0.0f;
+    for (int j = 0; j < kMaxHidden; ++j) a = (lane == j) ? accs[r][j] : a;
+    const float h = hj ? tanhf(a + b1l) : 0.0f;
     float z[kMaxClasses];
     float zmax = -3.0e38f;
 #pragma unroll
     for (int c = 0; c < kMaxClasses; ++c) {
       if (c < d.cls) {
-        float s = 0.0f;
+        float p = h * w2l[c];
 #pragma unroll
-        for (int j = 0; j < kMaxHidden; ++j)
-          if (j < d.hid) s += h[j] * W2[j * d.cls + c];
-        z[c] = s + b2[c];
+        for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+        z[c] = p + b2[c];
         zmax = fmaxf(zmax, z[c]);
       } else {
         z[c] = 0.0f;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float*
       esum += e[c];
     }
     const float inv = 1.0f / esum;
-    if (probs) {
+    if (probs && lane == 0) {
 #pragma unroll
       for (int c = 0; c < kMaxClasses; ++c)
         if (c < d.cls) probs[(size_t)row * d.cls + c] = e[c] * inv;
@@ -136,29 +140,24 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float*
           if (c == y) zy = z[c];
         }
       }
-      // -log softmax(z)[y], computed from the logits (what Keras does for a softmax-activated output)
-      rowstat[2 * row] = (logf(esum) + zmax) - zy;
-      rowstat[2 * row + 1] = (best == y) ? 1.0f : 0.0f;
+      if (lane == 0) {
+        // -log softmax(z)[y], computed from the logits (what Keras does for a softmax-activated output)
+        rowstat[2 * row] = (logf(esum) + zmax) - zy;
+        rowstat[2 * row + 1] = (best == y) ? 1.0f : 0.0f;
+      }
       const float invB = 1.0f / (float)B;
-      float dzl[kMaxClasses];
+      float s = 0.0f;
 #pragma unroll
       for (int c = 0; c < kMaxClasses; ++c) {
-        dzl[c] = (c < d.cls) ? (e[c] * inv - (c == y ? 1.0f : 0.0f)) * invB : 0.0f;
-        if (c < d.cls) dz[(size_t)row * d.cls + c] = dzl[c];
+        const float dzc = (c < d.cls) ? (e[c] * inv - (c == y ? 1.0f : 0.0f)) * invB : 0.0f;
+        if (c < d.cls && lane == 0) dz[(size_t)row * d.cls + c] = dzc;
+        s += dzc * w2l[c];
       }
-#pragma unroll
-      for (int j = 0; j < kMaxHidden; ++j) {
-        if (j < d.hid) {
-          float s = 0.0f;
-#pragma unroll
-          for (int c = 0; c < kMaxClasses; ++c)
-            if (c < d.cls) s += dzl[c] * W2[j * d.cls + c];
-          hbuf[(size_t)row * d.hid + j] = h[j];
-          dpre[(size_t)row * d.hid + j] = s * (1.0f - h[j] * h[j]);
-        }
+      if (hj) {
+        hbuf[(size_t)row * d.hid + lane] = h;
+        dpre[(size_t)row * d.hid + lane] = s * (1.0f - h * h);
       }
     }
-  }
   }
 }
 
