@@ -377,6 +377,10 @@ def main():
             per_kernel, emb_ms = embed_roofline(em, spec, B, args.profile_reps, arch, extra=None if cfg == "stream" else fe_entry)
             whole.update({"embedding_ms": round(emb_ms, 4),
                           "tflops": round(units_per_step * arch.EMBED_FLOPS_PER_CLIP / (ms_per_step * 1e-3) / 1e12, 2)})
+            if cfg in ("embed", "finetune"):
+                # what the per-kernel table (frontend + embedding launches) does NOT cover: augmentation, SpecAugment, the head's
+                # loss / gradient / update kernels, collectives.  Round 2 found 290 us hiding here in the fine-tune config.
+                whole["other_ms"] = round(max(0.0, ms_per_step - fe_ms - emb_ms), 4)
         roof, kernels = roofline_of(per_kernel)
         if cfg == "stream":
             one = audio[:1].contiguous()
