@@ -97,6 +97,18 @@ def test_import_savedmodel_by_variable_name(tmp_path):
     assert np.array_equal(rd.tensor(small, verify_crc=True), blob[[t for t in weights.manifest() if t["name"] == "stem_bn/gamma"][0]["offset"]:][:32])
 
 
+def test_import_savedmodel_from_several_data_shards(tmp_path):
+    """BundleHeaderProto.num_shards > 1: every entry names its shard; the reader opens variables.data-0000i-of-0000n lazily."""
+    blob = weights.synthetic_blob(seed=4, calibrate=False)
+    path = _write_model(tmp_path, blob, with_full_names=True, num_shards=3, block_entries=8)
+    assert sorted(os.listdir(os.path.join(path, "variables"))) == ["variables.data-00000-of-00003", "variables.data-00001-of-00003",
+                                                                     "variables.data-00002-of-00003", "variables.index"]
+    assert np.array_equal(ci.import_savedmodel(path), blob)
+    os.remove(os.path.join(path, "variables", "variables.data-00002-of-00003"))
+    with pytest.raises((ci.CheckpointFormatError, OSError)):
+        ci.import_savedmodel(path)
+
+
 def test_import_savedmodel_positionally_when_names_are_missing(tmp_path):
     blob = weights.synthetic_blob(seed=4, calibrate=False)
     path = _write_model(tmp_path, blob, with_full_names=False)

@@ -96,25 +96,28 @@ def write_table(path, items, block_entries=7, restart_interval=4, compress=False
     open(path, "wb").write(bytes(f))
 
 
-def write_bundle(prefix, tensors, object_graph=None, **table_kw):
-    """tensors: {checkpoint key: ndarray}; object_graph: serialized TrackableObjectGraph bytes (optional)."""
-    data = bytearray()
-    items = {b"": field_varint(1, 1) + field_varint(2, 0) + field_bytes(3, field_varint(1, 1))}
+def write_bundle(prefix, tensors, object_graph=None, num_shards=1, **table_kw):
+    """tensors: {checkpoint key: ndarray}; object_graph: serialized TrackableObjectGraph bytes (optional); num_shards > 1 deals the
+    tensors round-robin over data shards (what tf.train.Checkpoint writes from several devices)."""
+    data = [bytearray() for _ in range(num_shards)]
+    items = {b"": field_varint(1, num_shards) + field_varint(2, 0) + field_bytes(3, field_varint(1, 1))}
 
-    def entry(dtype, shape, off, size, crc):
+    def entry(dtype, shape, shard, off, size, crc):
         shp = b"".join(field_bytes(2, field_varint(1, d)) for d in shape)
-        return field_varint(1, dtype) + field_bytes(2, shp) + field_varint(3, 0) + field_varint(4, off) + field_varint(5, size) + field_fixed32(6, crc)
-    for k in sorted(tensors):
+        return field_varint(1, dtype) + field_bytes(2, shp) + field_varint(3, shard) + field_varint(4, off) + field_varint(5, size) + field_fixed32(6, crc)
+    for i, k in enumerate(sorted(tensors)):
         a = np.ascontiguousarray(tensors[k])
         raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
-        items[k.encode()] = entry(DT[a.dtype], a.shape, len(data), len(raw), mask_crc(crc32c(raw)) if len(raw) < (1 << 16) else 0)
-        data += raw
+        sh = i % num_shards
+        items[k.encode()] = entry(DT[a.dtype], a.shape, sh, len(data[sh]), len(raw), mask_crc(crc32c(raw)) if len(raw) < (1 << 16) else 0)
+        data[sh] += raw
     if object_graph is not None:
         lens = varint(len(object_graph))
         raw = lens + struct.pack("<I", mask_crc(crc32c(struct.pack("<Q", len(object_graph))))) + object_graph
-        items[b"_CHECKPOINTABLE_OBJECT_GRAPH"] = entry(7, (), len(data), len(raw), 0)
-        data += raw
-    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+        items[b"_CHECKPOINTABLE_OBJECT_GRAPH"] = entry(7, (), 0, len(data[0]), len(raw), 0)
+        data[0] += raw
+    for sh in range(num_shards):
+        open(prefix + f".data-{sh:05d}-of-{num_shards:05d}", "wb").write(bytes(data[sh]))
     write_table(prefix + ".index", items, **table_kw)
 
 
