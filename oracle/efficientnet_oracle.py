@@ -116,6 +116,49 @@ class EmbeddingOracle:
     def _swish(x):
         return x * torch.sigmoid(x)
 
+    # -- pieces (any spatial size: tests/test_hf_efficientnet_golden.py feeds even-sized maps) ---------
+    def preprocess(self, x):
+        """Rescaling(1/255) -> Normalization (NCHW in, NCHW out)."""
+        x = x * (1.0 / 255.0)
+        return (x - self.w["normalization/mean"].view(1, -1, 1, 1)) / torch.clamp(
+            torch.sqrt(self.w["normalization/variance"]), min=1e-7).view(1, -1, 1, 1)
+
+    def stem(self, x):
+        """ZeroPadding2D(correct_pad(3)) -> Conv 3x3 s2 valid -> BN -> swish (NCHW)."""
+        (pt, pb), (pl, pr) = correct_pad(x.shape[2], x.shape[3], 3)
+        x = F.pad(x, (pl, pr, pt, pb))
+        return self._swish(self._bn(self._conv(x, "stem_conv/kernel", stride=2), "stem_bn"))
+
+    def mbconv(self, x, block, tap=None):
+        """One MBConv block (keras efficientnet.block(), inference) on an NCHW tensor; block = a BLOCKS row."""
+        name, cin, cout, k, s, e = block
+        p = "block" + name
+        tap = tap or (lambda n, t: None)
+        inp = x
+        if e != 1:
+            x = self._swish(self._bn(self._conv(x, p + "_expand_conv/kernel"), p + "_expand_bn"))
+            tap(p + "_expand", x)
+        if s == 2:
+            (pt, pb), (pl, pr) = correct_pad(x.shape[2], x.shape[3], k)
+        else:
+            pt = pb = pl = pr = k // 2
+        x = F.pad(x, (pl, pr, pt, pb))
+        x = self._swish(self._bn(self._dwconv(x, p + "_dwconv/depthwise_kernel", s), p + "_bn"))
+        tap(p + "_dw", x)
+        se = x.mean(dim=(2, 3), keepdim=True)
+        se = self._swish(self._conv(se, p + "_se_reduce/kernel", bias=p + "_se_reduce/bias"))
+        se = torch.sigmoid(self._conv(se, p + "_se_expand/kernel", bias=p + "_se_expand/bias"))
+        tap(p + "_gate", se[:, :, 0, 0])
+        x = x * se
+        x = self._bn(self._conv(x, p + "_project_conv/kernel"), p + "_project_bn")
+        if s == 1 and cin == cout:
+            x = x + inp                                           # drop-connect is identity at inference
+        tap(p, x)
+        return x
+
+    def top(self, x):
+        return self._swish(self._bn(self._conv(x, "top_conv/kernel"), "top_bn"))
+
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, spec, taps=None):
         """spec: [B,49,40] or [B,49,40,1] (numpy or torch) -> embedding [B,1024] (torch, self.dtype).
@@ -129,37 +172,11 @@ class EmbeddingOracle:
             if taps is not None:
                 taps[name] = (t.permute(0, 2, 3, 1) if t.dim() == 4 else t).contiguous().numpy().copy()
 
-        # Rescaling(1/255) -> Normalization -> ZeroPadding2D(correct_pad(3)) -> Conv 3x3 s2 valid
-        x = x * (1.0 / 255.0)
-        x = (x - self.w["normalization/mean"].view(1, -1, 1, 1)) / torch.clamp(
-            torch.sqrt(self.w["normalization/variance"]), min=1e-7).view(1, -1, 1, 1)
-        (pt, pb), (pl, pr) = correct_pad(x.shape[2], x.shape[3], 3)
-        x = F.pad(x, (pl, pr, pt, pb))
-        x = self._swish(self._bn(self._conv(x, "stem_conv/kernel", stride=2), "stem_bn"))
+        x = self.stem(self.preprocess(x))
         tap("stem", x)
-        for name, cin, cout, k, s, e in BLOCKS:
-            p = "block" + name
-            inp = x
-            if e != 1:
-                x = self._swish(self._bn(self._conv(x, p + "_expand_conv/kernel"), p + "_expand_bn"))
-                tap(p + "_expand", x)
-            if s == 2:
-                (pt, pb), (pl, pr) = correct_pad(x.shape[2], x.shape[3], k)
-            else:
-                pt = pb = pl = pr = k // 2
-            x = F.pad(x, (pl, pr, pt, pb))
-            x = self._swish(self._bn(self._dwconv(x, p + "_dwconv/depthwise_kernel", s), p + "_bn"))
-            tap(p + "_dw", x)
-            se = x.mean(dim=(2, 3), keepdim=True)
-            se = self._swish(self._conv(se, p + "_se_reduce/kernel", bias=p + "_se_reduce/bias"))
-            se = torch.sigmoid(self._conv(se, p + "_se_expand/kernel", bias=p + "_se_expand/bias"))
-            tap(p + "_gate", se[:, :, 0, 0])
-            x = x * se
-            x = self._bn(self._conv(x, p + "_project_conv/kernel"), p + "_project_bn")
-            if s == 1 and cin == cout:
-                x = x + inp                                       # drop-connect is identity at inference
-            tap(p, x)
-        x = self._swish(self._bn(self._conv(x, "top_conv/kernel"), "top_bn"))
+        for block in BLOCKS:
+            x = self.mbconv(x, block, tap)
+        x = self.top(x)
         tap("top", x)
         x = x.mean(dim=(2, 3))
         tap("gap", x)
