@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKWS_ABI_VERSION 2
+#define MKWS_ABI_VERSION 3
 
 typedef enum mkws_status {
   MKWS_OK = 0,
@@ -37,7 +37,9 @@ typedef enum mkws_status {
   MKWS_ERR_NO_DEVICE = -3,     /* no HIP device / not gfx950 */
   MKWS_ERR_HIP = -4,           /* a HIP runtime call failed; see mkws_last_error() */
   MKWS_ERR_ALLOC = -5,
-  MKWS_ERR_BAD_WEIGHTS = -6    /* weight blob does not match the architecture */
+  MKWS_ERR_BAD_WEIGHTS = -6,   /* weight blob does not match the architecture */
+  MKWS_ERR_EXCHANGE = -7       /* an in-kernel exchange of the paired whole-block kernel failed in an EARLIER forward of this
+                                  handle (its embeddings are NaN); the handle has switched plans: repeat the call */
 } mkws_status;
 
 int mkws_abi_version(void);
@@ -142,7 +144,18 @@ int mkws_embed_create(const float* h_weights, size_t n_floats, int max_batch, mk
 void mkws_embed_destroy(mkws_embed* em);
 /* d_spec float32 [B,49,40,1] (NHWC, i.e. the frontend's output) -> d_emb float32 [B,1024]. */
 int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, void* stream);
-/* Execution options (A/B switches for measurement; results are equal up to fp32 rounding):
+/* Failure contract of the paired whole-block kernel ("fuse_pair", below).  Its two workgroups find each other through the
+ * GPU's dispatch order (workgroups are dealt round-robin over the 8 XCDs, so linear ids b and b^8 run on one XCD, adjacent in
+ * its queue).  That order is observed, probed at create and re-checked by every pair at run time, but it is NOT a documented
+ * guarantee (CU masking, CPX/DPX partitions, a second process holding CUs can break it).  When a pair finds itself on two XCDs,
+ * or a half waits ~0.5 s for a partner that is not resident, the launch fills its outputs with NaN and records the failure; all
+ * later paired launches of the handle poison without exchanging.  The next mkws_embed_forward / _forward_tap / _profile on the
+ * handle notices (a host-mapped word, no synchronisation), switches the handle to the one-workgroup-per-4-clips kernel for
+ * good ("fuse_pair" = 0, mkws_embed_get_option("pair_degraded") counts it) and returns MKWS_ERR_EXCHANGE: the earlier result is
+ * invalid, the repeated call is correct.  A captured hipGraph keeps replaying the paired launch: graph users poll
+ * mkws_embed_get_option(em, "pair_degraded") / check for NaN, or capture with "fuse_pair" = 0.
+ *
+ * Execution options (A/B switches for measurement; results are equal up to fp32 rounding):
  *   "fuse_front" (default 1): expand 1x1 conv + depthwise conv in one kernel (expanded tensor stays in LDS);
  *                 0 = separate GEMM and depthwise kernels.
  *   "fuse_block" (default 2 for handles with max_batch >= 384, else 0): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
@@ -164,6 +177,9 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (one clip per workgroup, both 25x20x32
  *                 activations stay in LDS); 0 = separate kernels. */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
+/* Current value of an option above, or of "pair_degraded" (times the handle left the paired kernel after a failed exchange) /
+ * "max_batch"; negative mkws_status for an unknown name.  ("pair_fault" is a write-only test hook that forces those failures.) */
+int mkws_embed_get_option(const mkws_embed* em, const char* name);
 
 /* Measurement aid (NOT capturable: it records a hipEvent pair around every kernel launch and
  * synchronises the stream after each of the `reps` passes).  Writes one line per launch,

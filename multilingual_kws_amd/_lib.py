@@ -7,6 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MKWS_LIB") or os.path.join(_HERE, "lib", "libmkws_hip.so")
 
 MKWS_OK = 0
+MKWS_ERR_EXCHANGE = -7
+ABI_VERSION = 3
 
 
 class MkwsError(RuntimeError):
@@ -50,6 +52,7 @@ SYMBOLS = [
     ("mkws_embed_destroy", None, [_P]),
     ("mkws_embed_forward", _I, [_P, _P, _I, _P, _P]),
     ("mkws_embed_set_option", _I, [_P, ctypes.c_char_p, _I]),
+    ("mkws_embed_get_option", _I, [_P, ctypes.c_char_p]),
     ("mkws_embed_profile", _I, [_P, _P, _I, _I, _P, ctypes.c_char_p, _SZ, _P]),
     ("mkws_embed_forward_tap", _I, [_P, _P, _I, ctypes.c_char_p, _P, _SZ, _P]),
     ("mkws_augment_batch", _I, [_P, _P, _P, ctypes.c_int64, _P, _I, _I, _P, _P]),

@@ -1958,14 +1958,21 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 // agent-scope fences cost 13 us (buffer_inv sc1) + 4-16 us (buffer_wbl2 sc1) EACH and are not needed inside one XCD.
 // Workgroups are dealt round-robin over the XCDs, so blocks b and b ^ 8 share an XCD and are adjacent in its dispatch
 // order (no deadlock: an XCD's resident set is a prefix of its sequence, complete pairs always finish); both halves publish
-// their XCC id with the first flag and the kernel poisons its output with NaN if they differ or if a wait times out.
+// their XCC id with the first flag.  If they differ, or a wait times out (CU masking, a partitioned device, another process
+// holding CUs: the dispatch-order assumption is not a documented guarantee), the half poisons its output tiles with NaN AND
+// records the failure (pair_report); every later launch of the handle then poisons without exchanging, and the next
+// mkws_embed_forward moves the handle to mbconv_block_kernel for good and returns MKWS_ERR_EXCHANGE (check_pair_health).
 // Reductions keep a fixed order (p0 + p1 commutes), so results are bit-identical across batch sizes.
 struct PairArgs {
   BlockArgs b;
   float* xc1;      // [pairs][2][384]
   float* xd;       // [pairs][2][10][2][256]
   int* flags;      // [pairs][2 exchanges][2 halves], zero between launches
+  int* err_dev;    // device word, sticky: nonzero = an exchange of this handle has failed; later launches skip their exchanges and poison
+  int* err_host;   // the same word in host-mapped memory: mkws_embed_forward reads it without synchronising (see check_pair_health)
+  int fault;       // test hook ("pair_fault"): 1 = both halves expect the wrong XCC id, 2 = half 1 never shows up (timeout)
 };
+enum { kPairErrTimeout = 1, kPairErrXcc = 2 };
 static constexpr int kPairXc1 = 384, kPairXdTiles = 10;
 
 __device__ __forceinline__ f32x4 ld_agent_x4(const float* p) {
@@ -1975,16 +1982,25 @@ __device__ __forceinline__ f32x4 ld_agent_x4(const float* p) {
   return v;
 }
 
-// Thread 0 of each half: publish `mine`, wait for the partner's flag, reset it.  Returns the partner's value (0 = timed out).
+// Thread 0 of each half: publish `mine`, wait for the partner's flag, reset it.  Returns the partner's value (0 = timed out;
+// the half then withdraws its own flag so that a partner arriving later times out too instead of consuming a stale signal).
 __device__ __forceinline__ int pair_signal_wait(int* mine, int* theirs, int value) {
   __hip_atomic_store(mine, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int got = 0, spins = 0;
   while ((got = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 22)) return 0;
+    if (++spins > (1 << 21)) { __hip_atomic_store(mine, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
   }
   __hip_atomic_store(theirs, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return got;
+}
+
+// A failed exchange is recorded twice: in device memory (read by every later launch of the handle, which then skips its
+// exchanges and poisons its output: stale flags can never be consumed silently) and in host-mapped memory (read by the
+// next mkws_embed_forward without a synchronisation: the handle then leaves the paired kernel for good).
+__device__ __forceinline__ void pair_report(int* err_dev, int* err_host, int code) {
+  __hip_atomic_store(err_dev, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Probe for mkws_embed_create: every workgroup records the XCC it runs on (see pair_layout_ok).
@@ -2044,7 +2060,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   xcc &= 0xf;
   int* flag_mine = pa.flags + (size_t)pair * 4 + h;
   int* flag_theirs = pa.flags + (size_t)pair * 4 + (h ^ 1);
-  if (tid == 0) *s_bad = 0;
+  if (pa.fault == 2 && h == 1) return;                            // test hook: the partner never arrives
+  if (tid == 0) *s_bad = __hip_atomic_load(pa.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky: an earlier launch failed
+  const int xcc_expect = 1 + (int)(pa.fault == 1 ? (xcc ^ 1u) : xcc);
 
 #ifdef MKWS_FRONT_TIMING
   const long long dbg_c0 = clock64();
@@ -2198,9 +2216,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && *s_bad == 0) {
     const int got = pair_signal_wait(flag_mine, flag_theirs, 1 + (int)xcc);
-    if (got != 1 + (int)xcc) *s_bad = 1;                         // timed out, or the halves sit on different XCDs
+    if (got != xcc_expect) {                                     // timed out, or the halves sit on different XCDs
+      *s_bad = 1;
+      pair_report(pa.err_dev, pa.err_host, got == 0 ? kPairErrTimeout : kPairErrXcc);
+    }
   }
   __syncthreads();
   if (tid < 48 * G) {
@@ -2288,9 +2309,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) {
+      if (tid == 0 && *s_bad == 0) {
         const int got = pair_signal_wait(flag_mine + 2, flag_theirs + 2, 1);
-        if (got != 1) *s_bad = 1;
+        if (got != 1) { *s_bad = 1; pair_report(pa.err_dev, pa.err_host, kPairErrTimeout); }
       }
       __syncthreads();
       if constexpr (NTW > 0) {
@@ -2501,6 +2522,11 @@ struct mkws_embed {
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   int fuse_pair = 1;               // stride-1 2x2 blocks on mbconv_pair_kernel: two workgroups share 8 clips and split the channels
   float* pair_xc1 = nullptr; float* pair_xd = nullptr; int* pair_flags = nullptr;   // exchange buffers of the paired kernel
+  int* pair_err_dev = nullptr;     // sticky failure word of the paired kernel (device memory)
+  int* pair_err_host = nullptr;    // the same in host-mapped memory (hipHostMalloc): read by the host without synchronising
+  size_t pair_flag_count = 0;
+  int pair_fault = 0;              // test hook, see PairArgs::fault
+  int pair_degraded = 0;           // how many times this handle left the paired kernel because an exchange failed
   int pair_mt = 2;                 // row tiles per pair (2 = 8 clips, 1 = 4 clips): pair_row_tiles(max_batch)
   int block_mt43 = 3;              // row tiles per workgroup of the 4x3 whole-block kernels (3 = 4 clips, 2 = 2 clips): same rule
   BlockPlan blocks[kNumBlocks];
@@ -2621,9 +2647,8 @@ int pick_cqb(int cq) {   // largest divisor of cq that is <= 64
   return 1;
 }
 
-// split-K workspace of the handle whose forward is running (set by run_forward)
-static thread_local float* g_splitk_ws = nullptr;
-static thread_local size_t g_splitk_ws_floats = 0;
+// split-K workspace: part of the handle's own workspace, handed to every launch_gemm of its forward
+struct SplitWs { float* p = nullptr; size_t floats = 0; };
 
 template <int MT, bool GATE>
 void launch_gemm_nt(int NT, dim3 grid, hipStream_t s, const GemmArgs& a) {
@@ -2658,7 +2683,7 @@ TileChoice pick_tile(int M, int NTtot, int KC) {
   return {1, 2, 1};
 }
 
-void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const float* X, int ldx, int M, int Mplan, int act, const float* gate, int HW,
+void launch_gemm(hipStream_t s, const SplitWs& sw, const char* stage, const GemmLayer& L, const float* X, int ldx, int M, int Mplan, int act, const float* gate, int HW,
                  const float* R, int ldr, float* Y, int ldy, int pool4 = 0) {
   GemmArgs a;
   a.pool4 = pool4;
@@ -2673,8 +2698,8 @@ void launch_gemm(hipStream_t s, const char* stage, const GemmLayer& L, const flo
   const int MT = tc.MT, NT = tc.NT;
   a.splitk = tc.splitk; a.part = nullptr; a.ldp = L.NTtot * 16;
   if (tc.splitk > 1) {
-    if (!g_splitk_ws || (size_t)tc.splitk * Mplan * a.ldp > g_splitk_ws_floats) a.splitk = 1;   // no workspace: plain path (decided on the planned M, so every batch size of a handle takes the same path)
-    else a.part = g_splitk_ws;
+    if (!sw.p || (size_t)tc.splitk * Mplan * a.ldp > sw.floats) a.splitk = 1;   // no workspace: plain path (decided on the planned M, so every batch size of a handle takes the same path)
+    else a.part = sw.p;
   }
   dim3 grid((M + 64 * MT - 1) / (64 * MT), (L.NTtot + NT - 1) / NT, a.splitk);
   {
@@ -2827,7 +2852,7 @@ bool block_supported(const BlockPlan& b, int mode) {
   return (ks == 5 && st == 1) || (ks == 3 && st == 1);
 }
 
-void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+int launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
   BlockArgs a;
   a.X = X; a.Cin = b.spec.in_ch;
   a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KCe = b.expand.KC; a.NTe = b.expand.NTtot;
@@ -2848,7 +2873,7 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43
   ProfScope ps(stage, std::string("mbconv_block_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," +
                           std::to_string(b.W) + "," + std::to_string(MT) + "," + std::to_string(kBlockWaves) + ">");
 #define MKWS_BLOCK(KS, S, H_, W_, MT_) do { \
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), 160 * 1024) != MKWS_OK) return; \
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), 160 * 1024)) return rc_; \
     hipLaunchKernelGGL((mbconv_block_kernel<KS, S, H_, W_, MT_, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, a); } while (0)
   if (b.H == 4 && b.W == 3 && MT == 3) {
     if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 3);
@@ -2866,10 +2891,11 @@ void launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43
 #ifdef MKWS_FRONT_TIMING
   report_block_timing(s, stage, grid.x, d_bt);
 #endif
+  return MKWS_OK;
 }
 
 // Paired whole-block kernel (mbconv_pair_kernel): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a).
-struct PairWs { float* xc1 = nullptr; float* xd = nullptr; int* flags = nullptr; int mt = 2; };
+struct PairWs { float* xc1 = nullptr; float* xd = nullptr; int* flags = nullptr; int* err_dev = nullptr; int* err_host = nullptr; int fault = 0; int mt = 2; };
 static int pair_count(int B, int mt) { const int G = 4 * mt; return ((B + G - 1) / G + 7) / 8 * 8; }   // padded to whole groups of 8 pairs (16 workgroups)
 static size_t pair_ws_floats(int max_batch, int mt) { return (size_t)pair_count(max_batch, mt) * (2 * kPairXc1 + 2 * kPairXdTiles * 2 * 256 + 4); }
 // Row tiles per pair for a handle: 8 clips per pair fill the chip from ~1024 clips up; smaller handles use 4-clip pairs so
@@ -2909,7 +2935,7 @@ bool pair_supported(const BlockPlan& b) {
   return ((size_t)L.U + L.E + L.Z) * sizeof(float) <= 160 * 1024;
 }
 
-void launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const PairWs& ws, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+int launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const PairWs& ws, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
   PairArgs pa;
   BlockArgs& a = pa.b;
   a.X = X; a.Cin = b.spec.in_ch;
@@ -2920,7 +2946,7 @@ void launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const Pai
   a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
-  pa.xc1 = ws.xc1; pa.xd = ws.xd; pa.flags = ws.flags;
+  pa.xc1 = ws.xc1; pa.xd = ws.xd; pa.flags = ws.flags; pa.err_dev = ws.err_dev; pa.err_host = ws.err_host; pa.fault = ws.fault;
   const PairLds L = pair_lds(b.expand.KC, b.ce / 2, ws.mt);
   const size_t lds = ((size_t)L.U + L.E + L.Z) * sizeof(float);
   const dim3 grid(2 * pair_count(B, ws.mt));
@@ -2931,7 +2957,7 @@ void launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const Pai
 #endif
   ProfScope ps(stage, std::string("mbconv_pair_kernel<") + std::to_string(ks) + "," + std::to_string(ws.mt) + "," + std::to_string(kBlockWaves) + ">");
 #define MKWS_PAIR(KS, MT_) do { \
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_kernel<KS, MT_, kBlockWaves>), 160 * 1024) != MKWS_OK) return; \
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_kernel<KS, MT_, kBlockWaves>), 160 * 1024)) return rc_; \
     hipLaunchKernelGGL((mbconv_pair_kernel<KS, MT_, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa); } while (0)
   if (ks == 5) { if (ws.mt == 2) MKWS_PAIR(5, 2); else MKWS_PAIR(5, 1); }
   else         { if (ws.mt == 2) MKWS_PAIR(3, 2); else MKWS_PAIR(3, 1); }
@@ -2939,6 +2965,7 @@ void launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const Pai
 #ifdef MKWS_FRONT_TIMING
   report_block_timing(s, stage, grid.x, d_bt);
 #endif
+  return MKWS_OK;
 }
 
 // Whole-block kernel for the big-image blocks 2a..4a (mbconv_mid_kernel): one instance per layer geometry.
@@ -2951,12 +2978,12 @@ bool mid_supported(const BlockPlan& b) {
 }
 
 template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int NTP, int G, int SEG, int NTHR, int WPE>
-void launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
+int launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
   using GM = MidGeom<KS, S, KCT, HT, WT, CEXP, CC, G, SEG>;
   constexpr size_t lds = (size_t)GM::lds_floats * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS carve exceeds one CU");
   auto* fn = &mbconv_mid_kernel<KS, S, KCT, HT, WT, CEXP, CC, NTP, G, SEG, NTHR, WPE>;
-  if (ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024) != MKWS_OK) return;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024)) return rc;
   ProfScope ps(stage, std::string("mbconv_mid_kernel<") + std::to_string(KS) + "," + std::to_string(S) + "," + std::to_string(HT) + "," + std::to_string(WT) +
                           "," + std::to_string(CEXP) + "," + std::to_string(CC) + "," + std::to_string(G) + "," + std::to_string(NTHR) + ">");
   const dim3 grid((a.B + G - 1) / G);
@@ -2979,6 +3006,7 @@ void launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
 #else
   hipLaunchKernelGGL(fn, grid, dim3(NTHR), lds, s, a);
 #endif
+  return MKWS_OK;
 }
 
 // fuse_mid: 1 = the blocks where the whole-block kernel measured faster (3a, 4a); 2 = all five big-image blocks
@@ -2989,7 +3017,7 @@ bool mid_enabled(const BlockPlan& b, int fuse_mid) {
   return (b.H == 13 && b.spec.kernel == 5) || (b.H == 7 && b.spec.stride == 2);
 }
 
-void launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+int launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
   MidArgs a;
   a.X = X; a.Cin = b.spec.in_ch;
   a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.NTtotE = b.expand.NTtot;
@@ -3000,11 +3028,11 @@ void launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const floa
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate; a.B = B;
   const int ks = b.spec.kernel, st = b.spec.stride;
   //                              KS S KCT  H   W  CEXP CC NTP G SEG NTHR WPE
-  if (b.H == 25) launch_mid_inst<3, 2, 1, 25, 20, 96, 16, 2, 1, 1, 1024, 4>(s, stage, a);                  // 2a
-  else if (b.H == 13 && ks == 3) launch_mid_inst<3, 1, 2, 13, 10, 144, 48, 2, 1, 2, 1024, 4>(s, stage, a); // 2b
-  else if (b.H == 13) launch_mid_inst<5, 2, 2, 13, 10, 144, 48, 3, 1, 1, 512, 4>(s, stage, a);             // 3a
-  else if (st == 1) launch_mid_inst<5, 1, 3, 7, 5, 240, 48, 3, 1, 1, 512, 4>(s, stage, a);                 // 3b
-  else launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 1, 512, 4>(s, stage, a);                              // 4a
+  if (b.H == 25) return launch_mid_inst<3, 2, 1, 25, 20, 96, 16, 2, 1, 1, 1024, 4>(s, stage, a);                  // 2a
+  if (b.H == 13 && ks == 3) return launch_mid_inst<3, 1, 2, 13, 10, 144, 48, 2, 1, 2, 1024, 4>(s, stage, a);     // 2b
+  if (b.H == 13) return launch_mid_inst<5, 2, 2, 13, 10, 144, 48, 3, 1, 1, 512, 4>(s, stage, a);                  // 3a
+  if (st == 1) return launch_mid_inst<5, 1, 3, 7, 5, 240, 48, 3, 1, 1, 512, 4>(s, stage, a);                      // 3b
+  return launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 1, 512, 4>(s, stage, a);                                   // 4a
 }
 
 // Back half (SE + gated projection in one launch) for the blocks that keep mbconv_front_kernel: 2a, 2b, 3b.
@@ -3015,25 +3043,26 @@ bool back_supported(const BlockPlan& b) {
 }
 
 template <int HOWO, int CEXP, int NTP, int RS, int NTHR, int WPE>
-void launch_back_inst(hipStream_t s, const char* stage, const BackArgs& a) {
+int launch_back_inst(hipStream_t s, const char* stage, const BackArgs& a) {
   constexpr int SCR = (RS * CEXP > NTHR) ? RS * CEXP : NTHR;
   constexpr size_t lds = ((size_t)HOWO * (CEXP + 4) + 2 * CEXP + 16 + SCR) * sizeof(float);
   auto* fn = &mbconv_back_kernel<HOWO, CEXP, NTP, RS, NTHR, WPE>;
-  if (ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024) != MKWS_OK) return;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024)) return rc;
   ProfScope ps(stage, std::string("mbconv_back_kernel<") + std::to_string(HOWO) + "," + std::to_string(CEXP) + "," + std::to_string(NTP) + "," + std::to_string(NTHR) + ">");
   hipLaunchKernelGGL(fn, dim3(a.B), dim3(NTHR), lds, s, a);
+  return MKWS_OK;
 }
 
-void launch_back(hipStream_t s, const char* stage, const BlockPlan& b, const float* D, const float* X, float* Y, float* dbg_gate, int B) {
+int launch_back(hipStream_t s, const char* stage, const BlockPlan& b, const float* D, const float* X, float* Y, float* dbg_gate, int B) {
   BackArgs a;
   a.D = D; a.X = X; a.Cin = b.spec.in_ch;
   a.Wr = b.se.Wr; a.br = b.se.br; a.We = b.se.We; a.be = b.se.be; a.se = b.se.se;
   a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift;
   a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0; a.dbg_gate = dbg_gate; a.B = B;
   //                          HOWO CEXP NTP RS NTHR WPE
-  if (b.ce == 96) launch_back_inst<130, 96, 2, 8, 512, 4>(s, stage, a);          // 2a: 52 KB of LDS -> 3 workgroups per CU
-  else if (b.ce == 144) launch_back_inst<130, 144, 2, 4, 512, 4>(s, stage, a);   // 2b: 80.5 KB -> 2 per CU
-  else launch_back_inst<35, 240, 3, 4, 512, 4>(s, stage, a);                      // 3b: 39 KB -> 4 per CU
+  if (b.ce == 96) return launch_back_inst<130, 96, 2, 8, 512, 4>(s, stage, a);   // 2a: 52 KB of LDS -> 3 workgroups per CU
+  if (b.ce == 144) return launch_back_inst<130, 144, 2, 4, 512, 4>(s, stage, a);  // 2b: 80.5 KB -> 2 per CU
+  return launch_back_inst<35, 240, 3, 4, 512, 4>(s, stage, a);                    // 3b: 39 KB -> 4 per CU
 }
 
 void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B) {
@@ -3062,11 +3091,31 @@ void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float
 #undef MKWS_SE
 }
 
+// Paired-kernel health: a failed exchange (see mbconv_pair_kernel) left a nonzero word in host-mapped memory.  Read here without
+// synchronising, at the top of every entry point that runs the network: the handle leaves the paired kernel for good
+// (mbconv_block_kernel computes the same blocks), flags and error words are cleared in stream order, and the CALL FAILS with
+// MKWS_ERR_EXCHANGE because a result the caller already holds (the failing forward was asynchronous) is poisoned with NaN.
+// The caller repeats the call; it then runs on the single-workgroup plan.
+int check_pair_health(mkws_embed* em, hipStream_t s) {
+  if (!em->pair_err_host) return MKWS_OK;
+  const int code = *reinterpret_cast<volatile int*>(em->pair_err_host);
+  if (code == 0) return MKWS_OK;
+  em->fuse_pair = 0;
+  em->pair_fault = 0;
+  ++em->pair_degraded;
+  *reinterpret_cast<volatile int*>(em->pair_err_host) = 0;
+  MKWS_HIP(hipMemsetAsync(em->pair_flags, 0, em->pair_flag_count * sizeof(int), s));
+  MKWS_HIP(hipMemsetAsync(em->pair_err_dev, 0, sizeof(int), s));
+  return fail(MKWS_ERR_EXCHANGE, "paired whole-block kernel: %s in an earlier forward of this handle -- that forward's embeddings are NaN-poisoned; "
+              "the handle now uses one workgroup per 4 clips (fuse_pair = 0): repeat the call",
+              code == kPairErrXcc ? "the two halves of a pair ran on different XCDs" : "a half timed out waiting for its partner");
+}
+
 // Runs the network; stops after `stop` (nullptr = run everything).  On stop, *tap_src/*tap_count describe
 // the buffer holding that stage's output.
 int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStream_t s, const char* stop,
                 const float** tap_src, size_t* tap_count) {
-  g_splitk_ws = em->splitk_ws; g_splitk_ws_floats = em->splitk_floats;
+  SplitWs sw; sw.p = em->splitk_ws; sw.floats = em->splitk_floats;
   auto hit = [&](const std::string& name, const float* p, size_t n) {
     if (stop && name == stop) { *tap_src = p; *tap_count = n; return true; }
     return false;
@@ -3107,7 +3156,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     if (mid_enabled(b, em->fuse_mid) && !want_expand_tap) {
       // big-image blocks: one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
-      launch_mid(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+      if (int rc = launch_mid(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
       if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
       if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
       if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
@@ -3119,9 +3168,10 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
       if (em->fuse_pair && pair_supported(b)) {
         PairWs pw; pw.xc1 = em->pair_xc1; pw.xd = em->pair_xd; pw.flags = em->pair_flags; pw.mt = em->pair_mt;
-        launch_pair(s, p.c_str(), b, pw, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+        pw.err_dev = em->pair_err_dev; pw.err_host = em->pair_err_host; pw.fault = em->pair_fault;
+        if (int rc = launch_pair(s, p.c_str(), b, pw, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
       } else {
-        launch_block(s, p.c_str(), b, em->block_mt43, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B);
+        if (int rc = launch_block(s, p.c_str(), b, em->block_mt43, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
       }
       if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
       if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
@@ -3131,13 +3181,13 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     }
     if (b.has_expand && (want_expand_tap || !em->fuse_front)) {
       // unfused path: kept for the "<block>_expand" parity tap and as an A/B switch (mkws_embed_set_option)
-      launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
+      launch_gemm(s, sw, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       if (hit(p + "_expand", em->bufE, (size_t)Min * b.ce)) return MKWS_OK;
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else if (b.has_expand && front_supported(b)) {
       launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
     } else if (b.has_expand) {
-      launch_gemm(s, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
+      launch_gemm(s, sw, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else {
       launch_dw(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
@@ -3146,7 +3196,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     if (em->fuse_back && back_supported(b)) {
       // SE + gated projection of this block in one launch, the clip's depthwise output staged in LDS once
       const bool tap_gate = stop && (p + "_gate") == stop;
-      launch_back(s, p.c_str(), b, em->bufD, cur, nxt, tap_gate ? em->gate : nullptr, B);
+      if (int rc = launch_back(s, p.c_str(), b, em->bufD, cur, nxt, tap_gate ? em->gate : nullptr, B)) return rc;
       if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
       if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
       float* t = cur; cur = nxt; nxt = t;
@@ -3154,7 +3204,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     }
     launch_se(s, (p + "_gate").c_str(), b, em->sums, em->se_part, em->gate, B);
     if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
-    launch_gemm(s, p.c_str(), b.project, em->bufD, b.ce, Mout, em->max_batch * b.Ho * b.Wo, ACT_NONE, em->gate, b.Ho * b.Wo, b.residual ? cur : nullptr,
+    launch_gemm(s, sw, p.c_str(), b.project, em->bufD, b.ce, Mout, em->max_batch * b.Ho * b.Wo, ACT_NONE, em->gate, b.Ho * b.Wo, b.residual ? cur : nullptr,
                 b.spec.out_ch, nxt, b.spec.out_ch);
     if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
     float* t = cur; cur = nxt; nxt = t;
@@ -3163,9 +3213,9 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
   const bool fuse_gap = em->fuse_gap && HWt == 4 && !(stop && strcmp(stop, "top") == 0);
   if (fuse_gap) {
     // top conv + BN + swish + global average pool in one launch: the [B*4, 1280] tensor never reaches HBM
-    launch_gemm(s, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->gap, kTopCh, 1);
+    launch_gemm(s, sw, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->gap, kTopCh, 1);
   } else {
-    launch_gemm(s, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, kTopCh);
+    launch_gemm(s, sw, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, kTopCh);
     if (hit("top", em->bufE, (size_t)B * HWt * kTopCh)) return MKWS_OK;
   }
   if (!fuse_gap) {
@@ -3174,12 +3224,12 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     hipLaunchKernelGGL(mean_hw_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, em->bufE, em->gap, B, HWt, kTopCh);
   }
   if (hit("gap", em->gap, (size_t)B * kTopCh)) return MKWS_OK;
-  launch_gemm(s, "dense", em->dense0, em->gap, kTopCh, B, em->max_batch, ACT_RELU, nullptr, 0, nullptr, 0, em->d0, kDense0);
+  launch_gemm(s, sw, "dense", em->dense0, em->gap, kTopCh, B, em->max_batch, ACT_RELU, nullptr, 0, nullptr, 0, em->d0, kDense0);
   if (hit("dense", em->d0, (size_t)B * kDense0)) return MKWS_OK;
-  launch_gemm(s, "dense_1", em->dense1, em->d0, kDense0, B, em->max_batch, ACT_RELU, nullptr, 0, nullptr, 0, em->d1, kDense1);
+  launch_gemm(s, sw, "dense_1", em->dense1, em->d0, kDense0, B, em->max_batch, ACT_RELU, nullptr, 0, nullptr, 0, em->d1, kDense1);
   if (hit("dense_1", em->d1, (size_t)B * kDense1)) return MKWS_OK;
   float* out = d_emb ? d_emb : em->d0;
-  launch_gemm(s, "dense_2", em->dense2, em->d1, kDense1, B, em->max_batch, ACT_SELU, nullptr, 0, nullptr, 0, out, kEmbDim);
+  launch_gemm(s, sw, "dense_2", em->dense2, em->d1, kDense1, B, em->max_batch, ACT_SELU, nullptr, 0, nullptr, 0, out, kEmbDim);
   if (hit("dense_2", out, (size_t)B * kEmbDim)) return MKWS_OK;
   if (stop) return fail(MKWS_ERR_INVALID_ARG, "unknown stage '%s'", stop);
   return MKWS_OK;
@@ -3332,7 +3382,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // workspace
   const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 20480 + 9 * 48;
   const size_t pair_floats = pair_ws_floats(max_batch, em->pair_mt);
-  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats;
+  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
   }
@@ -3347,9 +3397,13 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     em->pair_xc1 = w; w += np * 2 * kPairXc1;
     em->pair_xd = w; w += np * 2 * kPairXdTiles * 2 * 256;
     em->pair_flags = reinterpret_cast<int*>(w); w += np * 4;
-    if (hipMemset(em->pair_flags, 0, np * 4 * sizeof(int)) != hipSuccess) {
-      (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "clearing the pair flags failed");
+    em->pair_err_dev = em->pair_flags + np * 4; w += 4;          // cleared with the flags
+    em->pair_flag_count = np * 4;
+    if (hipMemset(em->pair_flags, 0, (np * 4 + 4) * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&em->pair_err_host), 64, hipHostMallocMapped) != hipSuccess) {
+      (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "setting up the pair flags failed");
     }
+    *em->pair_err_host = 0;
   }
   *out = em;
   return MKWS_OK;
@@ -3359,6 +3413,7 @@ void mkws_embed_destroy(mkws_embed* em) {
   if (!em) return;
   if (em->d_weights) (void)hipFree(em->d_weights);
   if (em->d_ws) (void)hipFree(em->d_ws);
+  if (em->pair_err_host) (void)hipHostFree(em->pair_err_host);
   delete em;
 }
 
@@ -3368,7 +3423,9 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
   if (B == 0) return MKWS_OK;
   if (!d_spec || !d_emb) return fail(MKWS_ERR_INVALID_ARG, "d_spec/d_emb is NULL");
   const float* src; size_t cnt;
-  int rc = run_forward(em, d_spec, B, d_emb, static_cast<hipStream_t>(stream), nullptr, &src, &cnt);
+  int rc = check_pair_health(em, static_cast<hipStream_t>(stream));
+  if (rc != MKWS_OK) return rc;
+  rc = run_forward(em, d_spec, B, d_emb, static_cast<hipStream_t>(stream), nullptr, &src, &cnt);
   if (rc != MKWS_OK) return rc;
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
@@ -3383,6 +3440,21 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
+  if (strcmp(name, "pair_fault") == 0) { em->pair_fault = value; return MKWS_OK; }     // test hook: forces the paired kernel's failure paths
+  return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+int mkws_embed_get_option(const mkws_embed* em, const char* name) {
+  if (!em || !name) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");
+  if (strcmp(name, "fuse_front") == 0) return em->fuse_front ? 1 : 0;
+  if (strcmp(name, "fuse_block") == 0) return em->fuse_block;
+  if (strcmp(name, "fuse_mid") == 0) return em->fuse_mid;
+  if (strcmp(name, "fuse_back") == 0) return em->fuse_back;
+  if (strcmp(name, "fuse_pair") == 0) return em->fuse_pair;
+  if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
+  if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;
+  if (strcmp(name, "pair_degraded") == 0) return em->pair_degraded;
+  if (strcmp(name, "max_batch") == 0) return em->max_batch;
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
@@ -3392,8 +3464,9 @@ int mkws_embed_profile(mkws_embed* em, const float* d_spec, int B, int reps, flo
   if (!d_spec || !d_emb) return fail(MKWS_ERR_INVALID_ARG, "d_spec/d_emb is NULL");
   LaunchProf prof;
   prof.stream = static_cast<hipStream_t>(stream);
+  int rc = check_pair_health(em, prof.stream);
+  if (rc != MKWS_OK) return rc;
   g_prof = &prof;
-  int rc = MKWS_OK;
   for (int r = 0; r < reps && rc == MKWS_OK; ++r) {
     const float* src; size_t cnt;
     rc = run_forward(em, d_spec, B, d_emb, prof.stream, nullptr, &src, &cnt);
@@ -3422,7 +3495,9 @@ int mkws_embed_forward_tap(mkws_embed* em, const float* d_spec, int B, const cha
   if (!d_spec || !d_dst) return fail(MKWS_ERR_INVALID_ARG, "d_spec/d_dst is NULL");
   const float* src = nullptr; size_t cnt = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc = run_forward(em, d_spec, B, nullptr, s, stage, &src, &cnt);
+  int rc = check_pair_health(em, s);
+  if (rc != MKWS_OK) return rc;
+  rc = run_forward(em, d_spec, B, nullptr, s, stage, &src, &cnt);
   if (rc != MKWS_OK) return rc;
   MKWS_HIP(hipGetLastError());
   if (cnt > cap_floats) return fail(MKWS_ERR_INVALID_ARG, "stage '%s' has %zu floats, destination holds %zu", stage, cnt, cap_floats);

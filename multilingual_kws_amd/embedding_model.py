@@ -56,9 +56,20 @@ class EmbeddingModel:
         with torch.cuda.device(self.device):
             for s in range(0, B, self.max_batch):
                 n = min(self.max_batch, B - s)
-                _lib.check(self.L.mkws_embed_forward(self.h, ctypes.c_void_p(spec[s:s + n].data_ptr()), n,
-                                                     ctypes.c_void_p(emb[s:s + n].data_ptr()), _lib.current_stream_ptr()))
+                self._call_forward(spec[s:s + n], n, emb[s:s + n])
         return emb
+
+    def _call_forward(self, spec, n, emb):
+        args = (self.h, ctypes.c_void_p(spec.data_ptr()), n, ctypes.c_void_p(emb.data_ptr()), _lib.current_stream_ptr())
+        rc = self.L.mkws_embed_forward(*args)
+        if rc == _lib.MKWS_ERR_EXCHANGE:
+            # include/mkws.h, "Failure contract of the paired whole-block kernel": an EARLIER forward of this handle returned
+            # NaN embeddings; the handle has switched plans and the repeated call is correct.  The earlier result cannot be
+            # recalled from here, so say so loudly.
+            import warnings
+            warnings.warn("multilingual_kws_amd: " + self.L.mkws_last_error().decode("utf-8", "replace"), RuntimeWarning)
+            rc = self.L.mkws_embed_forward(*args)
+        _lib.check(rc)
 
     def predict(self, x):
         """Keras-style: numpy in ([B,49,40,1]), numpy out ([B,1024])."""
@@ -79,6 +90,9 @@ class EmbeddingModel:
 
     def set_option(self, name, value):
         _lib.check(self.L.mkws_embed_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        return _lib.check(self.L.mkws_embed_get_option(self.h, name.encode()))
 
     def profile(self, spec, reps=5):
         """[(stage, kernel_name, avg_ms)] per kernel launch of one forward pass (hipEvent-timed)."""

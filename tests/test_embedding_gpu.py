@@ -201,3 +201,66 @@ def test_whole_block_plan_replays_in_a_hip_graph(ctx):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, refs[k]), k
+
+
+@pytest.mark.parametrize("fault", [1, 2])
+def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault):
+    """include/mkws.h, "Failure contract of the paired whole-block kernel": when the two halves of a pair land on different
+    XCDs (fault 1, forced through the test hook) or a half never arrives (fault 2: the other times out), the failing forward is
+    NaN-poisoned, the NEXT call returns MKWS_ERR_EXCHANGE having moved the handle to the single-workgroup kernel, and the
+    repeated call is correct -- for good, with no stale flag left behind."""
+    from multilingual_kws_amd import _lib
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    spec = _spec(np.random.default_rng(40 + fault), 24)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    ref = ctx["oracle"].forward(spec).numpy()
+    em = EmbeddingModel(ctx["blob"], max_batch=1024)
+    if em.get_option("fuse_pair") != 1:
+        pytest.skip("this device's dispatch order failed the probe at create: the paired kernel is not in use")
+    assert _rel(em.forward(x).cpu().numpy(), ref) < REL_TOL and em.get_option("pair_degraded") == 0
+    em.set_option("pair_fault", fault)
+    poisoned = em.forward(x)
+    torch.cuda.synchronize()
+    assert torch.isnan(poisoned).any()                                   # safe-fail: never a plausible wrong number
+    em.set_option("pair_fault", 0)
+    emb = torch.empty((24, 1024), device=ctx["dev"])
+    rc = em.L.mkws_embed_forward(em.h, x.data_ptr(), 24, emb.data_ptr(), _lib.current_stream_ptr())
+    assert rc == _lib.MKWS_ERR_EXCHANGE and b"repeat the call" in em.L.mkws_last_error()
+    assert em.get_option("fuse_pair") == 0 and em.get_option("pair_degraded") == 1
+    for _ in range(2):                                                   # the retry, and the call after it
+        out = em.forward(x)
+        assert torch.isfinite(out).all() and _rel(out.cpu().numpy(), ref) < REL_TOL
+    # the Python wrapper retries by itself (with a warning) when it is the one that meets the error code
+    em2 = EmbeddingModel(ctx["blob"], max_batch=1024)
+    em2.set_option("pair_fault", fault)
+    em2.forward(x)
+    torch.cuda.synchronize()
+    with pytest.warns(RuntimeWarning, match="NaN-poisoned"):
+        out = em2.forward(x)
+    assert _rel(out.cpu().numpy(), ref) < REL_TOL and em2.get_option("pair_degraded") == 1
+    # re-arming the paired kernel after the reset works: flags and the sticky word were cleared in stream order
+    em2.set_option("fuse_pair", 1)
+    assert _rel(em2.forward(x).cpu().numpy(), ref) < REL_TOL and em2.get_option("pair_degraded") == 1
+
+
+@pytest.mark.parametrize("max_batch", [1, 2, 256])
+def test_serving_handle_plans(ctx, max_batch):
+    """The handles bench.py's streaming config builds (BASELINE configs[4]: max_batch 1 for the latency leg, 256 for throughput)
+    against the oracle, with batch-size invariance inside the handle."""
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    n = min(max_batch, 40)
+    spec = _spec(np.random.default_rng(60 + max_batch), n)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    em = EmbeddingModel(ctx["blob"], max_batch=max_batch)
+    out = em.forward(x)
+    ref = ctx["oracle"].forward(spec).numpy()
+    assert _rel(out.cpu().numpy(), ref) < REL_TOL and np.array_equal(out.cpu().numpy().argmax(1), ref.argmax(1))
+    for b in sorted({1, n // 2, n - 1} - {0}):
+        assert torch.equal(em.forward(x[:b]), out[:b]), b
+    if max_batch == 256:
+        full = _spec(np.random.default_rng(7), 256)
+        xf = torch.from_numpy(full).to(ctx["dev"])
+        of = em.forward(xf)
+        idx = np.arange(0, 256, 23)
+        assert _rel(of[idx].cpu().numpy(), ctx["oracle"].forward(full[idx]).numpy()) < REL_TOL
+        assert torch.equal(em.forward(xf[:n]), of[:n])
