@@ -59,11 +59,51 @@ def _crc_table():
 _CRC = _crc_table()
 
 
-def crc32c(data, crc=0):
-    c = crc ^ 0xFFFFFFFF
-    for b in bytes(data):
+_CRC_NP = np.asarray(_CRC, dtype=np.uint32)
+_ZERO_OPS = {}
+
+
+def _crc_scalar(data, c):
+    for b in data:
         c = _CRC[(c ^ b) & 0xFF] ^ (c >> 8)
-    return c ^ 0xFFFFFFFF
+    return c
+
+
+def _zero_op(L):
+    """Columns of the GF(2)-linear map "advance the CRC register over L zero bytes" (one uint32 per input bit)."""
+    if L not in _ZERO_OPS:
+        st = (np.uint32(1) << np.arange(32, dtype=np.uint32)).astype(np.uint32)
+        for _ in range(L):
+            st = _CRC_NP[st & np.uint32(0xFF)] ^ (st >> np.uint32(8))
+        _ZERO_OPS[L] = [int(v) for v in st]
+    return _ZERO_OPS[L]
+
+
+def crc32c(data, crc=0):
+    """CRC-32C of `data`, continuing from `crc`.  Tensors are megabytes, so long inputs are cut into equal chunks whose
+    register remainders are computed side by side in numpy (the register update is linear over GF(2):
+    state(s0, A || B) = Z_len(B)(state(s0, A)) xor state(0, B)) and folded in order; short inputs take the byte loop."""
+    data = bytes(data)
+    c = crc ^ 0xFFFFFFFF
+    L = 1024
+    n = len(data) // L
+    if n >= 8:
+        a = np.frombuffer(data, dtype=np.uint8, count=n * L).reshape(n, L)
+        st = np.zeros(n, dtype=np.uint32)
+        for j in range(L):
+            st = _CRC_NP[(st ^ a[:, j]) & np.uint32(0xFF)] ^ (st >> np.uint32(8))
+        cols = _zero_op(L)
+        for r in st.tolist():
+            z = 0
+            k = 0
+            while c:
+                if c & 1:
+                    z ^= cols[k]
+                c >>= 1
+                k += 1
+            c = z ^ r
+        data = data[n * L:]
+    return _crc_scalar(data, c) ^ 0xFFFFFFFF
 
 
 def mask_crc(c):
@@ -380,7 +420,7 @@ def import_savedmodel(path, verify=True):
     out = {}
     if have_all:
         for t in tensors:
-            out[t["name"]] = rd.tensor(named[t["name"]])
+            out[t["name"]] = rd.tensor(named[t["name"]], verify_crc=verify)
     else:
         # positional fallback: group the manifest by layer, walk the checkpoint's weighted layers in order
         layers, cur = [], None
@@ -407,7 +447,7 @@ def import_savedmodel(path, verify=True):
                 leaf = t["name"].split("/")[1]
                 if leaf not in grp:
                     raise CheckpointFormatError(f"layer {t['name'].split('/')[0]}: checkpoint layer has {sorted(grp)}, no '{leaf}'")
-                out[t["name"]] = rd.tensor(grp[leaf])
+                out[t["name"]] = rd.tensor(grp[leaf], verify_crc=verify)
     for t in tensors:
         v = np.asarray(out[t["name"]], dtype=np.float32)
         if t["name"].startswith("normalization/") and v.size == 1:

@@ -469,6 +469,60 @@ class AudioDataset:
             out[:n + a] = t[-a:n]
         return out
 
+    # -- single-clip augmentation exactly as the reference's tf.data map applies it (host-side numpy; the batch path above makes
+    #    the same draws for a whole batch and runs the sample-level work in mkws_augment_batch) -----------------------
+    def _background_sample_host(self, background_volume=1.0):
+        idx, off = self._draw_background()
+        n = self.model_settings["desired_samples"]
+        return (self.background_host[idx, off:off + n] * np.float32(background_volume)).reshape(n).astype(np.float32)
+
+    def _timeshift_host(self, audio):
+        a, n = self._draw_shift(), self.model_settings["desired_samples"]
+        audio = np.asarray(audio, dtype=np.float32)
+        out = np.zeros(n, dtype=np.float32)
+        if a > 0:
+            out[a:] = audio[:n - a]
+        else:
+            out[:n + a] = audio[-a:n]
+        return out
+
+    def augment(self, audio, label):
+        """(audio [desired_samples], label str) -> (audio, label): reference input_data.py:277-304 -- time shift, then with
+        p = silence_percentage: a background slice at U(0,1) volume labelled _silence_; else with p = unknown_percentage (when
+        unknown files exist): a random unknown-word clip, shifted again, labelled _unknown_; else with p =
+        background_frequency: background mixed in at U(0, background_volume_range) of the clip's RMS."""
+        audio = np.asarray(audio.cpu() if hasattr(audio, "cpu") else audio, dtype=np.float32)
+        if self.max_time_shift_samples > 0:
+            audio = self._timeshift_host(audio)
+        if self.rng.uniform(0, 1) < self.silence_percentage / 100:
+            background_volume = self.rng.uniform(0, 1)
+            label = SILENCE_LABEL
+            audio = self._background_sample_host(background_volume)
+        elif len(self.unknown_files) > 0 and self.rng.uniform(0, 1) < self.unknown_percentage / 100:
+            audio = self.get_unknown()
+            if self.max_time_shift_samples > 0:
+                audio = self._timeshift_host(audio)
+            label = UNKNOWN_WORD_LABEL
+        elif self.rng.uniform(0, 1) < self.background_frequency:
+            background_volume = self.rng.uniform(0, self.background_volume_range)
+            audio = add_background(audio, self._background_sample_host(), background_volume)
+        return audio, label
+
+    def _random_silence(self):
+        """reference :510-514"""
+        background_volume = self.rng.uniform(0, 1)
+        return self._background_sample_host(background_volume), SILENCE_LABEL
+
+    def _random_unknown(self):
+        """reference :516-519"""
+        return self.get_unknown(), UNKNOWN_WORD_LABEL
+
+    def _random_silence_unknown(self, n_files):
+        """reference :521-530: int(n * silence%) silence clips followed by int(n * unknown%) unknown-word clips."""
+        n_silent = int(n_files * self.silence_percentage / 100)
+        n_unknown = int(n_files * self.unknown_percentage / 100)
+        return [self._random_silence() for _ in range(n_silent)] + [self._random_unknown() for _ in range(n_unknown)]
+
     def get_unknown(self):
         return _read_wav(self.unknown_files[int(self.rng.integers(0, len(self.unknown_files)))],
                          self.model_settings["desired_samples"])

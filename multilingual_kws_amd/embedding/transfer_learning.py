@@ -23,7 +23,7 @@ from . import input_data
 CATEGORIES = 3   # silence + unknown + target keyword
 
 
-def load_base_model(base_model_path, max_batch=1024):
+def load_base_model(base_model_path, max_batch=1024, base_model_output="dense_2"):
     """The frozen embedding model.  base_model_path: what the reference passes to tf.keras.models.load_model
     (transfer_learning.py:36) -- a Keras SavedModel directory such as multilingual_context_73_0.8011, read without
     TensorFlow by multilingual_kws_amd.checkpoint_import -- or a weight-container directory written by
@@ -38,7 +38,7 @@ def load_base_model(base_model_path, max_batch=1024):
         blob = checkpoint_import.import_savedmodel(p)
     else:
         blob = weights.load(p)
-    return EmbeddingModel(blob, max_batch=max_batch), blob
+    return EmbeddingModel(blob, max_batch=max_batch, output=base_model_output), blob
 
 
 class TransferLearnedModel:
@@ -73,7 +73,7 @@ class TransferLearnedModel:
         os.makedirs(path, exist_ok=True)
         np.savez(os.path.join(path, "head.npz"), params=self.head.get_params(),
                  dims=np.asarray([self.head.in_dim, self.head.hidden, self.head.classes]))
-        meta = {"format": "mkws-transfer-learned-v1", "base_model_path": self.base_model_path}
+        meta = {"format": "mkws-transfer-learned-v1", "base_model_path": self.base_model_path, "base_model_output": self.embedding.output}
         if self._blob is not None and not str(self.base_model_path).startswith("synthetic"):
             weights.save(os.path.join(path, "base"), self._blob)
             meta["base_model_path"] = "base"
@@ -86,7 +86,7 @@ class TransferLearnedModel:
         base = meta["base_model_path"]
         if not str(base).startswith("synthetic") and not os.path.isabs(base):
             base = os.path.join(path, base)
-        emb, blob = load_base_model(base, max_batch)
+        emb, blob = load_base_model(base, max_batch, meta.get("base_model_output", "dense_2"))
         z = np.load(os.path.join(path, "head.npz"))
         i, h, c = [int(v) for v in z["dims"]]
         return cls(emb, Head(i, h, c, max_batch=max_batch, params=z["params"]), blob, meta["base_model_path"])
@@ -115,18 +115,22 @@ def transfer_learn(
     """Single-target few-shot fine-tune; see the reference's docstring ("this only works for
     single-target models").  Extra keyword: `seed` (augmentation + head init; rank is added under DP).
     batch_size is the PER-RANK batch under torch.distributed (weak scaling)."""
-    if base_model_output != "dense_2":
-        raise ValueError(f'this build cuts the embedding at "dense_2" (got {base_model_output!r})')
+    from ..embedding_model import OUTPUT_LAYERS
+    if base_model_output not in OUTPUT_LAYERS:       # reference :38-42 cuts at get_layer(name=base_model_output)
+        raise ValueError(f"base_model_output {base_model_output!r}: this build cuts the embedding at one of {sorted(OUTPUT_LAYERS)}")
+    if backprop_into_embedding and base_model_output != "dense_2":
+        raise ValueError('backprop_into_embedding=True is implemented for base_model_output="dense_2" (the only value the reference\'s callers pass)')
     import torch
     rank, world = parallel.rank(), parallel.world_size()
-    embedding, blob = load_base_model(base_model_path, max_batch=max(batch_size, 64))
+    embedding, blob = load_base_model(base_model_path, max_batch=max(batch_size, 64), base_model_output=base_model_output)
+    feat = embedding.output_dim
     head_seed = None if seed is None else int(seed)
-    p0 = glorot_uniform_params(1024, 18, CATEGORIES, head_seed)
+    p0 = glorot_uniform_params(feat, 18, CATEGORIES, head_seed)
     if world > 1:      # identical initial head on every rank
         t = torch.from_numpy(p0).to(embedding.device)
         parallel.broadcast_(t, 0)
         p0 = t.cpu().numpy()
-    head = Head(1024, 18, CATEGORIES, max_batch=max(batch_size, 64), params=p0, device=embedding.device)
+    head = Head(feat, 18, CATEGORIES, max_batch=max(batch_size, 64), params=p0, device=embedding.device)
     xfer = TransferLearnedModel(embedding, head, blob, str(base_model_path))
 
     audio_dataset = input_data.AudioDataset(
@@ -184,7 +188,7 @@ def transfer_learn(
             tl, ta = (acc_stats / max(seen, 1)).tolist()
             if trainer is not None:      # validation runs the inference kernels on the current weights (moving statistics)
                 blob = trainer.blob()
-                embedding = EmbeddingModel(blob, max_batch=max(batch_size, 64), device=embedding.device)
+                embedding = EmbeddingModel(blob, max_batch=max(batch_size, 64), device=embedding.device, output=base_model_output)
                 xfer.embedding, xfer._blob = embedding, blob
                 xfer.base_model_path = "fine-tuned:" + str(base_model_path)
             # validation: every rank evaluates the full (small) validation set

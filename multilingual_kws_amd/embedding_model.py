@@ -11,11 +11,18 @@ from . import _lib
 
 EMBEDDING_DIM = 1024
 SPEC_SHAPE = (49, 40)
+# Keras layer names a caller may cut the base model at (transfer_learning.py:38-42 uses get_layer(name=base_model_output)) ->
+# (stage name of mkws_embed_forward_tap, features).  Flat outputs only: the reference puts Dense(18) straight on the cut.
+OUTPUT_LAYERS = {"dense_2": ("dense_2", 1024), "dense_1": ("dense_1", 2048), "dense": ("dense", 2048),
+                 "global_average_pooling2d": ("gap", 1280)}
 
 
 class EmbeddingModel:
-    def __init__(self, weight_blob, max_batch=1024, device=None):
+    def __init__(self, weight_blob, max_batch=1024, device=None, output="dense_2"):
         import torch
+        if output not in OUTPUT_LAYERS:
+            raise ValueError(f"base_model_output {output!r}: the embedding can be cut at {sorted(OUTPUT_LAYERS)} (flat outputs)")
+        self.output, (self.output_stage, self.output_dim) = output, OUTPUT_LAYERS[output]
         self.L = _lib.lib()
         blob = np.ascontiguousarray(weight_blob, dtype=np.float32)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -52,11 +59,15 @@ class EmbeddingModel:
         import torch
         spec = self._prep(spec)
         B = spec.shape[0]
-        emb = out if out is not None else torch.empty((B, EMBEDDING_DIM), dtype=torch.float32, device=self.device)
+        emb = out if out is not None else torch.empty((B, self.output_dim), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             for s in range(0, B, self.max_batch):
                 n = min(self.max_batch, B - s)
-                self._call_forward(spec[s:s + n], n, emb[s:s + n])
+                if self.output_stage == "dense_2":
+                    self._call_forward(spec[s:s + n], n, emb[s:s + n])
+                else:           # an earlier cut: the same launches, stopped at that layer
+                    _lib.check(self.L.mkws_embed_forward_tap(self.h, ctypes.c_void_p(spec[s:s + n].data_ptr()), n, self.output_stage.encode(),
+                                                             ctypes.c_void_p(emb[s:s + n].data_ptr()), n * self.output_dim, _lib.current_stream_ptr()))
         return emb
 
     def _call_forward(self, spec, n, emb):
@@ -72,7 +83,7 @@ class EmbeddingModel:
         _lib.check(rc)
 
     def predict(self, x):
-        """Keras-style: numpy in ([B,49,40,1]), numpy out ([B,1024])."""
+        """Keras-style: numpy in ([B,49,40,1]), numpy out ([B,1024], or the width of the layer the model was cut at)."""
         return self.forward(x).cpu().numpy()
 
     def tap(self, spec, stage):

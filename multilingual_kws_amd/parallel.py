@@ -56,13 +56,13 @@ def dp_step(head, emb, labels, lr, beta1=0.9, beta2=0.999, eps=1e-7, force_colle
     """One data-parallel optimizer step on a head-like object (loss_grad / grad_view / adam_step):
     local gradient of the local-mean loss -> all-reduce(sum) -> Adam with grad_scale 1/world.
     Returns the stats tensor [sum of row losses, #correct] summed over ranks (a view of the reduced buffer,
-    valid until the next loss_grad).  force_collective=True issues the all-reduce even in a world of one
-    (the single-GPU RCCL smoke test)."""
+    valid until the next loss_grad).  force_collective=True ALSO issues the all-reduce in a world of one
+    (the single-GPU RCCL smoke test); it can never switch the collective off when there are several ranks."""
     stats = head.loss_grad(emb, labels)
-    w = world_size() if force_collective is None else (2 if force_collective else 1)
-    if w > 1:
+    w = world_size()
+    if w > 1 or force_collective:
         # ONE collective per step: the two statistics ride behind the gradient in the same flat buffer
         buf = allreduce_sum_(head.grad_view(with_stats=True), force=bool(force_collective))
         stats = buf[-2:]
-    head.adam_step(lr=lr, beta1=beta1, beta2=beta2, eps=eps, grad_scale=1.0 / world_size())
+    head.adam_step(lr=lr, beta1=beta1, beta2=beta2, eps=eps, grad_scale=1.0 / w)
     return stats

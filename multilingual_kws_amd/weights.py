@@ -87,8 +87,12 @@ def synthetic_blob(seed=DEFAULT_SEED, calibrate=True, tensors=None):
     if calibrate:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"synthetic_bn_{int(seed)}.npy")
         if not os.path.exists(path):
-            raise FileNotFoundError(f"{path} is missing: run `python tools/calibrate_synthetic_bn.py --seed {int(seed)}` "
-                                    "(or pass calibrate=False for uncalibrated BatchNorm statistics)")
+            # only the statistics of DEFAULT_SEED ship with the package (data/): other seeds are valid weights, just with the
+            # raw random BatchNorm statistics -- say so instead of failing a documented call ("synthetic:SEED")
+            import warnings
+            warnings.warn(f"synthetic_blob(seed={int(seed)}): no calibrated BatchNorm statistics shipped for this seed ({path}); "
+                          f"using the uncalibrated ones.  `python tools/calibrate_synthetic_bn.py --seed {int(seed)}` writes them.", RuntimeWarning)
+            return blob
         stats = np.load(path)
         o = 0
         for t in bn_stat_tensors(tensors):

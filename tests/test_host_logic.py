@@ -84,7 +84,9 @@ def test_transfer_learn_argument_contract():
     kw = dict(target="t", train_files=[], val_files=[], unknown_files=[], num_epochs=1, num_batches=1, batch_size=4,
               primary_lr=1e-3, embedding_lr=0, model_settings=ms, base_model_path="synthetic")
     with pytest.raises(ValueError):
-        transfer_learning.transfer_learn(backprop_into_embedding=False, base_model_output="dense_1", **kw)
+        transfer_learning.transfer_learn(backprop_into_embedding=False, base_model_output="block7a_project_bn", **kw)   # 4-D cut: refused
+    with pytest.raises(ValueError):
+        transfer_learning.transfer_learn(backprop_into_embedding=True, base_model_output="dense_1", **kw)
     # backprop_into_embedding=True is implemented (tests/test_train_gpu.py); without a GPU it fails loudly like everything
     # else in the product path (no CPU fallback), never with NotImplementedError
     import torch
@@ -170,6 +172,54 @@ def test_shipped_bn_calibration_file_is_what_the_recipe_produces():
     assert shipped.dtype == np.float32 and np.array_equal(shipped, tool.calibrated_stats(1234))
     from multilingual_kws_amd import weights
     assert sum(t["count"] for t in weights.bn_stat_tensors()) == shipped.shape[0]
-    with pytest.raises(FileNotFoundError):
-        weights.synthetic_blob(seed=99)                       # no silent uncalibrated fallback
-    assert weights.synthetic_blob(seed=99, calibrate=False).shape == (weights.weight_count(),)
+    with pytest.warns(RuntimeWarning, match="no calibrated BatchNorm statistics"):      # "synthetic:SEED" stays usable for any seed,
+        other = weights.synthetic_blob(seed=99)                                          # but never SILENTLY uncalibrated
+    assert np.array_equal(other, weights.synthetic_blob(seed=99, calibrate=False)) and other.shape == (weights.weight_count(),)
+
+
+def test_single_clip_augment_follows_the_reference_law(tmp_path):
+    """AudioDataset.augment(audio, label) and the _random_* helpers (reference input_data.py:277-304, 510-530): branch
+    probabilities 10 % silence / 45 % unknown / 45 % target at transfer_learn's settings, silence = a background slice,
+    unknown = one of the unknown files (shifted), target = shifted clip with background mixed in 80 % of the time."""
+    d = make_fewshot_dataset(str(tmp_path), n_train=1, n_val=1, n_unknown=4, n_bg=2)
+    ms = input_data.standard_microspeech_model_settings(3)
+    ds = input_data.AudioDataset(ms, ["tiempo"], d["bg_dir"], d["unknown"], unknown_percentage=50.0, seed=3)
+    clip, label = ds.get_single_target_waveforms(d["train"][0])
+    assert label == "tiempo" and clip.shape == (16000,)
+    unknown = np.stack([input_data._read_wav(f, 16000) for f in d["unknown"]])
+    n, counts, mixed, shifts = 3000, {"_silence_": 0, "_unknown_": 0, "tiempo": 0}, 0, []
+    for _ in range(n):
+        a, lab = ds.augment(clip, label)
+        assert a.shape == (16000,) and a.dtype == np.float32 and np.abs(a).max() <= 1.0
+        counts[lab] += 1
+        if lab == "tiempo":
+            # the clean clip shifted by some k in [-1600, 1600) reproduces the output exactly unless background was mixed in
+            is_mixed = True
+            for k in range(-1600, 1600):
+                sh = np.zeros(16000, np.float32)
+                if k > 0:
+                    sh[k:] = clip[:16000 - k]
+                else:
+                    sh[:16000 + k] = clip[-k:]
+                if np.array_equal(sh, a):
+                    is_mixed = False
+                    shifts.append(k)
+                    break
+            mixed += is_mixed
+        if counts["tiempo"] >= 60 and lab == "tiempo":
+            break
+    tot = sum(counts.values())
+    assert abs(counts["_silence_"] / tot - 0.10) < 0.06 and abs(counts["_unknown_"] / tot - 0.45) < 0.12
+    assert 0.6 < mixed / counts["tiempo"] < 0.95 and len(shifts) >= 3 and min(shifts) >= -1600 and max(shifts) <= 1599
+    ds2 = input_data.AudioDataset(ms, ["tiempo"], d["bg_dir"], d["unknown"], unknown_percentage=50.0, time_shift_ms=0,
+                                  background_frequency=0.0, silence_percentage=0.0, seed=4)
+    labs = [ds2.augment(clip, label) for _ in range(200)]
+    assert all(np.array_equal(a, clip) for a, l in labs if l == "tiempo")                 # nothing left to draw: identity
+    assert all(any(np.array_equal(a, u) for u in unknown) for a, l in labs if l == "_unknown_")
+    assert 0.35 < np.mean([l == "_unknown_" for _, l in labs]) < 0.65
+    a, lab = ds._random_silence()
+    assert lab == "_silence_" and a.shape == (16000,) and 0 < np.abs(a).max() <= 800 / 32768 * 6
+    a, lab = ds._random_unknown()
+    assert lab == "_unknown_" and any(np.array_equal(a, u) for u in unknown)
+    extra = ds._random_silence_unknown(20)
+    assert [l for _, l in extra] == ["_silence_"] * 2 + ["_unknown_"] * 10

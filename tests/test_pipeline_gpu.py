@@ -128,6 +128,32 @@ def test_transfer_learn_contract_and_learning(data, tmp_path):
     assert np.array_equal(again.predict(specs[..., None]), model.predict(specs[..., None]))
 
 
+def test_transfer_learn_cut_at_another_layer(data, tmp_path):
+    """base_model_output names any flat layer of the base model (reference transfer_learning.py:38-42 uses get_layer): the head then
+    sits on that layer's features."""
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+    from oracle import head_oracle as ho
+    from oracle.efficientnet_oracle import EmbeddingOracle
+    ms = input_data.standard_microspeech_model_settings(3)
+    specs = np.stack([input_data.file2spec(ms, f) for f in data["val"]])
+    taps = {}
+    EmbeddingOracle(weights.synthetic_blob()).forward(specs, taps)
+    for layer, tap, width in (("dense_1", "dense_1", 2048), ("global_average_pooling2d", "gap", 1280)):
+        name, model, details = tl.transfer_learn(
+            target="target", train_files=data["train"], val_files=data["val"], unknown_files=data["unknown"],
+            num_epochs=1, num_batches=1, batch_size=16, primary_lr=0.001, backprop_into_embedding=False, embedding_lr=0,
+            model_settings=ms, base_model_path="synthetic", base_model_output=layer, bg_datadir=data["bg_dir"], verbose=0, seed=5)
+        assert model.head.in_dim == width and model.head.get_params().shape == (width * 18 + 18 + 18 * 3 + 3,)
+        preds = model.predict(specs[..., None])
+        ref_probs, _ = ho.forward(model.head.get_params(), taps[tap], in_dim=width)
+        assert np.abs(preds - ref_probs).max() < 1e-4 and np.array_equal(preds.argmax(1), ref_probs.argmax(1))
+        assert preds.shape == (8, 3) and np.allclose(preds.sum(1), 1, atol=1e-5)
+        model.save(str(tmp_path / layer))
+        again = tl.TransferLearnedModel.load(str(tmp_path / layer), max_batch=16)
+        assert np.array_equal(again.predict(specs[..., None]), preds)
+
+
 def test_smoke_entry_point():
     import __graft_entry__ as g
     g.smoke()

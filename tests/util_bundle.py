@@ -109,7 +109,7 @@ def write_bundle(prefix, tensors, object_graph=None, num_shards=1, **table_kw):
         a = np.ascontiguousarray(tensors[k])
         raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
         sh = i % num_shards
-        items[k.encode()] = entry(DT[a.dtype], a.shape, sh, len(data[sh]), len(raw), mask_crc(crc32c(raw)) if len(raw) < (1 << 16) else 0)
+        items[k.encode()] = entry(DT[a.dtype], a.shape, sh, len(data[sh]), len(raw), mask_crc(crc32c(raw)))
         data[sh] += raw
     if object_graph is not None:
         lens = varint(len(object_graph))
