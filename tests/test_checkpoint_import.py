@@ -139,7 +139,7 @@ def test_load_base_model_dispatches_on_a_savedmodel_directory(tmp_path, monkeypa
     seen = {}
 
     class FakeEmbedding:
-        def __init__(self, b, max_batch=0):
+        def __init__(self, b, max_batch=0, output="dense_2"):
             seen["blob"] = b
     monkeypatch.setattr(tl, "EmbeddingModel", FakeEmbedding)
     _, got = tl.load_base_model(path, max_batch=4)
