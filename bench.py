@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--config", choices=CONFIGS, default="embed", help="BASELINE.json configuration (default: configs[2])")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step (default: the config's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline samples (1/3 single thread, 2/3 all cores)")
     ap.add_argument("--profile-reps", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B execution switch passed to mkws_embed_set_option (e.g. fuse_block=1); default = shipped plan")
@@ -121,10 +121,21 @@ def _cpu_worker(kind, idx, threads, n_clips, first_clip, budget_s, q, go):
 
 
 def cpu_baseline(kind, budget_s):
+    """BASELINE.md section 3.3 asks for both: one thread, and all host cores.  The contract's fields describe the all-cores run;
+    "single_thread" holds the 1-core one (a third of the time budget)."""
+    one = _cpu_run(kind, budget_s / 3.0, procs=1, threads=1)
+    allc = _cpu_run(kind, budget_s * 2.0 / 3.0)
+    allc["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample")}
+    return allc
+
+
+def _cpu_run(kind, budget_s, procs=None, threads=None):
     import multiprocessing as mp
     ncpu = os.cpu_count() or 1
-    threads = 1 if kind == "frontend" else min(8, ncpu)           # PyTorch-CPU convs on 49x40 images stop scaling near 8 threads
-    procs = max(1, min(ncpu // threads, 64))
+    if threads is None:
+        threads = 1 if kind == "frontend" else min(8, ncpu)       # PyTorch-CPU convs on 49x40 images stop scaling near 8 threads
+    if procs is None:
+        procs = max(1, min(ncpu // threads, 64))
     ctx = mp.get_context("spawn")
     q, go = ctx.Queue(), ctx.Event()
     ps = [ctx.Process(target=_cpu_worker, args=(kind, i, threads, 128, 1024 + 128 * i, budget_s, q, go)) for i in range(procs)]
@@ -215,8 +226,18 @@ def embed_roofline(em, spec, B, reps, arch, extra=None):
     return per_kernel, sum(ms for _, _, ms in prof)
 
 
+def _kernel_frac(v):
+    """Fraction of its own roofline (the binding one of MFMA / HBM for its algorithmic work) a kernel-table entry reaches."""
+    t_roof = max(v["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12), v["bytes"] / (HBM_PEAK_GBS * 1e9))
+    return t_roof / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
+
+
 def roofline_of(per_kernel):
-    dom_name = max(per_kernel, key=lambda n: per_kernel[n]["ms"])
+    # "dominant" = most summed time per step; kernels within 5 % of the leader are a tie that timing noise would otherwise
+    # decide (round 2: 0.156 / 0.154 / 0.150 ms), so among those the one FURTHEST from its roofline is reported
+    top_ms = max(v["ms"] for v in per_kernel.values())
+    tied = [n for n, v in per_kernel.items() if v["ms"] >= 0.95 * top_ms]
+    dom_name = min(tied, key=lambda n: _kernel_frac(per_kernel[n]))
     dom = per_kernel[dom_name]
     avg_ms = dom["ms"] / dom["launches"]
     t_flops = dom["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
@@ -230,9 +251,12 @@ def roofline_of(per_kernel):
         ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
-    roof.update({"kernel": dom_name, "launches_per_step": dom["launches"], "avg_launch_ms": round(avg_ms, 5), "traffic_source": traffic_src,
+    tot_ms = sum(v["ms"] for v in per_kernel.values())
+    roof.update({"kernel": dom_name, "tied_for_dominant": sorted(tied), "launches_per_step": dom["launches"], "avg_launch_ms": round(avg_ms, 5), "traffic_source": traffic_src,
+                 # time-weighted mean over the whole kernel table: sum(roofline time) / sum(measured time)
+                 "time_weighted_frac": round(sum(_kernel_frac(v) * v["ms"] for v in per_kernel.values()) / tot_ms, 4) if tot_ms > 0 else None,
                  "algorithmic_per_launch": {"flops": dom["flops"] / dom["launches"], "bytes": dom["bytes"] / dom["launches"]}})
-    kernels = {n: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
+    kernels = {n: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"], "frac": round(_kernel_frac(v), 4),
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                for n, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])}
@@ -382,6 +406,10 @@ def main():
                 # loss / gradient / update kernels, collectives.  Round 2 found 290 us hiding here in the fine-tune config.
                 whole["other_ms"] = round(max(0.0, ms_per_step - fe_ms - emb_ms), 4)
         roof, kernels = roofline_of(per_kernel)
+        if cfg == "frontend":       # the whole step IS the one kernel
+            roof["whole_step_frac"] = round(B * arch.FRONTEND_BYTES_PER_CLIP_F32 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        else:                       # algorithmic FLOPs of the step (embedding forward of every clip / window) / wall time of the step / MFMA peak
+            roof["whole_step_frac"] = round(units_per_step * arch.EMBED_FLOPS_PER_CLIP / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
         if cfg == "stream":
             one = audio[:1].contiguous()
             em1 = EmbeddingModel(blob, max_batch=1, device=dev)          # small-batch handles plan the multi-kernel path

@@ -58,3 +58,64 @@ def test_bench_cli_accepts_the_driver_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_multi_gpu_self_spawn_and_refusal(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must (a) refuse to report N GPUs from fewer devices and (b) otherwise become
+    the launcher the driver uses: torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1, the original arguments
+    passed through, dmabuf IPC left on.  No GPU needed: device count and the process launch are stubbed."""
+    import torch
+    bench = _load_bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "finetune"])
+    args = bench.parse()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as ei:
+        bench.respawn_under_torchrun(args)
+    assert "only 1 GPU(s) visible" in str(ei.value.code) and "refusing" in str(ei.value.code)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    with pytest.raises(SystemExit) as ei:
+        bench.respawn_under_torchrun(args)
+    assert ei.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "finetune"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_launcher_world_size_must_match_gpus(monkeypatch):
+    """Under a launcher (WORLD_SIZE set) a mismatching --gpus is an error before any device work... unless there is no GPU at all,
+    which is reported first: either way bench.py never prints a line for the wrong world size."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "{" not in out.stdout
+    assert ("WORLD_SIZE=2" in out.stderr) or ("needs an MI355X" in out.stderr)
+
+
+def test_dominant_kernel_choice_is_stable_under_timing_noise():
+    """Kernels within 5 % of the leader are a tie; the tie goes to the one furthest from its roofline, not to noise."""
+    bench = _load_bench()
+    pk = {"dense": {"ms": 0.1563, "launches": 3, "flops": 3 * 6.08e9, "bytes": 1e6},
+          "pair": {"ms": 0.1537, "launches": 3, "flops": 3 * 4.0e9, "bytes": 1e6},
+          "small": {"ms": 0.05, "launches": 1, "flops": 1e8, "bytes": 1e6}}
+    r1, _ = bench.roofline_of(pk)
+    pk["dense"]["ms"], pk["pair"]["ms"] = 0.1530, 0.1560          # the noise flips the order
+    r2, k2 = bench.roofline_of(pk)
+    assert r1["kernel"] == r2["kernel"] == "pair" and r1["tied_for_dominant"] == ["dense", "pair"]
+    assert 0 < r2["time_weighted_frac"] < 1 and abs(k2["pair"]["frac"] - r2["frac"]) < 1e-3
