@@ -413,18 +413,22 @@ def main():
         if cfg == "stream":
             one = audio[:1].contiguous()
             em1 = EmbeddingModel(blob, max_batch=1, device=dev)          # small-batch handles plan the multi-kernel path
-            heads1 = [h for h in heads]
 
-            def one_window():
-                Head.forward_many(heads1, em1.forward(fe.forward(one)))
-            for _ in range(20):
-                one_window()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(200):
-                one_window()
+            def latency(fn, n=200):
+                for _ in range(20):
+                    fn()
                 torch.cuda.synchronize()
-            extra_out["latency_ms_batch1"] = round((time.perf_counter() - t1) / 200 * 1e3, 4)
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                    torch.cuda.synchronize()
+                return round((time.perf_counter() - t1) / n * 1e3, 4)
+            # one window at a time, synchronised after each (what a live caller waits for): launch by launch, then as one
+            # hipGraph replay (embedding.batch_streaming_analysis.StreamingSession)
+            extra_out["latency_ms_batch1_eager"] = latency(lambda: Head.forward_many(heads, em1.forward(fe.forward(one))))
+            sess = bsa.StreamingSession(embedding=em1, heads=heads, model_settings=ms, batch=1)
+            extra_out["latency_ms_batch1"] = latency(lambda: sess.infer(one))
+            assert torch.equal(sess.infer(one), Head.forward_many(heads, em1.forward(fe.forward(one))))
             extra_out["windows_per_stream"] = nwin
         result = {
             "metric": metric, "value": round(value, 1), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

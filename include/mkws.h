@@ -149,7 +149,8 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  * its queue).  That order is observed, probed at create and re-checked by every pair at run time, but it is NOT a documented
  * guarantee (CU masking, CPX/DPX partitions, a second process holding CUs can break it).  When a pair finds itself on two XCDs,
  * or a half waits ~0.5 s for a partner that is not resident, the launch fills its outputs with NaN and records the failure; all
- * later paired launches of the handle poison without exchanging.  The next mkws_embed_forward / _forward_tap / _profile on the
+ * later paired launches of the handle poison without exchanging, and the last layer of every forward that ran after the failure
+ * stores NaN for EVERY embedding (NaN inside the network would not survive the ReLUs of the dense layers).  The next mkws_embed_forward / _forward_tap / _profile on the
  * handle notices (a host-mapped word, no synchronisation), switches the handle to the one-workgroup-per-4-clips kernel for
  * good ("fuse_pair" = 0, mkws_embed_get_option("pair_degraded") counts it) and returns MKWS_ERR_EXCHANGE: the earlier result is
  * invalid, the repeated call is correct.  A captured hipGraph keeps replaying the paired launch: graph users poll

@@ -288,6 +288,7 @@ struct GemmArgs {
   int pool4;       // 1: global average pool fused into the epilogue: the 4 rows of a clip (2x2 image) are averaged, Y is [M/4, N]
   int splitk;      // > 1: blockIdx.z owns a slice of the K chunks and writes raw sums to part[z][M][ldp]
   float* part; int ldp;
+  const int* poison;   // optional device word: nonzero = an earlier kernel of this forward failed (mbconv_pair_kernel's exchange): store NaN
 };
 
 template <int MT, int NT, bool GATE>
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
     return;
   }
   // epilogue: lane (g, c) holds rows m = m0 + mt*16 + c, channels n = 16*(nt0+nt) + 4g .. +3
+  const bool poisoned = a.poison != nullptr && *a.poison != 0;       // uniform (scalar load)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (nt0 + nt) * 16 + 4 * g;
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
         y = apply_act4(y, a.act);
       }
       if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+      if (poisoned) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
       if (a.pool4) {
         // rows 4i..4i+3 of the tile sit in lanes c = 4i..4i+3 of the same lane group: two xor-shuffles fold them
         // (M is a multiple of 4, so a clip's rows are valid together; shuffles run on all lanes of the wave)
@@ -472,8 +475,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
 // split-K epilogue: Y = act(sum_z part[z] * scale + shift) + R, one float4 per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splitk, int M, int N, int ldp,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                                            const float* __restrict__ R, int ldr, float* __restrict__ Y, int ldy) {
+                                                            const float* __restrict__ R, int ldr, float* __restrict__ Y, int ldy,
+                                                            const int* __restrict__ poison) {
   const int nq = N / 4;
+  const bool poisoned = poison != nullptr && *poison != 0;
   const long total = (long)M * nq;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long m = i / nq;
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     f32x4 y = v * *reinterpret_cast<const f32x4*>(scale + n) + *reinterpret_cast<const f32x4*>(shift + n);
     if (act != ACT_NONE) y = apply_act4(y, act);
     if (R) y += *reinterpret_cast<const f32x4*>(R + (size_t)m * ldr + n);
+    if (poisoned) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
     *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + n) = y;
   }
 }
@@ -2648,7 +2654,7 @@ int pick_cqb(int cq) {   // largest divisor of cq that is <= 64
 }
 
 // split-K workspace: part of the handle's own workspace, handed to every launch_gemm of its forward
-struct SplitWs { float* p = nullptr; size_t floats = 0; };
+struct SplitWs { float* p = nullptr; size_t floats = 0; const int* poison = nullptr; };   // poison: see GemmArgs (set for the LAST layer only)
 
 template <int MT, bool GATE>
 void launch_gemm_nt(int NT, dim3 grid, hipStream_t s, const GemmArgs& a) {
@@ -2687,6 +2693,7 @@ void launch_gemm(hipStream_t s, const SplitWs& sw, const char* stage, const Gemm
                  const float* R, int ldr, float* Y, int ldy, int pool4 = 0) {
   GemmArgs a;
   a.pool4 = pool4;
+  a.poison = sw.poison;
   a.X = X; a.ldx = ldx; a.Wp = L.Wp; a.scale = L.scale; a.shift = L.shift; a.gate = gate; a.HW = HW > 0 ? HW : 1;
   a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy; a.M = M; a.K = L.K; a.N = L.N; a.KC = L.KC; a.NTtot = L.NTtot; a.act = act;
   TileChoice tc = pick_tile(Mplan, L.NTtot, L.KC);
@@ -2711,7 +2718,7 @@ void launch_gemm(hipStream_t s, const SplitWs& sw, const char* stage, const Gemm
     ProfScope ps(std::string(stage) + "#reduce", "splitk_reduce_kernel");
     const long total = (long)M * (L.N / 4);
     int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, a.part, a.splitk, M, L.N, a.ldp, L.scale, L.shift, act, R, ldr, Y, ldy);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, s, a.part, a.splitk, M, L.N, a.ldp, L.scale, L.shift, act, R, ldr, Y, ldy, a.poison);
   }
 }
 
@@ -3229,6 +3236,9 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
   launch_gemm(s, sw, "dense_1", em->dense1, em->d0, kDense0, B, em->max_batch, ACT_RELU, nullptr, 0, nullptr, 0, em->d1, kDense1);
   if (hit("dense_1", em->d1, (size_t)B * kDense1)) return MKWS_OK;
   float* out = d_emb ? d_emb : em->d0;
+  // NaN from a failed pair exchange does not survive the ReLUs above (max(NaN, 0) = 0), so the LAST layer reads the sticky error
+  // word itself: a forward that ran a failed exchange returns all-NaN embeddings, never plausible numbers
+  sw.poison = em->pair_err_dev;
   launch_gemm(s, sw, "dense_2", em->dense2, em->d1, kDense1, B, em->max_batch, ACT_SELU, nullptr, 0, nullptr, 0, out, kEmbDim);
   if (hit("dense_2", out, (size_t)B * kEmbDim)) return MKWS_OK;
   if (stop) return fail(MKWS_ERR_INVALID_ARG, "unknown stage '%s'", stop);

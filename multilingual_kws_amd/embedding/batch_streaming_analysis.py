@@ -102,6 +102,61 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
     return res[0] if single else res
 
 
+class StreamingSession:
+    """Live serving of the reference's window loop (batch_streaming_analysis.py:99-117), one or a few windows at a time: the
+    newest `batch` one-second windows -> micro-frontend -> embedding -> every keyword head, as ONE hipGraph replay.
+
+    At batch 1 the path is ~65 small launches; issued one by one each costs a host round trip, so a window took 0.55 ms with
+    the GPU mostly idle.  All mkws_* calls are asynchronous, allocation-free and synchronisation-free on the caller's stream
+    (include/mkws.h), so the whole chain is captured once and replayed: the per-window host cost is one copy into the static
+    input and one graph launch.  Results are the same launches on the same buffers, i.e. bit-identical to the eager calls.
+
+    models: TransferLearnedModel(s) sharing one embedding (or pass embedding= and heads= directly)."""
+
+    def __init__(self, models=None, model_settings=None, batch=1, embedding=None, heads=None, use_graph=True):
+        import torch
+        from ..head import Head
+        if models is not None:
+            mlist = list(models) if isinstance(models, (list, tuple)) else [models]
+            embedding, heads = mlist[0].embedding, [m.head for m in mlist]
+        self.embedding, self.heads, self.batch = embedding, list(heads), int(batch)
+        if self.batch > embedding.max_batch:
+            raise ValueError(f"StreamingSession(batch={batch}) exceeds the embedding handle's max_batch={embedding.max_batch}")
+        ms = model_settings or input_data.standard_microspeech_model_settings(3)
+        self.samples = ms["desired_samples"]
+        self.fe = input_data._frontend_for(ms, self.samples)
+        dev = embedding.device
+        self.audio = torch.zeros((self.batch, self.samples), dtype=torch.float32, device=dev)      # static graph input
+        self._Head = Head
+        self.graph = None
+        self.probs = self._chain()                      # eager pass: creates every lazily-built table / attribute
+        if use_graph:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._chain()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.probs = self._chain()
+            self.graph = g
+
+    def _chain(self):
+        return self._Head.forward_many(self.heads, self.embedding.forward(self.fe.forward(self.audio)))
+
+    def infer(self, audio):
+        """audio: [samples] or [batch, samples] float32 (numpy, CPU or CUDA tensor) -> CUDA tensor [n_heads, batch, 3] of softmax
+        outputs (a view of the session's static output: valid until the next infer)."""
+        import torch
+        a = audio if torch.is_tensor(audio) else torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
+        self.audio.copy_(a.reshape(self.batch, self.samples), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.probs = self._chain()
+        return self.probs
+
+
 def detect(inferences, flags: StreamFlags, threshold, sample_rate=16000, data_samples=None):
     """Runs the detector over per-window softmax outputs; returns (found_words, found_words_w_confidences)
     exactly as the reference collects them (:143-167)."""

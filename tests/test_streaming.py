@@ -135,3 +135,31 @@ def test_streaming_inferences_match_per_window_predict(tmp_path):
     assert np.array_equal(inf_chunked[:len(offs)], inf[0])
     tail = np.stack([audio[32000 + o:32000 + o + 16000] for o in tail_offs])
     assert np.array_equal(inf_chunked[len(offs):], models[0].predict(input_data.to_micro_spectrogram(ms, tail)[..., None]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 4])
+def test_streaming_session_graph_replay_equals_eager_predict(batch):
+    """StreamingSession: the live window loop as one hipGraph replay per window.  Every replay must equal the
+    reference semantics -- to_micro_spectrogram(window) -> model.predict -- bit for bit, for every keyword head."""
+    torch = pytest.importorskip("torch")
+    from multilingual_kws_amd import synth
+    from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+    from multilingual_kws_amd.head import Head
+    ms = input_data.standard_microspeech_model_settings(3)
+    emb, blob = tl.load_base_model("synthetic", max_batch=batch)
+    models = [tl.TransferLearnedModel(emb, Head(max_batch=batch, seed=s), blob, "synthetic") for s in range(5)]
+    sess = bsa.StreamingSession(models, ms, batch=batch)
+    assert sess.graph is not None
+    eager = bsa.StreamingSession(models, ms, batch=batch, use_graph=False)
+    clips = synth.clips_float32(3 * batch)
+    for k in (0, 1, 2, 1):
+        a = clips[k * batch:(k + 1) * batch]
+        got = sess.infer(a if k else torch.from_numpy(a).cuda()).clone()            # numpy and CUDA inputs
+        torch.cuda.synchronize()
+        specs = input_data.to_micro_spectrogram(ms, a)
+        for m, g in zip(models, got):
+            assert np.array_equal(g.cpu().numpy(), m.predict(specs[..., None]))
+        assert torch.equal(eager.infer(a), got)
+    with pytest.raises(ValueError):
+        bsa.StreamingSession(models, ms, batch=batch + 1)
