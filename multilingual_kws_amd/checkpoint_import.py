@@ -23,9 +23,12 @@ model prefixes and ":0" dropped); when an object graph has no usable full names,
 object-graph order against the manifest's layer order (identical to Keras' layer order for this architecture).
 
 HONEST STATUS: the released checkpoint is a GitHub release asset and cannot be fetched in this environment, and
-TensorFlow cannot be installed, so this reader is verified against bundles written by the independent minimal
-writer in tests/util_bundle.py (both block encodings, snappy literals/copies by known-answer vectors, CRC32C
-known answers) -- NOT yet against `multilingual_context_73_0.8011` itself.
+TensorFlow cannot be installed, so this reader is verified against (a) tests/golden/tf_bundle/, a bundle assembled byte
+by byte from the format specifications by a script that shares no code with this module or with the test writer
+(tests/golden/make_tf_bundle_fixture.py), (b) bundles written by the minimal writer in tests/util_bundle.py (same
+author as this reader: a self-comparison, kept for coverage of the object graph and multi-shard layouts), (c) snappy /
+CRC-32C known-answer vectors -- NOT yet against `multilingual_context_73_0.8011` itself.
+`python tools/import_savedmodel.py --verify <dir>` prints per-tensor shape / CRC verdict / sha1 for whoever holds it.
 """
 import os
 import struct

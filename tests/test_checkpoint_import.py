@@ -144,3 +144,45 @@ def test_load_base_model_dispatches_on_a_savedmodel_directory(tmp_path, monkeypa
     monkeypatch.setattr(tl, "EmbeddingModel", FakeEmbedding)
     _, got = tl.load_base_model(path, max_batch=4)
     assert np.array_equal(got, blob) and seen["blob"] is got
+
+
+def test_hand_assembled_bundle_from_the_format_specs(golden_dir, tmp_path):
+    """tests/golden/tf_bundle/: a tensor bundle written byte by byte from the LevelDB table-format / tensor_bundle.proto / snappy /
+    CRC-32C specifications by tests/golden/make_tf_bundle_fixture.py, which shares no code with the reader or with util_bundle.py
+    (one snappy-compressed data block: a literal of each length class and a 2-byte-offset copy; prefix-compressed keys; a
+    two-entry restart array; masked block and tensor CRCs).  The first evidence for the reader that is not its author's writer."""
+    import json
+    import shutil
+    d = os.path.join(golden_dir, "tf_bundle")
+    E = json.load(open(os.path.join(d, "expected.json")))
+    import hashlib
+    assert hashlib.sha1(open(os.path.join(d, "variables.index"), "rb").read()).hexdigest() == E["index_sha1"]
+    rd = ci.BundleReader(os.path.join(d, "variables"), verify=True)
+    assert sorted(rd.entries) == sorted(E["tensors"]) and rd.num_shards == 1
+    for key, exp in E["tensors"].items():
+        t = rd.tensor(key, verify_crc=True)
+        assert t.dtype == np.float32 and list(t.shape) == exp["shape"]
+        assert np.array_equal(t.ravel(), np.asarray(exp["values"], np.float32))
+        assert np.signbit(t.ravel()[1]) == np.signbit(np.float32(exp["values"][1]))          # -0.0 survives
+        assert ci.crc32c(t.tobytes()) == exp["crc32c"] and rd.entries[key]["crc32c"] == ci.mask_crc(exp["crc32c"])
+    # corruption is noticed at the right layer: a flipped tensor byte -> tensor CRC; a flipped index byte -> block CRC
+    for name, offset, needs in (("variables.data-00000-of-00001", 14, "tensor checksum"), ("variables.index", 40, "block checksum")):
+        bad = tmp_path / ("bad_" + name.split(".")[1][:4])
+        shutil.copytree(d, bad)
+        raw = bytearray(open(bad / name, "rb").read())
+        raw[offset] ^= 0x10
+        open(bad / name, "wb").write(bytes(raw))
+        with pytest.raises(ci.CheckpointFormatError, match=needs):
+            r2 = ci.BundleReader(str(bad / "variables"), verify=True)
+            for key in r2.entries:
+                r2.tensor(key, verify_crc=True)
+    # the --verify report of tools/import_savedmodel.py: one line per tensor with shape, CRC verdict and sha1
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "import_savedmodel.py"), "--verify", d], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for key, exp in E["tensors"].items():
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith(key + " ")]
+        assert len(line) == 1 and exp["sha1"] in line[0] and "crc32c ok" in line[0] and str(exp["shape"]).replace(" ", "") in line[0].replace(" ", "")
+    assert "2 tensors, 0 bad" in out.stdout

@@ -3,14 +3,72 @@
 WITHOUT TensorFlow (multilingual_kws_amd/checkpoint_import.py reads the variables bundle directly).
 
     python tools/import_savedmodel.py /path/to/multilingual_context_73_0.8011 out_dir
+    python tools/import_savedmodel.py --verify /path/to/multilingual_context_73_0.8011
 
-(transfer_learn / load_base_model also accept the SavedModel directory itself.)"""
+(transfer_learn / load_base_model also accept the SavedModel directory itself.)
+
+--verify imports nothing: it walks the variables bundle (<dir>/variables/variables.* or <dir>/variables.*), checks every
+block CRC of the index and every tensor's stored CRC-32C against its bytes, and prints one line per tensor
+
+    <checkpoint key> <dtype> <shape> <bytes> crc32c ok|MISMATCH|absent sha1 <sha1 of the tensor bytes> [-> <Keras variable name>]
+
+followed by whether the embedding architecture's 300+ tensors are all present -- so that whoever holds the released
+checkpoint (docker/Dockerfile:69-70 of the reference) can confirm the reader against the real file in one command and
+compare the sha1s with `tf.train.load_checkpoint(...).get_tensor(key).tobytes()`.  Exit code 1 on any mismatch."""
+import hashlib
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+
+def verify(path):
+    import numpy as np
+    from multilingual_kws_amd import checkpoint_import as ci
+    prefix = os.path.join(path, "variables", "variables")
+    if not os.path.exists(prefix + ".index"):
+        prefix = os.path.join(path, "variables")
+    if not os.path.exists(prefix + ".index"):
+        raise SystemExit(f"{path}: no variables/variables.index (SavedModel) and no variables.index (bare bundle)")
+    rd = ci.BundleReader(prefix, verify=True)                  # raises on a bad index block
+    names = {}
+    try:
+        info = ci.load_savedmodel(path, verify=True) if os.path.exists(os.path.join(path, "variables", "variables.index")) else None
+        if info:
+            names = {v: k for k, v in info["named"].items()}
+    except Exception as exc:                                    # a bare bundle has no object graph: keys only
+        print(f"# no variable names: {exc}")
+    bad = n = 0
+    for key in sorted(rd.entries):
+        e = rd.entries[key]
+        if e["dtype"] == ci.DT_STRING:
+            print(f"{key} string {e['shape']} {e['size']} (not checked)")
+            continue
+        raw = bytes(rd.raw(key))
+        if e["crc32c"] is None:
+            verdict = "absent"
+        elif ci.mask_crc(ci.crc32c(raw)) == e["crc32c"]:
+            verdict = "ok"
+        else:
+            verdict, bad = "MISMATCH", bad + 1
+        n += 1
+        dt = ci.DTYPES.get(e["dtype"])
+        print(f"{key} {np.dtype(dt).name if dt is not None else 'dtype' + str(e['dtype'])} {e['shape']} {len(raw)} crc32c {verdict} "
+              f"sha1 {hashlib.sha1(raw).hexdigest()}" + (f" -> {names[key]}" if key in names else ""))
+    print(f"# {n} tensors, {bad} bad")
+    if names:
+        from multilingual_kws_amd import weights
+        missing = [t["name"] for t in weights.manifest() if t["name"] not in set(names.values())]
+        print(f"# embedding architecture: {len(weights.manifest()) - len(missing)} of {len(weights.manifest())} tensors found by name"
+              + (f"; missing e.g. {missing[:3]} (the importer then matches layers positionally)" if missing else ""))
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--verify":
+        raise SystemExit(verify(sys.argv[2]))
+    if len(sys.argv) != 3:
+        raise SystemExit(__doc__)
     from multilingual_kws_amd import checkpoint_import, weights
     src, dst = sys.argv[1], sys.argv[2]
     blob = checkpoint_import.import_savedmodel(src)
