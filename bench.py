@@ -363,9 +363,15 @@ def main():
         units_per_step, unit = nwin, "windows/s"
 
         def step():
+            # = batch_streaming_analysis.streaming_inferences without the final device-to-host copy: full batches replay one
+            # captured hipGraph (embedding + 50 heads), the ragged last batch runs launch by launch
             specs = bsa.stream_spectrograms(ms, stream, 16000, 320)
             for s in range(0, specs.shape[0], B):
-                Head.forward_many(heads, em.forward(specs[s:s + B]))
+                part = specs[s:s + B]
+                if part.shape[0] == B:
+                    bsa._BatchGraph.get(em, heads, B).run(part)
+                else:
+                    Head.forward_many(heads, em.forward(part))
 
     def fence():
         torch.cuda.synchronize()

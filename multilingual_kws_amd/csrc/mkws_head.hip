@@ -26,6 +26,135 @@ struct HeadDims { int in, hid, cls; };
 constexpr int kHeadsPerLaunch = 64;
 struct HeadTable { const float* p[kHeadsPerLaunch]; };
 
+// Inference forward on the fp32 matrix cores (mkws_head_forward and the multi-keyword mkws_heads_forward).
+// The per-row kernel below spends its time on latency: 50 heads x 256 windows took 94 us for 0.47 GFLOP, one wave per SIMD with
+// ~300 live registers.  Here a wave owns 16 rows x (up to) 32 hidden units of ONE head: z1^T[hid, rows] = W1^T[hid, in] . x^T[in, rows]
+// as NT = ceil(hid / 16) tiles of v_mfma_f32_16x16x4_f32 (A = weights, B = activations, exactly as in pw_gemm_kernel), K walked in
+// ascending chunks of 16, so a row's result depends on nothing but that row and the head's parameters (bit-identical across batch
+// sizes, and between the single-head and the multi-head entry point).  Lane (g, c) supplies W1[16j + 4g + s][16 nt + c] (four
+// dword loads 72 B apart: the Keras [in, hid] layout is kept, the heads stay trainable in place) and x[row c][16j + 4g .. + 3]
+// (one float4).  Epilogue in registers: tanh, the hid x cls second layer as per-lane partial sums folded across the four lane
+// groups by two xor-shuffles, softmax on every lane, lane group 0 stores.  Needs in % 16 == 0 and hid <= 32.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int NT, bool MULTI>
+__global__ __launch_bounds__(256) void head_fwd_mfma_kernel(HeadDims d, const float* __restrict__ params, const float* __restrict__ x, int B,
+                                                            float* __restrict__ probs, HeadTable table) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int row0 = (blockIdx.x * 4 + wave) * 16;
+  if (row0 >= B) return;
+  if (MULTI) {
+    params = table.p[blockIdx.y];
+    probs += (size_t)blockIdx.y * B * d.cls;
+  }
+  const float* W1 = params;
+  const float* b1 = W1 + (size_t)d.in * d.hid;
+  const float* W2 = b1 + d.hid;
+  const float* b2 = W2 + (size_t)d.hid * d.cls;
+  const int row = row0 + c;
+  // operands as buffer descriptors + 32-bit lane offsets + the K-chunk offset in an SGPR: the steady state issues no VALU address
+  // arithmetic (see pw_gemm_kernel).  Columns past hid re-read column 0: their accumulator rows are never looked at.
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W1), 0, 0x7fffffff, 0x00020000);
+  const unsigned xoff = (unsigned)(((size_t)(row < B ? row : B - 1) * d.in + 4 * g) * sizeof(float));
+  unsigned woff[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = (16 * nt + c < d.hid) ? 16 * nt + c : 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) woff[nt][s] = (unsigned)(((4 * g + s) * d.hid + col) * sizeof(float));
+  }
+  const unsigned wchunk = (unsigned)(16 * d.hid * sizeof(float));
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int KC = d.in / 16;
+  constexpr int D = 4;                           // chunks in flight per wave
+  f32x4 xq[D];
+  float wq[D][NT][4];
+  auto load = [&](int j, f32x4& xv, float (&wv)[NT][4]) {
+    xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, xoff, 64u * (unsigned)j, 0));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wv[nt][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, woff[nt][s], wchunk * (unsigned)j, 0));
+  };
+  auto compute = [&](const f32x4& xv, const float (&wv)[NT][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][s], xv[s], acc[nt], 0, 0, 0);
+  };
+  if (KC >= D) {                                 // unconditional prologue / branch-free steady state / drain (hipcc then counts vmcnt)
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) load(dd, xq[dd], wq[dd]);
+    int j = 0;
+    for (; j + 2 * D <= KC; j += D) {
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) {
+        compute(xq[dd], wq[dd]);
+        load(j + D + dd, xq[dd], wq[dd]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      compute(xq[dd], wq[dd]);
+      if (j + D + dd < KC) load(j + D + dd, xq[dd], wq[dd]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    j += D;
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd)
+      if (j + dd < KC) compute(xq[dd], wq[dd]);
+  } else {
+    for (int j = 0; j < KC; ++j) {
+      load(j, xq[0], wq[0]);
+      compute(xq[0], wq[0]);
+    }
+  }
+  // acc[nt][r] = pre-activation of hidden unit 16 nt + 4 g + r for row c
+  float z[kMaxClasses];
+#pragma unroll
+  for (int k = 0; k < kMaxClasses; ++k) z[k] = 0.0f;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 16 * nt + 4 * g + r;
+      if (u < d.hid) {
+        const float h = tanhf(acc[nt][r] + b1[u]);
+#pragma unroll
+        for (int k = 0; k < kMaxClasses; ++k)
+          if (k < d.cls) z[k] += h * W2[u * d.cls + k];
+      }
+    }
+  float zmax = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < kMaxClasses; ++k) {
+    if (k < d.cls) {
+      z[k] += __shfl_xor(z[k], 16, 64);
+      z[k] += __shfl_xor(z[k], 32, 64);
+      z[k] += b2[k];
+      zmax = fmaxf(zmax, z[k]);
+    }
+  }
+  float e[kMaxClasses], esum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kMaxClasses; ++k) {
+    e[k] = (k < d.cls) ? expf(z[k] - zmax) : 0.0f;
+    esum += e[k];
+  }
+  const float inv = 1.0f / esum;
+  if (g == 0 && row < B) {
+#pragma unroll
+    for (int k = 0; k < kMaxClasses; ++k)
+      if (k < d.cls) probs[(size_t)row * d.cls + k] = e[k] * inv;
+  }
+}
+
 // R rows per wave: every W1 value a lane loads is used for R rows (the 50-head serving launch re-read each head's 73 KB of W1 once
 // per row and wave: 121 us per 256 windows).  The arithmetic of one row does not depend on R, so the results are bit-identical.
 template <bool TRAIN, bool MULTI = false, int R = 1>
@@ -348,8 +477,15 @@ int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, 
   if (B < 0) return fail(MKWS_ERR_INVALID_ARG, "negative batch");
   if (B == 0) return MKWS_OK;
   if (!d_emb || !d_probs) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
-  hipLaunchKernelGGL((head_rows_kernel<false>), dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb,
-                     nullptr, B, d_probs, nullptr, nullptr, nullptr, nullptr);
+  if (hd->d.in % 16 == 0) {        // matrix-core path (the same kernel serves mkws_heads_forward: results are bit-identical between the two)
+    if (hd->d.hid <= 16)
+      hipLaunchKernelGGL((head_fwd_mfma_kernel<1, false>), dim3((B + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb, B, d_probs, HeadTable());
+    else
+      hipLaunchKernelGGL((head_fwd_mfma_kernel<2, false>), dim3((B + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb, B, d_probs, HeadTable());
+  } else {
+    hipLaunchKernelGGL((head_rows_kernel<false>), dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb,
+                       nullptr, B, d_probs, nullptr, nullptr, nullptr, nullptr);
+  }
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -369,8 +505,17 @@ int mkws_heads_forward(mkws_head* const* heads, int n_heads, const float* d_emb,
     const int n = (n_heads - h0 < kHeadsPerLaunch) ? n_heads - h0 : kHeadsPerLaunch;
     HeadTable t;
     for (int i = 0; i < kHeadsPerLaunch; ++i) t.p[i] = heads[h0 + (i < n ? i : 0)]->params;
-    hipLaunchKernelGGL((head_rows_kernel<false, true, 4>), dim3((B + 15) / 16, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb,
-                       nullptr, B, d_probs + (size_t)h0 * B * d.cls, nullptr, nullptr, nullptr, nullptr, t);
+    if (d.in % 16 == 0) {
+      if (d.hid <= 16)
+        hipLaunchKernelGGL((head_fwd_mfma_kernel<1, true>), dim3((B + 63) / 64, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb, B,
+                           d_probs + (size_t)h0 * B * d.cls, t);
+      else
+        hipLaunchKernelGGL((head_fwd_mfma_kernel<2, true>), dim3((B + 63) / 64, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb, B,
+                           d_probs + (size_t)h0 * B * d.cls, t);
+    } else {
+      hipLaunchKernelGGL((head_rows_kernel<false, true, 4>), dim3((B + 15) / 16, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb,
+                         nullptr, B, d_probs + (size_t)h0 * B * d.cls, nullptr, nullptr, nullptr, nullptr, t);
+    }
   }
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;

@@ -76,8 +76,48 @@ def stream_spectrograms(model_settings, audio, clip_duration_samples, clip_strid
     return fe.stream(audio_t, clip_duration_samples, clip_stride_samples)[:nwin]
 
 
+class _BatchGraph:
+    """embedding.forward + every head over a FULL batch of `batch` spectrograms as one hipGraph (static input / output); cached per
+    (embedding handle, head handles, batch) so that a stream of many batches -- and the next stream -- replays it."""
+    _cache = {}
+
+    def __init__(self, embedding, heads, batch):
+        import torch
+        from ..head import Head
+        dev = embedding.device
+        self.keep = (embedding, list(heads))                         # the graph holds raw handles: keep their owners alive
+        self.spec = torch.zeros((batch, 49, 40), dtype=torch.float32, device=dev)
+
+        def chain():
+            return Head.forward_many(heads, embedding.forward(self.spec))
+        chain()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            chain()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.probs = chain()
+
+    @classmethod
+    def get(cls, embedding, heads, batch):
+        key = (id(embedding), embedding.h.value, tuple(h.h.value for h in heads), int(batch))
+        g = cls._cache.get(key)
+        if g is None:
+            if len(cls._cache) >= 8:
+                cls._cache.clear()
+            g = cls._cache[key] = cls(embedding, heads, batch)
+        return g
+
+    def run(self, spec):
+        self.spec.copy_(spec)
+        self.graph.replay()
+        return self.probs
+
+
 def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_duration_ms=1000, clip_stride_ms=20,
-                         batch_windows=4096, max_chunk_length_sec=None):
+                         batch_windows=4096, max_chunk_length_sec=None, use_graph=True):
     """Softmax outputs for every window.  `models`: one TransferLearnedModel or a list sharing one embedding
     (multi-keyword serving: the EfficientNet forward runs once, each keyword adds only its 18.5 k-parameter
     head).  Returns [num_windows, 3] (or a list of them)."""
@@ -93,9 +133,16 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
     max_chunk = None if max_chunk_length_sec is None else int(max_chunk_length_sec * sample_rate)
     for chunk in chunk_audio(audio_arr, max_chunk):
         specs = stream_spectrograms(model_settings, chunk, clip, stride)
-        for s in range(0, specs.shape[0], batch_windows):
-            emb = emb_model.forward(specs[s:s + batch_windows])
-            probs = Head.forward_many([m.head for m in mlist], emb)          # [N, windows, 3] in one launch
+        heads = [m.head for m in mlist]
+        bw = min(batch_windows, emb_model.max_batch)
+        for s in range(0, specs.shape[0], bw):
+            part = specs[s:s + bw]
+            if use_graph and part.shape[0] == bw and tuple(part.shape[1:]) == (49, 40):
+                # full batches replay one captured graph (~65 launches per batch otherwise, each a host round trip); the results are
+                # the same launches on the same plan, so they equal the eager path bit for bit
+                probs = _BatchGraph.get(emb_model, heads, bw).run(part).clone()
+            else:
+                probs = Head.forward_many(heads, emb_model.forward(part))        # [N, windows, 3] in one launch
             for k in range(len(mlist)):
                 outs[k].append(probs[k])
     res = [torch.cat(o).cpu().numpy() if o else np.zeros((0, 3), np.float32) for o in outs]
