@@ -362,16 +362,23 @@ def main():
         nwin = len(bsa.window_offsets(stream.shape[0], 16000, 320))
         units_per_step, unit = nwin, "windows/s"
 
+        lanes = int(os.environ.get("MKWS_SERVING_LANES", bsa.SERVING_LANES))
+
         def step():
-            # = batch_streaming_analysis.streaming_inferences without the final device-to-host copy: full batches replay one
-            # captured hipGraph (embedding + 50 heads), the ragged last batch runs launch by launch
+            # = batch_streaming_analysis.streaming_inferences without the final device-to-host copy: full batches replay a captured
+            # hipGraph (embedding + 50 heads), `lanes` independent batches per replay; the ragged last batch runs launch by launch
             specs = bsa.stream_spectrograms(ms, stream, 16000, 320)
-            for s in range(0, specs.shape[0], B):
-                part = specs[s:s + B]
-                if part.shape[0] == B:
-                    bsa._BatchGraph.get(em, heads, B).run(part)
+            nfull, s = specs.shape[0] // B, 0
+            while s < specs.shape[0]:
+                left = nfull - s // B
+                if left > 0:
+                    n = min(lanes, left)
+                    bsa._BatchGraph.get(em, heads, B, n).run([specs[s + i * B:s + (i + 1) * B] for i in range(n)])
+                    s += n * B
                 else:
-                    Head.forward_many(heads, em.forward(part))
+                    Head.forward_many(heads, em.forward(specs[s:s + B]))
+                    s += B
+        extra_out["serving_lanes"] = lanes
 
     def fence():
         torch.cuda.synchronize()

@@ -159,19 +159,19 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  * Execution options (A/B switches for measurement; results are equal up to fp32 rounding):
  *   "fuse_front" (default 1): expand 1x1 conv + depthwise conv in one kernel (expanded tensor stays in LDS);
  *                 0 = separate GEMM and depthwise kernels.
- *   "fuse_block" (default 2 for handles with max_batch >= 384, else 0): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
+ *   "fuse_block" (default 2): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
  *                 ONE kernel, 4 clips per workgroup, activations resident in LDS; 1 = only the 2x2 blocks
  *                 (6b..7a); 0 = the multi-kernel path everywhere.
- *   "fuse_pair" (default 1 for handles with max_batch >= 384, else 0; needs "fuse_block"): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a) run on
+ *   "fuse_pair" (default 1 when the probe at create passed; needs "fuse_block"): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a) run on
  *                 the PAIRED whole-block kernel: two workgroups on two CUs of one XCD share 8 clips and split the expanded channels,
  *                 so each CU streams half of the block's weights; two small in-kernel exchanges through L2.  0 = one workgroup per 4 clips.
  *                 mkws_embed_create turns it on only after a probe launch has shown that workgroups b and b^8 share an XCD on this device.
  *                 Handles with max_batch <= 512 pair 4 clips (and give the 4x3-image whole-block kernels 2 clips per workgroup) so that
  *                 every CU still gets a workgroup.
- *   "fuse_back" (default 1 for handles with max_batch >= 384, else 0): blocks 2a, 2b, 3b run squeeze-excite + gated projection as
+ *   "fuse_back" (default 1): blocks 2a, 2b, 3b run squeeze-excite + gated projection as
  *                 ONE kernel behind the fused expand+depthwise kernel (the clip's depthwise output is staged in LDS once);
  *                 0 = se_reduce + se_expand + projection GEMM launches.
- *   "fuse_mid" (default 1 for handles with max_batch >= 384, else 0): blocks with big images run expand -> depthwise -> SE ->
+ *   "fuse_mid" (default 1): blocks with big images run expand -> depthwise -> SE ->
  *                 project as ONE kernel per block (depthwise output of all channels resident in LDS): 1 = blocks 3a and 4a
  *                 (where it measured faster than the three-kernel path), 2 = all of 2a..4a, 0 = never.
  *   "fuse_gap" (default 1): global average pool fused into the top conv epilogue (its [B*4,1280] output is never stored).

@@ -3291,14 +3291,17 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   mkws_embed* em = new (std::nothrow) mkws_embed();
   if (!em) return fail(MKWS_ERR_ALLOC, "out of host memory");
   em->max_batch = max_batch;
-  // Whole-block kernels re-stream a block's weights once per 4 clips: that pays from a few hundred clips up
-  // (measured crossover between 256 and 512, tools/latency_sweep.py); small-batch (serving) handles use the
-  // multi-kernel path, which spreads the weights of a layer over the chip.  Per handle, so results stay
-  // bit-identical across the batch sizes one handle sees.
-  em->fuse_block = (max_batch >= 384) ? 2 : 0;
-  em->fuse_mid = (max_batch >= 384) ? 1 : 0;
-  em->fuse_back = (max_batch >= 384) ? 1 : 0;
-  em->fuse_pair = (max_batch >= 384 && pair_layout_ok()) ? 1 : 0;
+  // Plan: whole-block kernels (+ the paired kernel where the device's dispatch order passed the probe) for EVERY handle size.
+  // Round 2 gave handles below 384 clips the multi-kernel path (a whole-block kernel re-streams a block's weights once per 4
+  // clips, and with launch-by-launch calls that lost below ~300 clips).  Since the serving paths replay hipGraphs the count of
+  // dependent launches is what a small batch pays for (23 instead of ~65): tools/plan_sweep.py, graph replay, clips/s multi-kernel
+  // vs whole-block + pair: batch 1 2243 / 2289, 16 31.9 k / 34.7 k, 64 122 k / 136 k, 256 396 k / 479 k, 384 511 k / 630 k.
+  // The multi-kernel path stays behind mkws_embed_set_option (A/B, parity taps).  Per handle, so results stay bit-identical
+  // across the batch sizes one handle sees.
+  em->fuse_block = 2;
+  em->fuse_mid = 1;
+  em->fuse_back = 1;
+  em->fuse_pair = pair_layout_ok() ? 1 : 0;
   em->pair_mt = pair_row_tiles(max_batch);
   em->block_mt43 = (em->pair_mt == 1) ? 2 : 3;
   (void)hipGetDevice(&em->device);

@@ -77,43 +77,62 @@ def stream_spectrograms(model_settings, audio, clip_duration_samples, clip_strid
 
 
 class _BatchGraph:
-    """embedding.forward + every head over a FULL batch of `batch` spectrograms as one hipGraph (static input / output); cached per
-    (embedding handle, head handles, batch) so that a stream of many batches -- and the next stream -- replays it."""
+    """embedding.forward + every head over `lanes` FULL batches of `batch` spectrograms as ONE hipGraph replay (static inputs /
+    outputs); cached per (embedding handle, head handles, batch, lanes).
+
+    Why lanes: at 256 windows the embedding is ~60 small dependent launches, and the GPU sits mostly idle between and inside them
+    (each uses a fraction of the 256 CUs).  The batches of a stream are independent, so the graph forks into `lanes` branches --
+    one embedding handle (= one workspace) per branch, the heads are read-only and shared -- which the hardware queues run
+    concurrently.  Every branch is the same launches on the same plan as an eager call: results are bit-identical."""
     _cache = {}
 
-    def __init__(self, embedding, heads, batch):
+    def __init__(self, embedding, heads, batch, lanes=1):
         import torch
         from ..head import Head
         dev = embedding.device
-        self.keep = (embedding, list(heads))                         # the graph holds raw handles: keep their owners alive
-        self.spec = torch.zeros((batch, 49, 40), dtype=torch.float32, device=dev)
+        ems = embedding.replicas(lanes)
+        self.keep = (ems, list(heads))                               # the graph holds raw handles: keep their owners alive
+        self.lanes = lanes
+        self.specs = [torch.zeros((batch, 49, 40), dtype=torch.float32, device=dev) for _ in range(lanes)]
 
-        def chain():
-            return Head.forward_many(heads, embedding.forward(self.spec))
-        chain()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            chain()
-        torch.cuda.current_stream(dev).wait_stream(side)
+        def chain(i):
+            return Head.forward_many(heads, ems[i].forward(self.specs[i]))
+        side = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        for i in range(lanes):                                       # eager warm-up on side streams (lazy init outside the capture)
+            side[i].wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side[i]):
+                chain(i)
+            torch.cuda.current_stream(dev).wait_stream(side[i])
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.probs = chain()
+            main = torch.cuda.current_stream(dev)
+            self.probs = [chain(0)]
+            for i in range(1, lanes):                                # fork: branch i starts where the capture stream is now
+                side[i].wait_stream(main)
+                with torch.cuda.stream(side[i]):
+                    self.probs.append(chain(i))
+            for i in range(1, lanes):                                # join
+                main.wait_stream(side[i])
 
     @classmethod
-    def get(cls, embedding, heads, batch):
-        key = (id(embedding), embedding.h.value, tuple(h.h.value for h in heads), int(batch))
+    def get(cls, embedding, heads, batch, lanes=1):
+        key = (id(embedding), embedding.h.value, tuple(h.h.value for h in heads), int(batch), int(lanes))
         g = cls._cache.get(key)
         if g is None:
             if len(cls._cache) >= 8:
                 cls._cache.clear()
-            g = cls._cache[key] = cls(embedding, heads, batch)
+            g = cls._cache[key] = cls(embedding, heads, batch, lanes)
         return g
 
-    def run(self, spec):
-        self.spec.copy_(spec)
+    def run(self, parts):
+        """parts: `lanes` tensors [batch,49,40] -> list of [n_heads, batch, 3] (views of the static outputs)."""
+        for dst, src in zip(self.specs, parts):
+            dst.copy_(src)
         self.graph.replay()
         return self.probs
+
+
+SERVING_LANES = 4      # concurrent batches per graph replay in streaming_inferences
 
 
 def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_duration_ms=1000, clip_stride_ms=20,
@@ -135,16 +154,24 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
         specs = stream_spectrograms(model_settings, chunk, clip, stride)
         heads = [m.head for m in mlist]
         bw = min(batch_windows, emb_model.max_batch)
-        for s in range(0, specs.shape[0], bw):
-            part = specs[s:s + bw]
-            if use_graph and part.shape[0] == bw and tuple(part.shape[1:]) == (49, 40):
-                # full batches replay one captured graph (~65 launches per batch otherwise, each a host round trip); the results are
-                # the same launches on the same plan, so they equal the eager path bit for bit
-                probs = _BatchGraph.get(emb_model, heads, bw).run(part).clone()
+        nfull = specs.shape[0] // bw if (use_graph and tuple(specs.shape[1:]) == (49, 40)) else 0
+        s = 0
+        while s < specs.shape[0]:
+            left = nfull - s // bw
+            if left > 0:
+                # full batches replay a captured graph, up to SERVING_LANES of them concurrently (see _BatchGraph); same launches on
+                # the same plan as the eager path, so the results equal it bit for bit
+                lanes = min(SERVING_LANES, left)
+                got = _BatchGraph.get(emb_model, heads, bw, lanes).run([specs[s + i * bw:s + (i + 1) * bw] for i in range(lanes)])
+                for probs in got:
+                    for k in range(len(mlist)):
+                        outs[k].append(probs[k].clone())
+                s += lanes * bw
             else:
-                probs = Head.forward_many(heads, emb_model.forward(part))        # [N, windows, 3] in one launch
-            for k in range(len(mlist)):
-                outs[k].append(probs[k])
+                probs = Head.forward_many(heads, emb_model.forward(specs[s:s + bw]))     # ragged tail: [N, windows, 3] in one launch
+                for k in range(len(mlist)):
+                    outs[k].append(probs[k])
+                s += bw
     res = [torch.cat(o).cpu().numpy() if o else np.zeros((0, 3), np.float32) for o in outs]
     return res[0] if single else res
 

@@ -31,8 +31,18 @@ class EmbeddingModel:
             _lib.check(self.L.mkws_embed_create(blob.ctypes.data, blob.shape[0], int(max_batch), ctypes.byref(h)))
         self.h = h
         self.max_batch = int(max_batch)
+        self._blob, self._replicas = blob, []
+
+    def replicas(self, n):
+        """[self, + n - 1 more handles on the same weights]: a handle owns one workspace, so batches that run CONCURRENTLY (the
+        multi-lane serving graph of embedding.batch_streaming_analysis) need one handle each.  Created on first use, kept."""
+        while len(self._replicas) < n - 1:
+            self._replicas.append(EmbeddingModel(self._blob, self.max_batch, self.device, self.output))
+        return [self] + self._replicas[:n - 1]
 
     def close(self):
+        for r in getattr(self, "_replicas", []):
+            r.close()
         if getattr(self, "h", None):
             self.L.mkws_embed_destroy(self.h)
             self.h = None

@@ -146,8 +146,8 @@ def test_weight_container_roundtrip(ctx, tmp_path):
 
 
 def test_small_batch_handle_plan(ctx):
-    """Handles created for small batches plan the multi-kernel path (mkws_embed_create: fuse_block follows
-    max_batch); same numbers within fp32 rounding, still bit-identical across the batch sizes of that handle."""
+    """A small-batch handle (2-clip workgroups / 4-clip pairs instead of 4 / 8): same numbers within fp32 rounding as the
+    1024-clip handle, bit-identical across the batch sizes of that handle."""
     from multilingual_kws_amd.embedding_model import EmbeddingModel
     spec = _spec(np.random.default_rng(21), 8)
     x = torch.from_numpy(spec).to(ctx["dev"])
@@ -243,15 +243,22 @@ def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault):
     assert _rel(em2.forward(x).cpu().numpy(), ref) < REL_TOL and em2.get_option("pair_degraded") == 1
 
 
+@pytest.mark.parametrize("plan", ["default", "multi-kernel"])
 @pytest.mark.parametrize("max_batch", [1, 2, 256])
-def test_serving_handle_plans(ctx, max_batch):
+def test_serving_handle_plans(ctx, max_batch, plan):
     """The handles bench.py's streaming config builds (BASELINE configs[4]: max_batch 1 for the latency leg, 256 for throughput)
-    against the oracle, with batch-size invariance inside the handle."""
+    against the oracle, with batch-size invariance inside the handle -- on the shipped plan (whole-block kernels for every handle
+    size since round 3) and on the multi-kernel path (split-K projections, separate SE launches) that small handles used before."""
     from multilingual_kws_amd.embedding_model import EmbeddingModel
     n = min(max_batch, 40)
     spec = _spec(np.random.default_rng(60 + max_batch), n)
     x = torch.from_numpy(spec).to(ctx["dev"])
     em = EmbeddingModel(ctx["blob"], max_batch=max_batch)
+    if plan == "multi-kernel":
+        for k in ("fuse_block", "fuse_mid", "fuse_back", "fuse_pair"):
+            em.set_option(k, 0)
+    else:
+        assert em.get_option("fuse_block") == 2 and em.get_option("fuse_mid") == 1
     out = em.forward(x)
     ref = ctx["oracle"].forward(spec).numpy()
     assert _rel(out.cpu().numpy(), ref) < REL_TOL and np.array_equal(out.cpu().numpy().argmax(1), ref.argmax(1))

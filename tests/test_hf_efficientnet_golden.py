@@ -89,6 +89,6 @@ def test_device_trunk_against_the_port(G):
         got = em.tap(x, name).cpu().numpy().reshape(ref.shape)
         worst = max(worst, _rel(got, ref))
         assert _rel(got, ref) < 1e-4, (name, _rel(got, ref))
-    pooled = em.tap(x, "gap").cpu().numpy()
+    pooled = em.tap(x, "gap").cpu().numpy().reshape(G["chain/pooled"].shape)
     assert _rel(pooled, G["chain/pooled"]) < 1e-4
     print(f"device vs HF port: worst relative error {worst:.2e}")

@@ -119,9 +119,9 @@ def test_streaming_inferences_match_per_window_predict(tmp_path):
         assert np.array_equal(got, m.predict(specs[..., None]))            # bit-identical: frame sharing changes nothing
     assert not np.array_equal(inf[0], inf[1])
     # full batches replay a captured hipGraph, the ragged tail runs eagerly: 125 windows = 3 x 32 + 29, twice (cache hit), vs no graph
-    for _ in range(2):
-        inf_g = bsa.streaming_inferences(models, ms, audio, batch_windows=32)
-        assert all(np.array_equal(a, b) for a, b in zip(inf_g, inf))
+    for bw in (32, 32, 16):                # 3 concurrent lanes + tail;  again (cache hit);  4 lanes, then 3, then a tail of 13
+        inf_g = bsa.streaming_inferences(models, ms, audio, batch_windows=bw)
+        assert all(np.array_equal(a, b) for a, b in zip(inf_g, inf)), bw
     assert all(np.array_equal(a, b) for a, b in zip(bsa.streaming_inferences(models, ms, audio, batch_windows=32, use_graph=False), inf))
     flags = bsa.StreamFlags(wav=wav, ground_truth="", target_keyword="kw", detection_thresholds=[0.3, 0.6])
     results, inferences = bsa.calculate_streaming_accuracy(models[0], ms, [flags])
