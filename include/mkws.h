@@ -237,6 +237,10 @@ int mkws_head_input_grad(mkws_head* hd, float* d_dx, int B, void* stream);
  * after a sum all-reduce): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps). */
 int mkws_head_adam_step(mkws_head* hd, float lr, float beta1, float beta2, float eps, int step_t,
                         float grad_scale, void* stream);
+/* The same update with the step index t read from device memory (*d_step >= 1, see mkws_op_step_inc): a captured hipGraph
+ * replays ONE launch for every step, so t cannot be a launch argument there. */
+int mkws_head_adam_step_dev(mkws_head* hd, float lr, float beta1, float beta2, float eps, const int* d_step,
+                            float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-batch assembly.  Replaces the per-clip tf.data map of AudioDataset.augment /
@@ -274,14 +278,26 @@ int mkws_specaug_apply(float* d_spec, const int32_t* d_masks, int B, int frames,
  * is host code (multilingual_kws_amd/embedding_trainer.py) and each numerical operator is one entry point below.
  * All tensors are device float32, NHWC viewed as row-major [M, C]; parameters keep their Keras layouts (1x1 conv
  * kernel = [K, N], depthwise [kh, kw, C], dense [in, out]).  `act`: 0 none, 1 swish, 2 relu, 3 selu, 4 sigmoid.
- * Cross-workgroup reductions use fp32 atomics (gradients are not bit-reproducible; inference is unaffected).
+ * Cross-workgroup reductions are two-level and FIXED-ORDER (partial sums in a caller-provided scratch arena, folded in index
+ * order by a second launch): no atomics, a step with the same inputs is bit-reproducible.
  * ---------------------------------------------------------------------------------------------- */
+/* Scratch arena (device memory, caller-owned) for those partial sums; per host thread, used by every mkws_op_* call of that
+ * thread until changed, in stream order (ops on ONE stream share it safely; give concurrent streams separate threads / arenas).
+ * 16 Mi floats cover every layer of the network at any batch (the largest user is the split reduction of mkws_op_gemm, which
+ * splits only as far as the arena reaches).  Ops that need it fail with MKWS_ERR_INVALID_ARG when it is missing or too small. */
+int mkws_op_set_scratch(float* d_scratch, size_t floats);
 /* C[M,N] (+)= op(A)[M,K] . op(B)[K,N] on the fp32 MFMA; op(A)(m,k) = transA ? A[k*lda+m] : A[m*lda+k], likewise B.
- * ksplit > 1 splits K over workgroups and adds into C atomically (requires accumulate = 1 and a zeroed or live C). */
+ * ksplit > 1 splits K over workgroups (slice sums go to the scratch arena, a second launch folds them in order into C);
+ * ksplit = 0 picks the split from the shapes and the arena size (small grids with a long K: ~512 workgroups). */
 int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
                  int accumulate, int ksplit, void* stream);
-/* Batch statistics of Z [M,C] per channel: mean, biased variance (two passes). */
+/* Batch statistics of Z [M,C] per channel: mean, biased variance (per-chunk mean / M2, combined with Chan's update). */
 int mkws_op_bn_stats(const float* d_Z, int M, int C, float* d_mean, float* d_var, void* stream);
+/* Training-mode BatchNormalization forward in three launches: statistics (as above) + moving-average update
+ * (moving = momentum * moving + (1 - momentum) * batch, variance Bessel-corrected) + A = act(gamma * xhat + beta).
+ * d_mean / d_var receive the batch statistics the backward pass needs. */
+int mkws_op_bn_train_fwd(const float* d_Z, int M, int C, const float* d_gamma, const float* d_beta, float eps, int act, float momentum,
+                         float* d_moving_mean, float* d_moving_var, float* d_mean, float* d_var, float* d_A, void* stream);
 /* A = act(gamma * (Z - mean) / sqrt(var + eps) + beta) */
 int mkws_op_bn_act_fwd(const float* d_Z, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, float eps, int act,
                        float* d_A, int M, int C, void* stream);
@@ -317,6 +333,11 @@ int mkws_op_axpy(float* d_y, const float* d_x, float alpha, int64_t n, void* str
 /* Keras Adam over a flat buffer (same arithmetic as mkws_head_adam_step). */
 int mkws_op_adam(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps, int step_t,
                  float grad_scale, void* stream);
+/* Graph-replayable form: the step index lives in device memory.  mkws_op_step_inc adds 1 to *d_step (once per optimizer step,
+ * before the Adam launches that share the counter); mkws_op_adam_dev computes lr_t from *d_step on the device. */
+int mkws_op_step_inc(int* d_step, void* stream);
+int mkws_op_adam_dev(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     const int* d_step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

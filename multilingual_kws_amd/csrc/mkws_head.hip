@@ -394,6 +394,27 @@ __global__ __launch_bounds__(256) void head_adam_kernel(float* __restrict__ para
   params[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
 }
 
+// The same update with the step index read from device memory (a captured hipGraph replays one launch for every step)
+__global__ __launch_bounds__(256) void head_adam_dev_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ m,
+                                                            float* __restrict__ v, int n, float lr, float beta1, float beta2, float eps,
+                                                            const int* __restrict__ step, float grad_scale) {
+  __shared__ float s_lr;
+  if (threadIdx.x == 0) {
+    const int t = *step;
+    s_lr = (float)((double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t)));
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float lr_t = s_lr;
+  const float g = grads[i] * grad_scale;
+  const float mi = m[i] + (g - m[i]) * (1.0f - beta1);
+  const float vi = v[i] + (g * g - v[i]) * (1.0f - beta2);
+  m[i] = mi;
+  v[i] = vi;
+  params[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
+}
+
 }  // namespace mkws
 
 using namespace mkws;
@@ -555,6 +576,14 @@ int mkws_head_adam_step(mkws_head* hd, float lr, float beta1, float beta2, float
   const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, step_t)) / (1.0 - std::pow((double)beta1, step_t));
   hipLaunchKernelGGL(head_adam_kernel, dim3((hd->nparams + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), hd->params, hd->grads,
                      hd->m, hd->v, hd->nparams, (float)lr_t, beta1, beta2, eps, grad_scale);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_head_adam_step_dev(mkws_head* hd, float lr, float beta1, float beta2, float eps, const int* d_step, float grad_scale, void* stream) {
+  if (!hd || !d_step) return fail(MKWS_ERR_INVALID_ARG, "head handle / step counter is NULL");
+  hipLaunchKernelGGL(head_adam_dev_kernel, dim3((hd->nparams + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), hd->params, hd->grads,
+                     hd->m, hd->v, hd->nparams, lr, beta1, beta2, eps, d_step, grad_scale);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

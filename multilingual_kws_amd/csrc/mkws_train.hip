@@ -8,8 +8,9 @@
 // below (include/mkws.h, "training operators").  All tensors are NHWC float32 viewed as row-major [M, C]; parameter
 // tensors keep their Keras layouts (conv kernels HWIO = [K, N] for 1x1, depthwise [kh, kw, C], dense [in, out]), so
 // the flat parameter / gradient buffers are the weight blob itself.
-// Reductions that cross workgroups use fp32 atomics (training is stochastic anyway: SpecAugment, drop-connect);
-// the inference path of this library stays bit-reproducible and does not use these kernels.
+// Reductions that cross workgroups are FIXED-ORDER (round 3): every workgroup writes its partial sums to a caller-provided scratch
+// arena (mkws_op_set_scratch) and a small second launch folds them in index order -- no atomics, no memsets, so a training step
+// with the same inputs, masks and parameters is bit-reproducible (round 2 used fp32 atomics).
 #include "mkws_common.h"
 
 #include <cmath>
@@ -51,9 +52,11 @@ __device__ __forceinline__ float act_grad(float y, int act) {
 // dZ . W^T: NT; weight gradient X^T . dZ: TN with the long reduction split over blockIdx.z and fp32 atomics).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
-                                                         int K, int lda, int ldb, int ldc, int accumulate, int ksplit) {
-  __shared__ float As[64][17];
-  __shared__ float Bs[16][65];
+                                                         int K, int lda, int ldb, int ldc, int accumulate, int ksplit, float* __restrict__ part) {
+  // Two LDS stages; the next K step's operands travel global -> registers while the current step's MFMAs run (round 2 loaded,
+  // synchronised and multiplied one K step at a time: a full memory latency per 16 columns of K, 44-61 us per call at batch 64).
+  __shared__ float As[2][64][17];
+  __shared__ float Bs[2][16][65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -64,39 +67,55 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  float ra[4], rb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                      // A tile: 64 x 16
       const int e = tid + 256 * i;
       const int r = TA ? (e & 63) : (e >> 4), kk = TA ? (e >> 6) : (e & 15);
       const int m = m0 + r, k = k0 + kk;
-      float v = 0.0f;
-      if (m < M && k < kend) v = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
-      As[r][kk] = v;
+      ra[i] = (m < M && k < kend) ? (TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                      // B tile: 16 x 64
       const int e = tid + 256 * i;
       const int kk = TB ? (e & 15) : (e >> 6), cn = TB ? (e >> 4) : (e & 63);
       const int n = n0 + cn, k = k0 + kk;
-      float v = 0.0f;
-      if (n < N && k < kend) v = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
-      Bs[kk][cn] = v;
+      rb[i] = (n < N && k < kend) ? (TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.0f;
     }
-    __syncthreads();
+  };
+  auto stash = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      As[st][TA ? (e & 63) : (e >> 4)][TA ? (e >> 6) : (e & 15)] = ra[i];
+      Bs[st][TB ? (e & 15) : (e >> 6)][TB ? (e >> 4) : (e & 63)] = rb[i];
+    }
+  };
+  if (kbeg < kend) {
+    fetch(kbeg);
+    stash(0);
+  }
+  __syncthreads();
+  int st = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    const bool more = k0 + 16 < kend;
+    if (more) fetch(k0 + 16);
 #pragma unroll
     for (int ks = 0; ks < 16; ks += 4) {
       float a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[wm * 32 + i * 16 + (lane & 15)][ks + (lane >> 4)];
+      for (int i = 0; i < 2; ++i) a[i] = As[st][wm * 32 + i * 16 + (lane & 15)][ks + (lane >> 4)];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[ks + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
+      for (int j = 0; j < 2; ++j) b[j] = Bs[st][ks + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (more) stash(st ^ 1);
     __syncthreads();
+    st ^= 1;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -106,18 +125,99 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 32 + i * 16 + 4 * (lane >> 4) + r, n = n0 + wn * 32 + j * 16 + (lane & 15);
         if (m < M && n < N) {
-          float* dst = C + (size_t)m * ldc + n;
-          if (ksplit > 1) atomicAdd(dst, acc[i][j][r]);
-          else *dst = accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+          if (ksplit > 1) {
+            part[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];       // raw slice sums; gemm_reduce_kernel folds them in order
+          } else {
+            float* dst = C + (size_t)m * ldc + n;
+            *dst = accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+          }
         }
       }
 }
 
+// C (+)= part[0] + part[1] + ... (fixed order)
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ C, int M, int N, int ldc, int accumulate) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float v = part[i];
+    for (int z = 1; z < ksplit; ++z) v += part[(size_t)z * total + i];
+    float* dst = C + (i / N) * (size_t)ldc + (i % N);
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+// out[i] (+)= sum over chunks of part[chunk][i]  (fixed order): second stage of every cross-workgroup reduction below
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out, float scale, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = part[i];
+  for (int z = 1; z < chunks; ++z) v += part[(size_t)z * n + i];
+  v *= scale;
+  out[i] = accumulate ? out[i] + v : v;
+}
+
 // ------------------------------------------------------------------------------------------------
-// Per-channel sums over the rows of Z [M, C]: out[c] += sum_m f(Z[m, c]); MODE 0: z;  MODE 1: (z - mean[c])^2.
-// block = 64 channel lanes x 4 row lanes; grid (ceil(C/64), row chunks).
+// Batch statistics of Z [M, C] per channel, two levels, fixed order.
+// Level 1 (grid: 64-channel slabs x row chunks, block = 64 channel lanes x 4 row lanes): every workgroup computes the mean of ITS
+// rows and the sum of squared deviations from that mean (two passes over its own rows, which sit in L2 after the first), and
+// writes (mean_k, M2_k) to part[chunk][2][C].  Level 2 folds the chunks in index order with Chan's parallel-variance update
+// (no E[z^2] - mean^2 cancellation) and, in the same launch, updates the moving statistics as Keras' fused BatchNorm does.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ Z, float* __restrict__ part, int M, int C) {
+  __shared__ float s[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per < M) ? r0 + per : M;
+  const int n = r1 > r0 ? r1 - r0 : 0;
+  float acc = 0.0f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) acc += Z[(size_t)r * C + c];
+  s[rl][cl] = acc;
+  __syncthreads();
+  const float mu = n > 0 ? ((s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl])) / (float)n : 0.0f;
+  __syncthreads();
+  acc = 0.0f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) { const float d = Z[(size_t)r * C + c] - mu; acc += d * d; }
+  s[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = mu;
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int M, int C, float* __restrict__ mean,
+                                                                float* __restrict__ var, float* __restrict__ mmean, float* __restrict__ mvar, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int per = (M + chunks - 1) / chunks;
+  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+  for (int k = 0; k < chunks; ++k) {
+    const int r0 = k * per, r1 = (r0 + per < M) ? r0 + per : M;
+    const float nk = (float)(r1 > r0 ? r1 - r0 : 0);
+    if (nk <= 0.0f) continue;
+    const float muk = part[((size_t)k * 2 + 0) * C + c], m2k = part[((size_t)k * 2 + 1) * C + c];
+    const float d = muk - mu, nn = n + nk;
+    mu += d * (nk / nn);
+    m2 += m2k + d * d * (n * nk / nn);
+    n = nn;
+  }
+  const float v = m2 / (float)M;                       // biased variance: what the normalisation uses
+  mean[c] = mu;
+  var[c] = v;
+  if (mmean) {                                         // moving averages: the variance enters Bessel-corrected (Keras' fused BN)
+    const float bessel = M > 1 ? (float)M / (float)(M - 1) : 1.0f;
+    mmean[c] = momentum * mmean[c] + (1.0f - momentum) * mu;
+    mvar[c] = momentum * mvar[c] + (1.0f - momentum) * v * bessel;
+  }
+}
+
+// Per-channel sums over the rows of X [M, C] -> part[chunk][C] (MODE 0), or the same after an in-place elementwise backward
+// of a bias + activation (MODE 1: X <- X * act'(Zb + bias), the dense / SE layers' backward)
 template <int MODE>
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ Z, const float* __restrict__ mean, float* __restrict__ out, int M, int C) {
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(float* __restrict__ X, const float* __restrict__ Zb, const float* __restrict__ bias, int act,
+                                                              float* __restrict__ part, int M, int C) {
   __shared__ float s[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -125,20 +225,17 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   const int r0 = blockIdx.y * per, r1 = (r0 + per < M) ? r0 + per : M;
   float acc = 0.0f;
   if (c < C) {
-    const float mu = MODE == 1 ? mean[c] : 0.0f;
+    const float bc = MODE == 1 ? bias[c] : 0.0f;
     for (int r = r0 + rl; r < r1; r += 4) {
-      const float z = Z[(size_t)r * C + c];
-      acc += MODE == 1 ? (z - mu) * (z - mu) : z;
+      const size_t i = (size_t)r * C + c;
+      float x = X[i];
+      if (MODE == 1) { x *= act_grad(Zb[i] + bc, act); X[i] = x; }
+      acc += x;
     }
   }
   s[rl][cl] = acc;
   __syncthreads();
-  if (rl == 0 && c < C) atomicAdd(out + c, (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]));
-}
-
-__global__ void scale_vec_kernel(float* __restrict__ v, float s, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) v[i] *= s;
+  if (rl == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
 }
 
 // A = act(gamma * (Z - mean) * rsqrt(var + eps) + beta)
@@ -155,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 // backward step 1: dY = dA * act'(y) in place, and sums[c] += dY, sums[C + c] += dY * xhat
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
-                                                                float* __restrict__ dA, float* __restrict__ sums, int M, int C) {
+                                                                float* __restrict__ dA, float* __restrict__ part /*[chunks][2][C]*/, int M, int C) {
   __shared__ float s1[4][64], s2[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -176,8 +273,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
   s1[rl][cl] = a1; s2[rl][cl] = a2;
   __syncthreads();
   if (rl == 0 && c < C) {
-    atomicAdd(sums + c, (s1[0][cl] + s1[1][cl]) + (s1[2][cl] + s1[3][cl]));
-    atomicAdd(sums + C + c, (s2[0][cl] + s2[1][cl]) + (s2[2][cl] + s2[3][cl]));
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = (s1[0][cl] + s1[1][cl]) + (s1[2][cl] + s1[3][cl]);
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s2[0][cl] + s2[1][cl]) + (s2[2][cl] + s2[3][cl]);
   }
 }
 
@@ -264,12 +361,13 @@ __global__ __launch_bounds__(256) void dw_bwd_input_kernel(const float* __restri
 
 // dW[i,j,c] += sum_{b,oh,ow} dZ[b,oh,ow,c] X[b, oh*s-pt+i, ow*s-pl+j, c];  block = 64 channel quads x 4 position lanes
 template <int KS>
-__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ dW, int B, int H,
-                                                            int Wd, int C, int s, int pt, int pl, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ part /*[chunks][KS*KS*C]*/,
+                                                            int B, int H, int Wd, int C, int s, int pt, int pl, int Ho, int Wo) {
+  __shared__ float red[4][64][4];
   const int ql = threadIdx.x & 63, pl4 = threadIdx.x >> 6;
   const int q = blockIdx.x * 64 + ql;
-  if (q * 4 >= C) return;
-  const int npos = B * Ho * Wo;
+  const bool qok = q * 4 < C;
+  const int npos = qok ? B * Ho * Wo : 0;
   const int per = (npos + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * per, p1 = (p0 + per < npos) ? p0 + per : npos;
   f32x4 acc[KS * KS];
@@ -290,10 +388,19 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       }
     }
   }
+  // the four position lanes of a channel quad fold in lane order, then one store per (tap, channel) into this chunk's slab
+  float* slab = part + (size_t)blockIdx.y * KS * KS * C;
 #pragma unroll
-  for (int t = 0; t < KS * KS; ++t)
+  for (int t = 0; t < KS * KS; ++t) {
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW + (size_t)t * C + 4 * q + r, acc[t][r]);
+    for (int r = 0; r < 4; ++r) red[pl4][ql][r] = acc[t][r];
+    __syncthreads();
+    if (pl4 == 0 && qok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(size_t)t * C + 4 * q + r] = (red[0][ql][r] + red[1][ql][r]) + (red[2][ql][r] + red[3][ql][r]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,7 +425,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   }
 }
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ spec, const float* __restrict__ dZ, float nm, float ns,
-                                                              float* __restrict__ dW /*[9][32]*/, int B) {
+                                                              float* __restrict__ part /*[gridDim.x][9][32]*/, int B) {
+  __shared__ float red[32][8][4];
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;            // 8 quads x 32 pixel lanes
   const int npix = B * 500;
   const int per = (npix + gridDim.x - 1) / gridDim.x;
@@ -335,23 +443,45 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) acc[ii * 3 + jj] += dz * stem_in(img, oh * 2 - 1 + ii, ow * 2 + jj, nm, ns);
   }
+  float* slab = part + (size_t)blockIdx.x * 288;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW + t * 32 + 4 * q + r, acc[t][r]);
+    for (int r = 0; r < 4; ++r) red[pl][q][r] = acc[t][r];
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = red[0][q][r];
+        for (int l = 1; l < 32; ++l) v += red[l][q][r];
+        slab[t * 32 + 4 * q + r] = v;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // squeeze-excite pieces and small elementwise operators
 // mean[b,c] = (1/HW) sum_hw A[b,hw,c]
 __global__ __launch_bounds__(256) void pool_hw_kernel(const float* __restrict__ A, float* __restrict__ mean, int B, int HW, int C) {
-  const int cq = C / 4;
-  const int total = B * cq;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int b = i / cq, q = i % cq;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < HW; ++p) s += *reinterpret_cast<const f32x4*>(A + ((size_t)b * HW + p) * C + 4 * q);
-    *reinterpret_cast<f32x4*>(mean + (size_t)b * C + 4 * q) = s * (1.0f / (float)HW);
+  // grid (channel-quad slabs of 64, clips); block = 64 quads x 4 position lanes (coalesced rows, 4x the parallelism of one thread
+  // per (clip, quad)); the lanes fold in fixed order
+  __shared__ float red[4][64][4];
+  const int ql = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + ql, b = blockIdx.y;
+  const bool ok = q * 4 < C;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (ok)
+    for (int p = pl; p < HW; p += 4) s += *reinterpret_cast<const f32x4*>(A + ((size_t)b * HW + p) * C + 4 * q);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[pl][ql][r] = s[r];
+  __syncthreads();
+  if (pl == 0 && ok) {
+    f32x4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = (red[0][ql][r] + red[1][ql][r]) + (red[2][ql][r] + red[3][ql][r]);
+    *reinterpret_cast<f32x4*>(mean + (size_t)b * C + 4 * q) = t * (1.0f / (float)HW);
   }
 }
 // out[b,hw,c] = A[b,hw,c] * g[b,c]
@@ -366,19 +496,28 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const float* __rest
 // dA[b,hw,c] = dOut * g[b,c];  dg[b,c] = sum_hw dOut * A
 __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ A, const float* __restrict__ g, const float* __restrict__ dOut, float* __restrict__ dA,
                                                      float* __restrict__ dg, int B, int HW, int C) {
-  const int cq = C / 4;
-  const int total = B * cq;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int b = i / cq, q = i % cq;
+  __shared__ float red[4][64][4];
+  const int ql = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + ql, b = blockIdx.y;
+  const bool ok = q * 4 < C;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (size_t)b * C + 4 * q);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < HW; ++p) {
+    for (int p = pl; p < HW; p += 4) {
       const size_t o = ((size_t)b * HW + p) * C + 4 * q;
       const f32x4 d = *reinterpret_cast<const f32x4*>(dOut + o);
       s += d * *reinterpret_cast<const f32x4*>(A + o);
       *reinterpret_cast<f32x4*>(dA + o) = d * gv;
     }
-    *reinterpret_cast<f32x4*>(dg + (size_t)b * C + 4 * q) = s;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[pl][ql][r] = s[r];
+  __syncthreads();
+  if (pl == 0 && ok) {
+    f32x4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = (red[0][ql][r] + red[1][ql][r]) + (red[2][ql][r] + red[3][ql][r]);
+    *reinterpret_cast<f32x4*>(dg + (size_t)b * C + 4 * q) = t;
   }
 }
 // X[b,hw,c] += v[b,c] * scale   (gradient of a mean over hw; also: broadcast add)
@@ -393,10 +532,6 @@ __global__ __launch_bounds__(256) void add_bcast_kernel(float* __restrict__ X, c
 // A = act(Z + bias)
 __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ bias, int act, float* __restrict__ A, size_t total, int N) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) A[i] = act_fwd(Z[i] + bias[i % N], act);
-}
-// dZ = dA * act'(Z + bias) in place
-__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ bias, int act, float* __restrict__ dA, size_t total, int N) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dA[i] *= act_grad(Z[i] + bias[i % N], act);
 }
 // out[b, :] = a[b, :] * s[b] + c[b, :]   (c may be NULL)  -- drop-connect + residual add, and its backward
 __global__ __launch_bounds__(256) void row_scale_add_kernel(const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ c, float* __restrict__ out,
@@ -422,6 +557,27 @@ __global__ __launch_bounds__(256) void train_adam_kernel(float* __restrict__ p, 
   }
 }
 
+// Adam whose step index lives in device memory: a captured hipGraph replays the same launch every step, so lr_t cannot be a kernel
+// argument.  step_inc_kernel runs once per step before the Adam launches that share the counter.
+__global__ void step_inc_kernel(int* __restrict__ step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+__global__ __launch_bounds__(256) void train_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                             float lr, float b1, float b2, float eps, const int* __restrict__ step, float grad_scale) {
+  __shared__ float s_lr;
+  if (threadIdx.x == 0) {
+    const int t = *step;
+    s_lr = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  }
+  __syncthreads();
+  const float lr_t = s_lr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    m[i] = mi; v[i] = vi;
+    p[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
+  }
+}
+
 inline int grid_for(size_t total, int cap = 8192) {
   size_t g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
@@ -433,34 +589,76 @@ using namespace mkws;
 
 #define MKWS_REQ(cond, ...) do { if (!(cond)) return fail(MKWS_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
 
+namespace {
+// Scratch arena for the partial sums of the fixed-order reductions: caller-owned device memory, set per host thread.
+thread_local float* g_scratch = nullptr;
+thread_local size_t g_scratch_floats = 0;
+inline float* scratch(size_t floats) { return (g_scratch && floats <= g_scratch_floats) ? g_scratch : nullptr; }
+inline int row_chunks(int M, int cap) { int c = (M + 255) / 256; if (c > cap) c = cap; if (c < 1) c = 1; return c; }
+}  // namespace
+
 extern "C" {
+
+int mkws_op_set_scratch(float* d_scratch, size_t floats) {
+  g_scratch = d_scratch;
+  g_scratch_floats = d_scratch ? floats : 0;
+  return MKWS_OK;
+}
 
 int mkws_op_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
                  void* stream) {
   MKWS_REQ(A && B && C, "gemm: NULL operand");
-  MKWS_REQ(M > 0 && N > 0 && K > 0 && ksplit >= 1, "gemm: bad dimensions");
-  MKWS_REQ(ksplit == 1 || accumulate, "gemm: a split reduction adds into C (zero it and pass accumulate=1)");
+  MKWS_REQ(M > 0 && N > 0 && K > 0 && ksplit >= 0, "gemm: bad dimensions");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+  if (ksplit == 0) {
+    // auto: split the reduction until the launch has ~512 workgroups (256 CUs, several resident per CU), at least 64 columns of K
+    // per slice, as far as the scratch arena reaches.  A function of the shapes and the arena size only: reproducible.
+    ksplit = 1;
+    if (tiles < 512 && K >= 128) {
+      ksplit = (512 + tiles - 1) / tiles;
+      if (ksplit > K / 64) ksplit = K / 64;
+      while (ksplit > 1 && !scratch((size_t)ksplit * M * N)) --ksplit;
+      if (ksplit < 1) ksplit = 1;
+    }
+  }
+  float* part = nullptr;
+  if (ksplit > 1) {
+    part = scratch((size_t)ksplit * M * N);
+    MKWS_REQ(part, "gemm: ksplit = %d needs %zu floats of scratch (mkws_op_set_scratch)", ksplit, (size_t)ksplit * M * N);
+  }
   const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
-  if (!transA && !transB) hipLaunchKernelGGL((train_gemm_kernel<false, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
-  else if (!transA) hipLaunchKernelGGL((train_gemm_kernel<false, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
-  else if (!transB) hipLaunchKernelGGL((train_gemm_kernel<true, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
-  else hipLaunchKernelGGL((train_gemm_kernel<true, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit);
+  if (!transA && !transB) hipLaunchKernelGGL((train_gemm_kernel<false, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
+  else if (!transA) hipLaunchKernelGGL((train_gemm_kernel<false, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
+  else if (!transB) hipLaunchKernelGGL((train_gemm_kernel<true, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
+  else hipLaunchKernelGGL((train_gemm_kernel<true, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
+  if (ksplit > 1) hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, s, part, ksplit, C, M, N, ldc, accumulate);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+static int bn_stats_impl(const float* Z, int M, int C, float* mean, float* var, float* mmean, float* mvar, float momentum, hipStream_t s) {
+  const int chunks = row_chunks(M, 64);
+  float* part = scratch((size_t)chunks * 2 * C);
+  MKWS_REQ(part, "bn_stats: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, part, M, C);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, chunks, M, C, mean, var, mmean, mvar, momentum);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
 
 int mkws_op_bn_stats(const float* Z, int M, int C, float* mean, float* var, void* stream) {
   MKWS_REQ(Z && mean && var && M > 0 && C > 0, "bn_stats: bad arguments");
+  return bn_stats_impl(Z, M, C, mean, var, nullptr, nullptr, 0.0f, static_cast<hipStream_t>(stream));
+}
+
+int mkws_op_bn_train_fwd(const float* Z, int M, int C, const float* gamma, const float* beta, float eps, int act, float momentum, float* moving_mean,
+                         float* moving_var, float* mean, float* var, float* A, void* stream) {
+  MKWS_REQ(Z && gamma && beta && moving_mean && moving_var && mean && var && A && M > 0 && C > 0, "bn_train_fwd: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int chunks = (M + 255) / 256; if (chunks > 256) chunks = 256; if (chunks < 1) chunks = 1;
-  const dim3 grid((C + 63) / 64, chunks);
-  MKWS_HIP(hipMemsetAsync(mean, 0, (size_t)C * sizeof(float), s));
-  MKWS_HIP(hipMemsetAsync(var, 0, (size_t)C * sizeof(float), s));
-  hipLaunchKernelGGL((col_sum_kernel<0>), grid, dim3(256), 0, s, Z, nullptr, mean, M, C);
-  hipLaunchKernelGGL(scale_vec_kernel, dim3((C + 255) / 256), dim3(256), 0, s, mean, 1.0f / (float)M, C);
-  hipLaunchKernelGGL((col_sum_kernel<1>), grid, dim3(256), 0, s, Z, mean, var, M, C);
-  hipLaunchKernelGGL(scale_vec_kernel, dim3((C + 255) / 256), dim3(256), 0, s, var, 1.0f / (float)M, C);
+  if (int rc = bn_stats_impl(Z, M, C, mean, var, moving_mean, moving_var, momentum, s)) return rc;
+  const size_t total = (size_t)M * C;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, A, total, C);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -478,9 +676,11 @@ int mkws_op_bn_act_bwd(const float* Z, const float* mean, const float* var, cons
                        float* dbeta, float* scratch, int M, int C, void* stream) {
   MKWS_REQ(Z && mean && var && gamma && beta && dA && dgamma && dbeta && scratch && M > 0 && C > 0, "bn_act_bwd: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int chunks = (M + 255) / 256; if (chunks > 256) chunks = 256; if (chunks < 1) chunks = 1;
-  MKWS_HIP(hipMemsetAsync(scratch, 0, 2 * (size_t)C * sizeof(float), s));
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, scratch, M, C);
+  const int chunks = row_chunks(M, 64);
+  float* part = ::scratch((size_t)chunks * 2 * C);
+  MKWS_REQ(part, "bn_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, part, M, C);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, part, chunks, 2 * C, scratch, 1.0f, 0);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)M * C)), dim3(256), 0, s, Z, mean, var, gamma, eps, dA, scratch, dgamma, dbeta, M, C);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
@@ -506,11 +706,13 @@ int mkws_op_dwconv_bwd(const float* X, const float* W, const float* dZ, float* d
   MKWS_REQ(X && W && dZ && dW && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_bwd: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dX) hipLaunchKernelGGL(dw_bwd_input_kernel, dim3(grid_for((size_t)B * H * Wd * (C / 4))), dim3(256), 0, st, dZ, W, dX, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
-  MKWS_HIP(hipMemsetAsync(dW, 0, (size_t)k * k * C * sizeof(float), st));
   int chunks = (B * Ho * Wo + 63) / 64; if (chunks > 128) chunks = 128; if (chunks < 1) chunks = 1;
+  float* part = scratch((size_t)chunks * k * k * C);
+  MKWS_REQ(part, "dwconv_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * k * k * C);
   const dim3 grid((C / 4 + 63) / 64, chunks);
-  if (k == 3) hipLaunchKernelGGL((dw_bwd_weight_kernel<3>), grid, dim3(256), 0, st, X, dZ, dW, B, H, Wd, C, s, pt, pl, Ho, Wo);
-  else hipLaunchKernelGGL((dw_bwd_weight_kernel<5>), grid, dim3(256), 0, st, X, dZ, dW, B, H, Wd, C, s, pt, pl, Ho, Wo);
+  if (k == 3) hipLaunchKernelGGL((dw_bwd_weight_kernel<3>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
+  else hipLaunchKernelGGL((dw_bwd_weight_kernel<5>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((k * k * C + 255) / 256), dim3(256), 0, st, part, chunks, k * k * C, dW, 1.0f, 0);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -525,16 +727,18 @@ int mkws_op_stem_fwd(const float* spec, const float* W, float norm_mean, float n
 int mkws_op_stem_bwd_weight(const float* spec, const float* dZ, float norm_mean, float norm_std, float* dW, int B, void* stream) {
   MKWS_REQ(spec && dZ && dW && B > 0, "stem_bwd_weight: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  MKWS_HIP(hipMemsetAsync(dW, 0, 9 * 32 * sizeof(float), s));
   int blocks = (B * 500 + 255) / 256; if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, dZ, norm_mean, norm_std, dW, B);
+  float* part = scratch((size_t)blocks * 288);
+  MKWS_REQ(part, "stem_bwd_weight: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)blocks * 288);
+  hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, dZ, norm_mean, norm_std, part, B);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(2), dim3(256), 0, s, part, blocks, 288, dW, 1.0f, 0);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
 
 int mkws_op_pool_hw(const float* A, float* mean, int B, int HW, int C, void* stream) {
   MKWS_REQ(A && mean && B > 0 && HW > 0 && C % 4 == 0, "pool_hw: bad arguments");
-  hipLaunchKernelGGL(pool_hw_kernel, dim3(grid_for((size_t)B * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), A, mean, B, HW, C);
+  hipLaunchKernelGGL(pool_hw_kernel, dim3((C / 4 + 63) / 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), A, mean, B, HW, C);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -548,7 +752,7 @@ int mkws_op_scale_channels(const float* A, const float* g, float* out, int B, in
 
 int mkws_op_se_bwd(const float* A, const float* g, const float* dOut, float* dA, float* dg, int B, int HW, int C, void* stream) {
   MKWS_REQ(A && g && dOut && dA && dg && B > 0 && HW > 0 && C % 4 == 0, "se_bwd: bad arguments");
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(grid_for((size_t)B * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), A, g, dOut, dA, dg, B, HW, C);
+  hipLaunchKernelGGL(se_bwd_kernel, dim3((C / 4 + 63) / 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), A, g, dOut, dA, dg, B, HW, C);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -571,11 +775,12 @@ int mkws_op_bias_act_fwd(const float* Z, const float* bias, int act, float* A, i
 int mkws_op_bias_act_bwd(const float* Z, const float* bias, int act, float* dA, float* dbias, int M, int N, void* stream) {
   MKWS_REQ(Z && bias && dA && dbias && M > 0 && N > 0, "bias_act_bwd: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t total = (size_t)M * N;
-  hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, Z, bias, act, dA, total, N);
-  MKWS_HIP(hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), s));
   int chunks = (M + 63) / 64; if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL((col_sum_kernel<0>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, dA, nullptr, dbias, M, N);
+  float* part = scratch((size_t)chunks * N);
+  MKWS_REQ(part, "bias_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * N);
+  // one pass: dA <- dA * act'(Z + bias) in place and this chunk's column sums; then the chunks fold in order into dbias
+  hipLaunchKernelGGL((col_sum_partial_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, dA, Z, bias, act, part, M, N);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, chunks, N, dbias, 1.0f, 0);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -590,6 +795,22 @@ int mkws_op_row_scale_add(const float* a, const float* row_scale, const float* c
 int mkws_op_axpy(float* y, const float* x, float alpha, int64_t n, void* stream) {
   MKWS_REQ(y && x && n > 0, "axpy: bad arguments");
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), y, x, alpha, (size_t)n);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_step_inc(int* d_step, void* stream) {
+  MKWS_REQ(d_step, "step_inc: NULL counter");
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_step);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_adam_dev(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, const int* d_step,
+                     float grad_scale, void* stream) {
+  MKWS_REQ(params && grads && m && v && n > 0 && d_step, "adam_dev: bad arguments");
+  hipLaunchKernelGGL(train_adam_dev_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, m, v, (size_t)n, lr, beta1, beta2, eps,
+                     d_step, grad_scale);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

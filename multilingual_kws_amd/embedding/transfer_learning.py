@@ -163,6 +163,7 @@ def transfer_learn(
             from ..embedding_trainer import DROP_CONNECT_RATE, EmbeddingTrainer
             trainer = EmbeddingTrainer(blob, device=embedding.device)
             head.reset_optimizer()
+            graphed = None          # one hipGraph replay per step (single process; the DP phase keeps the launch-by-launch path)
         history = {"loss": [], "accuracy": [], "val_loss": [], "val_accuracy": []}
         for epoch in range(num_epochs):
             acc_stats = torch.zeros(2, dtype=torch.float64, device=embedding.device)
@@ -172,6 +173,14 @@ def transfer_learn(
                 if trainer is None:
                     emb = embedding.forward(spec)
                     stats = parallel.dp_step(head, emb, labels, lr=lr)
+                elif world == 1:
+                    nb = spec.shape[0]
+                    masks = {name: audio_dataset.rng.uniform(0, 1, nb) >= DROP_CONNECT_RATE * bi / len(BLOCKS)
+                             for bi, (name, cin, cout, k, s, e) in enumerate(BLOCKS) if s == 1 and cin == cout}
+                    if graphed is None or graphed.B != nb:
+                        from ..embedding_trainer import TrainStepGraph
+                        graphed = TrainStepGraph(trainer, head, nb, lr)
+                    stats = graphed.run(spec, labels, masks)
                 else:
                     nb = spec.shape[0]
                     masks = {name: audio_dataset.rng.uniform(0, 1, nb) >= DROP_CONNECT_RATE * bi / len(BLOCKS)

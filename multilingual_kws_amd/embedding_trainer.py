@@ -13,6 +13,11 @@ PyTorch only provides device memory, streams and torch.distributed.  Parameters,
 device buffers in the weight blob's own order and Keras layouts, so the gradient all-reduce is a handful of
 contiguous RCCL calls, issued as soon as a range of the buffer is final (the dense layers -- 93 % of the bytes --
 finish first) so they overlap the rest of the backward sweep.
+
+Round 3: every cross-workgroup reduction of the operators is fixed-order (partials in a scratch arena this class owns), so a step
+is bit-reproducible; BatchNormalization's training forward is three launches instead of eight; the generic GEMM prefetches and
+splits long reductions by itself; and `TrainStepGraph` captures forward + loss + backward + Adam of one step in a hipGraph (the
+Adam step index lives on the device), so a step is one replay instead of ~1000 ctypes round trips.
 """
 import ctypes
 
@@ -54,6 +59,9 @@ class EmbeddingTrainer:
         self._views = {}
         self._pool, self._pool_pos, self._pool_B = [], 0, None
         self._stream = None
+        # partial sums of the fixed-order reductions (include/mkws.h: mkws_op_set_scratch); 16 Mi floats cover every layer
+        self._scratch = torch.empty(16 << 20, dtype=torch.float32, device=self.device)
+        self.d_step = torch.zeros(1, dtype=torch.int32, device=self.device)        # Adam step index for the graph-replayed step
 
     # ---- plumbing -----------------------------------------------------------------------------------------------------
     def _s(self):
@@ -61,6 +69,7 @@ class EmbeddingTrainer:
 
     def _bind_stream(self):
         self._stream = _lib.current_stream_ptr()
+        _lib.check(self.L.mkws_op_set_scratch(self._p(self._scratch), self._scratch.numel()))     # per host thread: cheap, idempotent
 
     @staticmethod
     def _p(t):
@@ -94,7 +103,8 @@ class EmbeddingTrainer:
             self._pool.append(buf)
         return buf
 
-    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, acc=0, ksplit=1):
+    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, acc=0, ksplit=0):
+        # ksplit = 0: the library splits a long reduction over workgroups when the grid is small (fixed-order fold through the scratch)
         _lib.check(self.L.mkws_op_gemm(self._p(A), self._p(B), self._p(C), M, N, K, lda, ldb, ldc, ta, tb, acc, ksplit, self._s()))
 
     def blob(self):
@@ -104,13 +114,11 @@ class EmbeddingTrainer:
     # ---- layers ---------------------------------------------------------------------------------------------------------
     def _bn_fwd(self, Z, M, C, prefix, act):
         mean, var = self.new(C), self.new(C)
-        _lib.check(self.L.mkws_op_bn_stats(self._p(Z), M, C, self._p(mean), self._p(var), self._s()))
         A = self.new(M, C)
-        _lib.check(self.L.mkws_op_bn_act_fwd(self._p(Z), self._p(mean), self._p(var), self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")),
-                                             BN_EPS, act, self._p(A), M, C, self._s()))
-        # Keras updates the moving averages during the training-mode forward pass
-        _lib.check(self.L.mkws_op_bn_update_moving(self._p(self.P(prefix + "/moving_mean")), self._p(self.P(prefix + "/moving_variance")), self._p(mean), self._p(var),
-                                                   BN_MOMENTUM, M, C, self._s()))
+        # batch statistics + moving-average update (Keras does it during the training-mode forward pass) + normalise / activate
+        _lib.check(self.L.mkws_op_bn_train_fwd(self._p(Z), M, C, self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")), BN_EPS, act, BN_MOMENTUM,
+                                               self._p(self.P(prefix + "/moving_mean")), self._p(self.P(prefix + "/moving_variance")), self._p(mean), self._p(var),
+                                               self._p(A), self._s()))
         return A, (Z, mean, var, M, C, prefix, act)
 
     def _bn_bwd(self, rec, dA):
@@ -127,9 +135,8 @@ class EmbeddingTrainer:
         return Z
 
     def _conv_bwd(self, X, dZ, M, K, N, wname, need_dx=True):
-        """dW += X^T dZ (long reduction split over workgroups), dX = dZ W^T."""
-        ksplit = max(1, min(64, M // 512))
-        self.gemm(X, dZ, self.G(wname), K, N, M, K, N, N, ta=1, tb=0, acc=1, ksplit=ksplit)
+        """dW += X^T dZ (the long reduction over the rows is split by the library), dX = dZ W^T."""
+        self.gemm(X, dZ, self.G(wname), K, N, M, K, N, N, ta=1, tb=0, acc=1)
         if not need_dx:
             return None
         dX = self.new(M, K)
@@ -149,9 +156,11 @@ class EmbeddingTrainer:
         return self._conv_bwd(X, dA, M, K, N, prefix + "/kernel", need_dx)
 
     # ---- forward (training mode) ------------------------------------------------------------------------------------------
-    def forward_train(self, spec, drop_masks=None):
+    def forward_train(self, spec, drop_masks=None, keep_scales=None):
         """spec CUDA [B,49,40(,1)] -> embedding CUDA [B,1024] in TRAINING mode; keeps the tape for backward().
-        drop_masks: {block name: bool [B] of KEPT samples} for the residual blocks, or None (no drop-connect)."""
+        drop_masks: {block name: bool [B] of KEPT samples} for the residual blocks, or None (no drop-connect).
+        keep_scales: the same information as device tensors {block name: float32 [B] = kept / (1 - rate)} that the caller owns and
+        refills between steps (what a graph-replayed step needs: no host-to-device traffic inside the step)."""
         torch = self.torch
         self._bind_stream()
         spec = spec.to(self.device, dtype=torch.float32)
@@ -200,7 +209,9 @@ class EmbeddingTrainer:
                 scale = self._views.get(("ones", B))
                 if scale is None:
                     scale = self._views[("ones", B)] = torch.ones(B, dtype=torch.float32, device=self.device)
-                if drop_masks is not None and name in drop_masks:
+                if keep_scales is not None and name in keep_scales:
+                    scale = keep_scales[name]
+                elif drop_masks is not None and name in drop_masks:
                     rate = DROP_CONNECT_RATE * bi / len(BLOCKS)
                     scale = torch.as_tensor(np.asarray(drop_masks[name]), device=self.device).to(torch.float32) / (1.0 - rate)
                 rec["keep_scale"] = scale.contiguous()
@@ -299,6 +310,83 @@ class EmbeddingTrainer:
         _lib.check(self.L.mkws_op_adam(self._p(self.params), self._p(self.grads), self._p(self.m), self._p(self.v), self.params.shape[0], lr, beta1, beta2, eps,
                                        self.step_t, grad_scale, self._s()))
 
+    def adam_step_dev(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """The same update with the step index read from self.d_step on the device (see TrainStepGraph)."""
+        self._bind_stream()
+        _lib.check(self.L.mkws_op_adam_dev(self._p(self.params), self._p(self.grads), self._p(self.m), self._p(self.v), self.params.shape[0], lr, beta1, beta2, eps,
+                                           self._p(self.d_step), grad_scale, self._s()))
+
     def named_grads(self):
         g = self.grads.cpu().numpy()
         return {n: g[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"]) for n, t in self.tensors.items()}
+
+
+def drop_connect_rates():
+    """{block name: drop rate} of the residual blocks (keras efficientnet: drop_connect_rate * block index / number of blocks)."""
+    return {name: DROP_CONNECT_RATE * bi / len(BLOCKS) for bi, (name, cin, cout, k, st, e) in enumerate(BLOCKS) if st == 1 and cin == cout}
+
+
+class TrainStepGraph:
+    """One optimizer step of the `backprop_into_embedding=True` phase -- training-mode forward, head loss / gradient, backward through
+    the whole embedding, Keras Adam on the head and on the embedding -- captured ONCE in a hipGraph and replayed per step.
+
+    Everything a step consumes sits in static device buffers the caller refills (spectrograms, labels, the per-block drop-connect
+    scales); the Adam step index is a device counter (mkws_op_step_inc / *_adam*_dev), so the captured launches are valid for every
+    step.  Single process only: the data-parallel phase keeps the launch-by-launch path (its gradient all-reduce is host-driven)."""
+
+    def __init__(self, trainer, head, batch, lr, use_graph=True):
+        import torch
+        self.tr, self.head, self.B, self.lr = trainer, head, int(batch), float(lr)
+        dev = trainer.device
+        self.spec = torch.zeros((self.B, 49, 40), dtype=torch.float32, device=dev)
+        self.labels = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.rates = drop_connect_rates()
+        self.scales = {n: torch.ones(self.B, dtype=torch.float32, device=dev) for n in self.rates}
+        self.graph, self.stats = None, None
+        if use_graph:
+            # warm-up on a side stream: fills the trainer's buffer pool for this batch size and every lazily created view, on state
+            # that is restored afterwards (parameters, moving statistics, Adam moments, step counters)
+            snap = [t.clone() for t in (trainer.params, trainer.m, trainer.v, trainer.d_step)]
+            hp = head.get_params()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            for t, c in zip((trainer.params, trainer.m, trainer.v, trainer.d_step), snap):
+                t.copy_(c)
+            head.set_params(hp)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.stats = self._body()
+            self.graph = g
+
+    def _body(self):
+        tr, head = self.tr, self.head
+        emb = tr.forward_train(self.spec, keep_scales=self.scales)
+        stats = head.loss_grad(emb, self.labels)
+        tr.backward(head.input_grad(self.B))
+        _lib.check(tr.L.mkws_op_step_inc(tr._p(tr.d_step), _lib.current_stream_ptr()))
+        head.adam_step_dev(self.lr, tr.d_step)
+        tr.adam_step_dev(self.lr)
+        return stats
+
+    def run(self, spec, labels, drop_masks=None):
+        """spec CUDA [B,49,40(,1)], labels CUDA [B], drop_masks {block: bool [B] kept} (host) -> stats tensor [sum of row losses,
+        #correct] of this step's batch (a view of the head's buffer: read it before the next step)."""
+        import torch
+        if spec.dim() == 4:
+            spec = spec[..., 0]
+        self.spec.copy_(spec)
+        self.labels.copy_(labels.to(torch.int32))
+        for n, rate in self.rates.items():
+            if drop_masks is not None and n in drop_masks:
+                keep = torch.as_tensor(np.asarray(drop_masks[n], dtype=np.float32) / np.float32(1.0 - rate))
+                self.scales[n].copy_(keep, non_blocking=True)
+            else:
+                self.scales[n].fill_(1.0)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.stats
+        return self._body()

@@ -133,6 +133,12 @@ class Head:
         """A fresh Adam (zero moments, t = 0) on the current parameters -- what re-compiling the Keras model does."""
         self.set_params(self.get_params())
 
+    def adam_step_dev(self, lr, d_step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """Adam with the step index read from the int32 device tensor d_step (graph-replayed steps: embedding_trainer.TrainStepGraph)."""
+        import torch
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mkws_head_adam_step_dev(self.h, lr, beta1, beta2, eps, ctypes.c_void_p(d_step.data_ptr()), grad_scale, _lib.current_stream_ptr()))
+
     def adam_step(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         import torch
         self.step_t += 1

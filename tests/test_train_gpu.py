@@ -31,11 +31,15 @@ def ops():
     o.L, o.dev, o.check, o.s = L, dev, _lib.check, _lib.current_stream_ptr
     o.p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     o.t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    # scratch arena for the partial sums of the fixed-order reductions (include/mkws.h: mkws_op_set_scratch)
+    o.scratch = torch.empty(4 << 20, dtype=torch.float32, device=dev)
+    _lib.check(L.mkws_op_set_scratch(o.p(o.scratch), o.scratch.numel()))
     return o
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb,ks", [(130, 96, 16, 0, 0, 1), (77, 24, 144, 0, 0, 1), (64, 40, 100, 0, 1, 1), (16, 96, 4000, 1, 0, 7),
-                                            (240, 10, 6, 0, 0, 1), (5, 6, 240, 0, 1, 1), (2048, 1024, 8, 1, 0, 1), (33, 65, 17, 1, 1, 1)])
+                                            (240, 10, 6, 0, 0, 1), (5, 6, 240, 0, 1, 1), (2048, 1024, 8, 1, 0, 1), (33, 65, 17, 1, 1, 1),
+                                            (64, 2048, 2048, 0, 0, 0), (16, 96, 32000, 1, 0, 0), (64, 300, 1000, 0, 1, 0), (100, 70, 33, 0, 0, 0)])
 def test_gemm_all_transposes(ops, M, N, K, ta, tb, ks):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
@@ -43,8 +47,14 @@ def test_gemm_all_transposes(ops, M, N, K, ta, tb, ks):
     ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
     dA, dB = ops.t(A), ops.t(B)
     C = torch.zeros((M, N), dtype=torch.float32, device=ops.dev)
-    ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 1 if ks > 1 else 0, ks, ops.s()))
+    ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 0, ks, ops.s()))
     assert _rel(C.cpu().numpy(), ref) < 1e-5
+    if ks != 1:      # split reductions (explicit, or ks = 0: chosen by the library) fold in a fixed order: bit-reproducible, and they accumulate too
+        C2 = torch.full((M, N), 7.0, dtype=torch.float32, device=ops.dev)
+        ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C2), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 0, ks, ops.s()))
+        assert torch.equal(C2, C)
+        ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C2), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 1, ks, ops.s()))
+        assert _rel(C2.cpu().numpy(), 2 * ref) < 1e-5
     if ks == 1:      # accumulate
         ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 1, 1, ops.s()))
         assert _rel(C.cpu().numpy(), 2 * ref) < 1e-5
@@ -76,6 +86,19 @@ def test_batchnorm_train_forward_backward(ops, M, C, act):
     ops.check(ops.L.mkws_op_bn_update_moving(ops.p(mm), ops.p(mv), ops.p(dm), ops.p(dv), 0.99, M, C, ops.s()))
     assert _rel(mm.cpu().numpy(), 0.01 * mean.detach().numpy()) < 1e-5
     assert _rel(mv.cpu().numpy(), 0.99 + 0.01 * var.detach().numpy() * M / (M - 1)) < 1e-5
+    # the fused training forward (statistics + moving update + normalise / activate in three launches) gives the same numbers, bit for bit
+    mm2, mv2 = ops.t(np.zeros(C)), ops.t(np.ones(C))
+    dm2, dv2, A2 = torch.empty(C, device=ops.dev), torch.empty(C, device=ops.dev), torch.empty((M, C), device=ops.dev)
+    ops.check(ops.L.mkws_op_bn_train_fwd(ops.p(dZ), M, C, ops.p(dg), ops.p(db), 1e-3, act, 0.99, ops.p(mm2), ops.p(mv2), ops.p(dm2), ops.p(dv2), ops.p(A2), ops.s()))
+    assert torch.equal(dm2, dm) and torch.equal(dv2, dv) and torch.equal(A2, A) and torch.equal(mm2, mm) and torch.equal(mv2, mv)
+    # fixed-order reductions: the backward pass repeats bit for bit
+    d2, gg2, gb2 = ops.t(dA), torch.empty(C, device=ops.dev), torch.empty(C, device=ops.dev)
+    ops.check(ops.L.mkws_op_bn_act_bwd(ops.p(dZ), ops.p(dm), ops.p(dv), ops.p(dg), ops.p(db), 1e-3, act, ops.p(d2), ops.p(gg2), ops.p(gb2), ops.p(scr), M, C, ops.s()))
+    assert torch.equal(d2, d) and torch.equal(gg2, gg) and torch.equal(gb2, gb)
+    # without a scratch arena the op fails loudly instead of falling back to atomics
+    ops.check(ops.L.mkws_op_set_scratch(None, 0))
+    assert ops.L.mkws_op_bn_stats(ops.p(dZ), M, C, ops.p(dm), ops.p(dv), ops.s()) < 0 and b"scratch" in ops.L.mkws_last_error()
+    ops.check(ops.L.mkws_op_set_scratch(ops.p(ops.scratch), ops.scratch.numel()))
 
 
 @pytest.mark.parametrize("H,W,C,k,s", [(25, 20, 96, 3, 2), (13, 10, 144, 5, 2), (7, 5, 240, 5, 1), (4, 3, 480, 3, 1), (4, 3, 672, 5, 2), (2, 2, 1152, 5, 1)])
@@ -165,6 +188,13 @@ def test_stem_se_and_elementwise_operators(ops):
         ops.check(ops.L.mkws_op_adam(ops.p(P), ops.p(Gd), ops.p(m), ops.p(v), n, 1e-3, 0.9, 0.999, 1e-7, t, 0.5, ops.s()))
         pr = opt.step(pr, 0.5 * gr.astype(np.float64))
     assert np.abs(P.cpu().numpy() - pr).max() < 1e-6
+    # the graph-replayable form (step index on the device) walks the same trajectory
+    P2, m2, v2 = ops.t(p0), ops.t(np.zeros(n)), ops.t(np.zeros(n))
+    step = torch.zeros(1, dtype=torch.int32, device=ops.dev)
+    for t in range(1, 4):
+        ops.check(ops.L.mkws_op_step_inc(ops.p(step), ops.s()))
+        ops.check(ops.L.mkws_op_adam_dev(ops.p(P2), ops.p(Gd), ops.p(m2), ops.p(v2), n, 1e-3, 0.9, 0.999, 1e-7, ops.p(step), 0.5, ops.s()))
+    assert int(step.item()) == 3 and np.abs(P2.cpu().numpy() - P.cpu().numpy()).max() < 1e-7
 
 
 def test_training_mode_gradients_match_the_oracle():
@@ -306,7 +336,48 @@ def test_bucketed_gradient_allreduce_over_rccl():
         assert len(spans) == 3
         spans.sort()
         assert spans[0][0] == 0 and spans[-1][1] == tr2.grads.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-        # atomics make gradients order-dependent in the last bits: equal within fp32 round-off, not bit for bit
-        assert float((tr2.grads - plain).abs().max() / plain.abs().max()) < 1e-4
+        # every reduction has a fixed order (round 3): a second trainer on the same inputs gives the same gradient bit for bit
+        assert torch.equal(tr2.grads, plain)
     finally:
         dist.destroy_process_group()
+
+
+def test_graph_replayed_training_step_equals_the_eager_step():
+    """TrainStepGraph: forward + head loss + backward + both Adam updates of one `backprop_into_embedding` step as ONE hipGraph
+    replay.  Three steps with fresh inputs and drop-connect masks must leave exactly the parameters, moving statistics and head
+    the launch-by-launch path leaves (all reductions are fixed-order, the Adam step index is a device counter)."""
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding_trainer import EmbeddingTrainer, TrainStepGraph, drop_connect_rates
+    from multilingual_kws_amd.head import Head
+    blob = weights.synthetic_blob()
+    rng = np.random.default_rng(11)
+    B, lr = 8, 1e-4
+    specs = [torch.from_numpy(rng.integers(0, 670, size=(B, 49, 40)).astype(np.float32) * np.float32(10 / 256)).cuda() for _ in range(3)]
+    labels = [torch.from_numpy(rng.integers(0, 3, B).astype(np.int32)).cuda() for _ in range(3)]
+    masks = [{n: rng.uniform(0, 1, B) >= r for n, r in drop_connect_rates().items()} for _ in range(3)]
+    tr_e, hd_e = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    stats_e = []
+    for x, y, mk in zip(specs, labels, masks):
+        emb = tr_e.forward_train(x, mk)
+        stats_e.append(hd_e.loss_grad(emb, y).clone())
+        tr_e.backward(hd_e.input_grad(B))
+        hd_e.adam_step(lr=lr)
+        tr_e.adam_step(lr=lr)
+    tr_g, hd_g = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    step = TrainStepGraph(tr_g, hd_g, B, lr)
+    assert step.graph is not None
+    assert np.array_equal(tr_g.blob(), blob) and int(tr_g.d_step.item()) == 0           # the capture warm-up left no trace
+    for i, (x, y, mk) in enumerate(zip(specs, labels, masks)):
+        st = step.run(x, y, mk).clone()
+        assert torch.allclose(st, stats_e[i], rtol=1e-6, atol=1e-6), i
+    torch.cuda.synchronize()
+    assert int(tr_g.d_step.item()) == 3
+    pe, pg = tr_e.blob(), tr_g.blob()
+    assert np.abs(pe - pg).max() <= 1e-7 * max(1.0, np.abs(pe).max())                   # (host pow vs device pow in lr_t: last-bit only)
+    assert np.abs(hd_e.get_params() - hd_g.get_params()).max() < 1e-7
+    # and the graph path repeats itself bit for bit
+    tr_h, hd_h = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    step2 = TrainStepGraph(tr_h, hd_h, B, lr)
+    for x, y, mk in zip(specs, labels, masks):
+        step2.run(x, y, mk)
+    assert np.array_equal(tr_h.blob(), pg) and np.array_equal(hd_h.get_params(), hd_g.get_params())
