@@ -293,7 +293,7 @@ int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, i
                  int accumulate, int ksplit, void* stream);
 /* Batch statistics of Z [M,C] per channel: mean, biased variance (per-chunk mean / M2, combined with Chan's update). */
 int mkws_op_bn_stats(const float* d_Z, int M, int C, float* d_mean, float* d_var, void* stream);
-/* Training-mode BatchNormalization forward in three launches: statistics (as above) + moving-average update
+/* Training-mode BatchNormalization forward in two launches: chunk statistics, then (fold of the chunks +) moving-average update
  * (moving = momentum * moving + (1 - momentum) * batch, variance Bessel-corrected) + A = act(gamma * xhat + beta).
  * d_mean / d_var receive the batch statistics the backward pass needs. */
 int mkws_op_bn_train_fwd(const float* d_Z, int M, int C, const float* d_gamma, const float* d_beta, float eps, int act, float momentum,

@@ -15,7 +15,7 @@ contiguous RCCL calls, issued as soon as a range of the buffer is final (the den
 finish first) so they overlap the rest of the backward sweep.
 
 Round 3: every cross-workgroup reduction of the operators is fixed-order (partials in a scratch arena this class owns), so a step
-is bit-reproducible; BatchNormalization's training forward is three launches instead of eight; the generic GEMM prefetches and
+is bit-reproducible; BatchNormalization's training forward is two launches instead of eight; the generic GEMM prefetches and
 splits long reductions by itself; and `TrainStepGraph` captures forward + loss + backward + Adam of one step in a hipGraph (the
 Adam step index lives on the device), so a step is one replay instead of ~1000 ctypes round trips.
 """
