@@ -291,6 +291,9 @@ int mkws_op_set_scratch(float* d_scratch, size_t floats);
  * ksplit = 0 picks the split from the shapes and the arena size (small grids with a long K: ~512 workgroups). */
 int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
                  int accumulate, int ksplit, void* stream);
+/* Dense / SE layer forward in one call: Z = X[M,K] . W[K,N] (kept: the backward pass differentiates the activation at Z + bias) and
+ * A = act(Z + bias), the epilogue fused into the GEMM (or into its split-reduction fold). */
+int mkws_op_dense_fwd(const float* d_X, const float* d_W, const float* d_bias, int act, float* d_Z, float* d_A, int M, int N, int K, void* stream);
 /* Batch statistics of Z [M,C] per channel: mean, biased variance (per-chunk mean / M2, combined with Chan's update). */
 int mkws_op_bn_stats(const float* d_Z, int M, int C, float* d_mean, float* d_var, void* stream);
 /* Training-mode BatchNormalization forward in two launches: chunk statistics, then (fold of the chunks +) moving-average update

@@ -52,7 +52,8 @@ __device__ __forceinline__ float act_grad(float y, int act) {
 // dZ . W^T: NT; weight gradient X^T . dZ: TN with the long reduction split over blockIdx.z and fp32 atomics).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
-                                                         int K, int lda, int ldb, int ldc, int accumulate, int ksplit, float* __restrict__ part) {
+                                                         int K, int lda, int ldb, int ldc, int accumulate, int ksplit, float* __restrict__ part,
+                                                         const float* __restrict__ bias, int act, float* __restrict__ Act) {
   // Two LDS stages; the next K step's operands travel global -> registers while the current step's MFMAs run (round 2 loaded,
   // synchronised and multiplied one K step at a time: a full memory latency per 16 columns of K, 44-61 us per call at batch 64).
   __shared__ float As[2][64][17];
@@ -129,20 +130,25 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
             part[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];       // raw slice sums; gemm_reduce_kernel folds them in order
           } else {
             float* dst = C + (size_t)m * ldc + n;
-            *dst = accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+            const float v = accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+            *dst = v;
+            if (Act) Act[(size_t)m * ldc + n] = act_fwd(v + bias[n], act);      // fused dense / SE epilogue: C keeps the pre-activation for the backward pass
           }
         }
       }
 }
 
 // C (+)= part[0] + part[1] + ... (fixed order)
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ C, int M, int N, int ldc, int accumulate) {
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ C, int M, int N, int ldc, int accumulate,
+                                                          const float* __restrict__ bias, int act, float* __restrict__ Act) {
   const size_t total = (size_t)M * N;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float v = part[i];
     for (int z = 1; z < ksplit; ++z) v += part[(size_t)z * total + i];
-    float* dst = C + (i / N) * (size_t)ldc + (i % N);
-    *dst = accumulate ? *dst + v : v;
+    const size_t o = (i / N) * (size_t)ldc + (i % N);
+    if (accumulate) v += C[o];
+    C[o] = v;
+    if (Act) Act[o] = act_fwd(v + bias[i % N], act);
   }
 }
 
@@ -196,11 +202,12 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// Chan's parallel-variance fold of the chunk statistics of one channel, in chunk order -> (mean, biased variance)
-__device__ __forceinline__ void bn_fold_chunks(const float* __restrict__ part, int chunks, int M, int C, int c, float* mean_out, float* var_out) {
+// Chan's parallel-variance fold of the chunk statistics [k0, k1) of one channel, in chunk order -> (count, mean, M2)
+__device__ __forceinline__ void bn_fold_range(const float* __restrict__ part, int chunks, int M, int C, int c, int k0, int k1, float* n_out, float* mean_out,
+                                              float* m2_out) {
   const int per = (M + chunks - 1) / chunks;
   float n = 0.0f, mu = 0.0f, m2 = 0.0f;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = k0; k < k1; ++k) {
     const int r0 = k * per, r1 = (r0 + per < M) ? r0 + per : M;
     const float nk = (float)(r1 > r0 ? r1 - r0 : 0);
     if (nk <= 0.0f) continue;
@@ -210,16 +217,42 @@ __device__ __forceinline__ void bn_fold_chunks(const float* __restrict__ part, i
     m2 += m2k + d * d * (n * nk / nn);
     n = nn;
   }
-  *mean_out = mu;
-  *var_out = m2 / (float)M;
+  *n_out = n; *mean_out = mu; *m2_out = m2;
+}
+// The statistics of the 64 channels of slab `slab`, by all 256 threads of a workgroup: thread group q = tid / 64 folds the q-th
+// quarter of the chunks, then lane group 0 combines the four results in order.  The grouping is a function of `chunks` only, so
+// every workgroup (and bn_stats_finalize_kernel) produces the same bits.  Results in s_mean / s_var [64]; needs a barrier after.
+__device__ __forceinline__ void bn_fold_slab(const float* __restrict__ part, int chunks, int M, int C, int slab, float (*s_q)[64][3], float* s_mean, float* s_var) {
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = slab * 64 + cl;
+  const int per4 = (chunks + 3) / 4;
+  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+  if (c < C) bn_fold_range(part, chunks, M, C, c, q * per4, (q + 1) * per4 < chunks ? (q + 1) * per4 : chunks, &n, &mu, &m2);
+  s_q[q][cl][0] = n; s_q[q][cl][1] = mu; s_q[q][cl][2] = m2;
+  __syncthreads();
+  if (q == 0) {
+    n = s_q[0][cl][0]; mu = s_q[0][cl][1]; m2 = s_q[0][cl][2];
+    for (int j = 1; j < 4; ++j) {
+      const float nk = s_q[j][cl][0];
+      if (nk <= 0.0f) continue;
+      const float d = s_q[j][cl][1] - mu, nn = n + nk;
+      mu += d * (nk / nn);
+      m2 += s_q[j][cl][2] + d * d * (n * nk / nn);
+      n = nn;
+    }
+    s_mean[cl] = mu;
+    s_var[cl] = m2 / (float)M;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, int M, int C, float* __restrict__ mean,
                                                                 float* __restrict__ var, float* __restrict__ mmean, float* __restrict__ mvar, float momentum) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float mu, v;
-  bn_fold_chunks(part, chunks, M, C, c, &mu, &v);
+  __shared__ float s_q[4][64][3], s_mean[64], s_var[64];
+  bn_fold_slab(part, chunks, M, C, blockIdx.x, s_q, s_mean, s_var);
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= 64 || c >= C) return;
+  const float mu = s_mean[threadIdx.x], v = s_var[threadIdx.x];
   mean[c] = mu;
   var[c] = v;                                          // biased variance: what the normalisation uses
   if (mmean) {                                         // moving averages: the variance enters Bessel-corrected (Keras' fused BN)
@@ -236,18 +269,15 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
                                                            const float* __restrict__ beta, float eps, int act, float momentum, float* __restrict__ mmean,
                                                            float* __restrict__ mvar, float* __restrict__ mean, float* __restrict__ var, float* __restrict__ A, int M,
                                                            int C) {
-  __shared__ float s_sc[64], s_sh[64];
+  __shared__ float s_q[4][64][3], s_sh[64], s_var[64], s_sc[64];
   const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  bn_fold_slab(part, chunks, M, C, blockIdx.x, s_q, s_sh, s_var);          // s_sh = mean
+  __syncthreads();
   if (threadIdx.x < 64) {
     const int c = blockIdx.x * 64 + threadIdx.x;
-    float sc = 0.0f, sh = 0.0f;
     if (c < C) {
-      float mu, v;
-      bn_fold_chunks(part, chunks, M, C, c, &mu, &v);
-      const float inv = rsqrtf(v + eps);
-      sc = gamma[c] * inv;
-      sh = beta[c];
-      s_sc[threadIdx.x] = inv;                        // xhat = (z - mu) * inv is formed exactly as bn_act_fwd_kernel does
+      const float mu = s_sh[threadIdx.x], v = s_var[threadIdx.x];
+      s_sc[threadIdx.x] = rsqrtf(v + eps);             // xhat = (z - mu) * inv is formed exactly as bn_act_fwd_kernel does
       if (blockIdx.y == 0) {
         mean[c] = mu;
         var[c] = v;
@@ -255,9 +285,7 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
         mmean[c] = momentum * mmean[c] + (1.0f - momentum) * mu;
         mvar[c] = momentum * mvar[c] + (1.0f - momentum) * v * bessel;
       }
-      s_sh[threadIdx.x] = mu;
     }
-    (void)sc; (void)sh;
   }
   __syncthreads();
   const int c0 = blockIdx.x * 64 + 4 * ql;
@@ -364,15 +392,22 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
                                                            const float* __restrict__ gamma, float eps, float* __restrict__ dY, const float* __restrict__ part,
                                                            int chunks, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
-  __shared__ float s_a[64], s_b[64];
+  __shared__ float s_a[64], s_b[64], s_q[4][64][2];
   const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  if (threadIdx.x < 64) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < C) {
-      float t1 = part[c], t2 = part[(size_t)C + c];
-      for (int k = 1; k < chunks; ++k) { t1 += part[((size_t)k * 2 + 0) * C + c]; t2 += part[((size_t)k * 2 + 1) * C + c]; }
-      s_a[threadIdx.x] = t1;
-      s_b[threadIdx.x] = t2;
+  {
+    // thread group q folds the q-th quarter of the chunks, group 0 adds the four results in order (a function of `chunks` only)
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int per4 = (chunks + 3) / 4, k0 = q * per4, k1 = (k0 + per4 < chunks) ? k0 + per4 : chunks;
+    float t1 = 0.0f, t2 = 0.0f;
+    if (c < C)
+      for (int k = k0; k < k1; ++k) { t1 += part[((size_t)k * 2 + 0) * C + c]; t2 += part[((size_t)k * 2 + 1) * C + c]; }
+    s_q[q][cl][0] = t1; s_q[q][cl][1] = t2;
+    __syncthreads();
+    if (q == 0 && c < C) {
+      t1 = (s_q[0][cl][0] + s_q[1][cl][0]) + (s_q[2][cl][0] + s_q[3][cl][0]);
+      t2 = (s_q[0][cl][1] + s_q[1][cl][1]) + (s_q[2][cl][1] + s_q[3][cl][1]);
+      s_a[cl] = t1;
+      s_b[cl] = t2;
       if (blockIdx.y == 0) { dbeta[c] = t1; dgamma[c] = t2; }
     }
   }
@@ -464,21 +499,23 @@ __global__ __launch_bounds__(256) void dw_bwd_input_kernel(const float* __restri
   }
 }
 
-// dW[i,j,c] += sum_{b,oh,ow} dZ[b,oh,ow,c] X[b, oh*s-pt+i, ow*s-pl+j, c];  block = 64 channel quads x 4 position lanes
+// dW[i,j,c] = sum_{b,oh,ow} dZ[b,oh,ow,c] X[b, oh*s-pt+i, ow*s-pl+j, c]: block = 16 channel quads x 16 position lanes (round 2 used
+// 64 x 4: with 24..60 quads per layer most lanes idled), grid (quad slabs of 16, position chunks); the position lanes fold in lane
+// order and every workgroup stores its chunk's slab of partial sums (folded in chunk order by fold_partials_kernel).
 template <int KS>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ part /*[chunks][KS*KS*C]*/,
                                                             int B, int H, int Wd, int C, int s, int pt, int pl, int Ho, int Wo) {
-  __shared__ float red[4][64][4];
-  const int ql = threadIdx.x & 63, pl4 = threadIdx.x >> 6;
-  const int q = blockIdx.x * 64 + ql;
+  __shared__ float red[16][16][4];
+  const int ql = threadIdx.x & 15, pl16 = threadIdx.x >> 4;
+  const int q = blockIdx.x * 16 + ql;
   const bool qok = q * 4 < C;
   const int npos = qok ? B * Ho * Wo : 0;
-  const int per = (npos + gridDim.y - 1) / gridDim.y;
+  const int per = (B * Ho * Wo + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * per, p1 = (p0 + per < npos) ? p0 + per : npos;
   f32x4 acc[KS * KS];
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int p = p0 + pl4; p < p1; p += 4) {
+  for (int p = p0 + pl16; p < p1; p += 16) {
     const int ow = p % Wo, oh = (p / Wo) % Ho, b = p / (Wo * Ho);
     const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + (size_t)p * C + 4 * q);
 #pragma unroll
@@ -493,17 +530,17 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       }
     }
   }
-  // the four position lanes of a channel quad fold in lane order, then one store per (tap, channel) into this chunk's slab
   float* slab = part + (size_t)blockIdx.y * KS * KS * C;
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t) {
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[pl4][ql][r] = acc[t][r];
+    for (int r = 0; r < 4; ++r) red[pl16][ql][r] = acc[t][r];
     __syncthreads();
-    if (pl4 == 0 && qok) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) slab[(size_t)t * C + 4 * q + r] = (red[0][ql][r] + red[1][ql][r]) + (red[2][ql][r] + red[3][ql][r]);
+    if (pl16 < 4 && qok) {                              // lane r of the first four position lanes finishes component r
+      float v = red[0][ql][pl16];
+      for (int l = 1; l < 16; ++l) v += red[l][ql][pl16];
+      slab[(size_t)t * C + 4 * q + pl16] = v;
     }
   }
 }
@@ -710,18 +747,17 @@ int mkws_op_set_scratch(float* d_scratch, size_t floats) {
   return MKWS_OK;
 }
 
-int mkws_op_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
-                 void* stream) {
+static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
+                     const float* bias, int act, float* Act, hipStream_t s) {
   MKWS_REQ(A && B && C, "gemm: NULL operand");
   MKWS_REQ(M > 0 && N > 0 && K > 0 && ksplit >= 0, "gemm: bad dimensions");
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
   if (ksplit == 0) {
-    // auto: split the reduction until the launch has ~512 workgroups (256 CUs, several resident per CU), at least 64 columns of K
-    // per slice, as far as the scratch arena reaches.  A function of the shapes and the arena size only: reproducible.
+    // auto: split a long reduction of a small grid until the launch has ~256 workgroups, at least 64 columns of K per slice, as far
+    // as the scratch arena reaches.  A function of the shapes and the arena size only: reproducible.
     ksplit = 1;
     if (tiles < 256 && K >= 512) {
-      ksplit = (512 + tiles - 1) / tiles;
+      ksplit = (256 + tiles - 1) / tiles;
       if (ksplit > K / 64) ksplit = K / 64;
       while (ksplit > 1 && !scratch((size_t)ksplit * M * N)) --ksplit;
       if (ksplit < 1) ksplit = 1;
@@ -733,13 +769,26 @@ int mkws_op_gemm(const float* A, const float* B, float* C, int M, int N, int K, 
     MKWS_REQ(part, "gemm: ksplit = %d needs %zu floats of scratch (mkws_op_set_scratch)", ksplit, (size_t)ksplit * M * N);
   }
   const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
-  if (!transA && !transB) hipLaunchKernelGGL((train_gemm_kernel<false, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
-  else if (!transA) hipLaunchKernelGGL((train_gemm_kernel<false, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
-  else if (!transB) hipLaunchKernelGGL((train_gemm_kernel<true, false>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
-  else hipLaunchKernelGGL((train_gemm_kernel<true, true>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part);
-  if (ksplit > 1) hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, s, part, ksplit, C, M, N, ldc, accumulate);
+#define MKWS_TG(TA_, TB_) hipLaunchKernelGGL((train_gemm_kernel<TA_, TB_>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part, bias, act, \
+                                             ksplit > 1 ? nullptr : Act)
+  if (!transA && !transB) MKWS_TG(false, false);
+  else if (!transA) MKWS_TG(false, true);
+  else if (!transB) MKWS_TG(true, false);
+  else MKWS_TG(true, true);
+#undef MKWS_TG
+  if (ksplit > 1) hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, s, part, ksplit, C, M, N, ldc, accumulate, bias, act, Act);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
+}
+
+int mkws_op_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
+                 void* stream) {
+  return gemm_impl(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, accumulate, ksplit, nullptr, 0, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int mkws_op_dense_fwd(const float* X, const float* W, const float* bias, int act, float* Z, float* A, int M, int N, int K, void* stream) {
+  MKWS_REQ(X && W && bias && Z && A, "dense_fwd: NULL operand");
+  return gemm_impl(X, W, Z, M, N, K, K, N, N, 0, 0, 0, 0, bias, act, A, static_cast<hipStream_t>(stream));
 }
 
 static int bn_stats_impl(const float* Z, int M, int C, float* mean, float* var, float* mmean, float* mvar, float momentum, hipStream_t s) {
@@ -748,7 +797,7 @@ static int bn_stats_impl(const float* Z, int M, int C, float* mean, float* var, 
   float* part = scratch((size_t)chunks * 2 * C);
   MKWS_REQ(part, "bn_stats: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, part, M, C);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, chunks, M, C, mean, var, mmean, mvar, momentum);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, chunks, M, C, mean, var, mmean, mvar, momentum);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -817,10 +866,10 @@ int mkws_op_dwconv_bwd(const float* X, const float* W, const float* dZ, float* d
   MKWS_REQ(X && W && dZ && dW && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_bwd: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dX) hipLaunchKernelGGL(dw_bwd_input_kernel, dim3(grid_for((size_t)B * H * Wd * (C / 4))), dim3(256), 0, st, dZ, W, dX, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
-  int chunks = (B * Ho * Wo + 63) / 64; if (chunks > 128) chunks = 128; if (chunks < 1) chunks = 1;
+  int chunks = (B * Ho * Wo + 127) / 128; if (chunks > 128) chunks = 128; if (chunks < 1) chunks = 1;
   float* part = scratch((size_t)chunks * k * k * C);
   MKWS_REQ(part, "dwconv_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * k * k * C);
-  const dim3 grid((C / 4 + 63) / 64, chunks);
+  const dim3 grid((C / 4 + 15) / 16, chunks);
   if (k == 3) hipLaunchKernelGGL((dw_bwd_weight_kernel<3>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   else hipLaunchKernelGGL((dw_bwd_weight_kernel<5>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   hipLaunchKernelGGL(fold_partials_kernel, dim3((k * k * C + 255) / 256), dim3(256), 0, st, part, chunks, k * k * C, dW, 1.0f, 0);

@@ -144,10 +144,8 @@ class EmbeddingTrainer:
         return dX
 
     def _fc_fwd(self, X, M, K, N, prefix, act):
-        Z = self.new(M, N)
-        self.gemm(X, self.P(prefix + "/kernel"), Z, M, N, K, K, N, N)
-        A = self.new(M, N)
-        _lib.check(self.L.mkws_op_bias_act_fwd(self._p(Z), self._p(self.P(prefix + "/bias")), act, self._p(A), M, N, self._s()))
+        Z, A = self.new(M, N), self.new(M, N)
+        _lib.check(self.L.mkws_op_dense_fwd(self._p(X), self._p(self.P(prefix + "/kernel")), self._p(self.P(prefix + "/bias")), act, self._p(Z), self._p(A), M, N, K, self._s()))
         return A, (X, Z, M, K, N, prefix, act)
 
     def _fc_bwd(self, rec, dA, need_dx=True):

@@ -172,6 +172,16 @@ def test_stem_se_and_elementwise_operators(ops):
         assert _rel(Ab.cpu().numpy(), a.detach().numpy()) < 1e-6, act
         ops.check(ops.L.mkws_op_bias_act_bwd(ops.p(dZb), ops.p(dbias), act, ops.p(d), ops.p(gb), M, N, ops.s()))
         assert _rel(d.cpu().numpy(), zz.grad.numpy()) < 1e-5 and _rel(gb.cpu().numpy(), bb.grad.numpy()) < 1e-5, act
+    # dense / SE forward with the bias + activation epilogue fused into the GEMM: unsplit (K = 48) and split-reduction (K = 2048) forms
+    for Md, Nd, Kd, act in ((37, 50, 48, 1), (64, 72, 2048, 2), (5, 20, 1152, 4)):
+        Xd, Wd = rng.standard_normal((Md, Kd)).astype(np.float32), (rng.standard_normal((Kd, Nd)) / np.sqrt(Kd)).astype(np.float32)
+        bd = rng.standard_normal(Nd).astype(np.float32)
+        zref = Xd.astype(np.float64) @ Wd.astype(np.float64)
+        aref = fns[act](torch.tensor(zref + bd)).numpy()
+        dX_, dW_, db_ = ops.t(Xd), ops.t(Wd), ops.t(bd)
+        Zd, Ad = torch.empty((Md, Nd), device=ops.dev), torch.empty((Md, Nd), device=ops.dev)
+        ops.check(ops.L.mkws_op_dense_fwd(ops.p(dX_), ops.p(dW_), ops.p(db_), act, ops.p(Zd), ops.p(Ad), Md, Nd, Kd, ops.s()))
+        assert _rel(Zd.cpu().numpy(), zref) < 1e-5 and _rel(Ad.cpu().numpy(), aref) < 1e-5, (Md, Nd, Kd)
     # drop-connect + residual, axpy, Adam
     a, c, sc = ops.t(A), ops.t(dO), ops.t(np.array([0.0, 1.25, 1.25, 0.0]))
     out = torch.empty((B, HW, C), device=ops.dev)
