@@ -10,8 +10,13 @@ here from SURVEY.md Appendix B with F.conv2d and explicit zero padding.
 
 TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg).
 PARITY UNPINNED BY THE REFERENCE: it ships neither tests nor the trained checkpoint, and
-TensorFlow/Keras cannot be installed here, so this restatement is checked against hand-computed
-small cases and Keras' documented parameter counts only (tests/test_oracle_embedding.py).
+TensorFlow/Keras cannot be installed here.  What this restatement is checked against instead: an independent
+float64 explicit-loop re-derivation of every block and Keras' documented parameter / MAC counts
+(tests/test_oracle_embedding.py), and -- the one check not written by this project -- a THIRD-PARTY
+PyTorch port of keras/applications/efficientnet.py (Hugging Face transformers' EfficientNetModel) on the
+same weights: every block of the unmodified port where its padding equals Keras', and the whole trunk
+(tests/golden/make_hf_efficientnet_golden.py -> tests/test_hf_efficientnet_golden.py).  Real TF output
+(tests/golden/keras_golden.npz, tools/make_keras_golden.py) is still absent.
 """
 import math
 
