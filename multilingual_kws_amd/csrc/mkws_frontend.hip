@@ -218,7 +218,10 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
   s16x2 m2 = mk2(0, 0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const s16x2 neg = mk2(0, 0) - W[j];                // int16 negate: -(-32768) stays negative, as upstream
+    // int16 negate: -(-32768) stays -32768, as upstream's (int16_t)(-x).  Done on the unsigned lanes: wrap-around is defined there
+    // (a signed vector subtract that overflows is not), same v_pk_sub instruction
+    using u16x2 = __attribute__((ext_vector_type(2))) unsigned short;
+    const s16x2 neg = __builtin_bit_cast(s16x2, (u16x2)(0) - __builtin_bit_cast(u16x2, W[j]));
     m2 = __builtin_elementwise_max(m2, __builtin_elementwise_max(W[j], neg));
   }
   const int mx = wave_max_nonneg(max((int)m2.x, (int)m2.y));
