@@ -336,6 +336,10 @@ int mkws_op_axpy(float* d_y, const float* d_x, float alpha, int64_t n, void* str
 /* Keras Adam over a flat buffer (same arithmetic as mkws_head_adam_step). */
 int mkws_op_adam(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, float lr, float beta1, float beta2, float eps, int step_t,
                  float grad_scale, void* stream);
+/* Sparse categorical cross-entropy from logits over N classes (the classifier the reference trains the embedding with,
+ * train_multilingual_embedding.py:84-93): d_logits [B,N] is overwritten with d(mean loss)/d(logits); d_rowstat [B,2] receives
+ * {-log softmax(z)[y], argmax(z) == y} per row and d_stats [2] their sums (rows folded in index order). */
+int mkws_op_softmax_ce(float* d_logits, const int32_t* d_labels, int B, int N, float* d_rowstat, float* d_stats, void* stream);
 /* Graph-replayable form: the step index lives in device memory.  mkws_op_step_inc adds 1 to *d_step (once per optimizer step,
  * before the Adam launches that share the counter); mkws_op_adam_dev computes lr_t from *d_step on the device. */
 int mkws_op_step_inc(int* d_step, void* stream);

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("mkws_op_set_scratch", _I, [_P, _SZ]),
     ("mkws_op_bn_train_fwd", _I, [_P, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P]),
     ("mkws_op_step_inc", _I, [_P, _P]),
+    ("mkws_op_softmax_ce", _I, [_P, _P, _I, _I, _P, _P, _P]),
     ("mkws_op_dense_fwd", _I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     ("mkws_op_adam_dev", _I, [_P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _P, _F, _P]),
     ("mkws_op_gemm", _I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -699,6 +699,55 @@ __global__ __launch_bounds__(256) void train_adam_kernel(float* __restrict__ p, 
   }
 }
 
+// Sparse categorical cross-entropy FROM LOGITS over N classes (the 761-way classifier the reference trains the embedding with,
+// train_multilingual_embedding.py:84-93): one workgroup per row.  rowstat[b] = {-log softmax(z)[y], argmax == y}, and in place
+// z <- (softmax(z) - onehot(y)) * inv_batch (the gradient of the MEAN loss).  Row reductions fold in a fixed tree.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(float* __restrict__ Z, const int* __restrict__ labels, float* __restrict__ rowstat, int N, float inv_batch) {
+  __shared__ float s_v[256];
+  __shared__ int s_i[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* z = Z + (size_t)b * N;
+  float mx = -3.0e38f;
+  int arg = 0;
+  for (int i = tid; i < N; i += 256) { const float v = z[i]; if (v > mx) { mx = v; arg = i; } }      // first maximum of this thread's (ascending) indices
+  s_v[tid] = mx; s_i[tid] = arg;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (tid < st) {
+      const float o = s_v[tid + st]; const int oi = s_i[tid + st];
+      if (o > s_v[tid] || (o == s_v[tid] && oi < s_i[tid])) { s_v[tid] = o; s_i[tid] = oi; }           // ties -> lowest index, like argmax
+    }
+    __syncthreads();
+  }
+  mx = s_v[0]; arg = s_i[0];
+  __syncthreads();
+  float sum = 0.0f;
+  for (int i = tid; i < N; i += 256) sum += expf(z[i] - mx);
+  s_v[tid] = sum;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (tid < st) s_v[tid] += s_v[tid + st];
+    __syncthreads();
+  }
+  sum = s_v[0];
+  const int y = labels[b];
+  const float inv = 1.0f / sum;
+  if (tid == 0) {
+    rowstat[2 * b] = (logf(sum) + mx) - z[y];
+    rowstat[2 * b + 1] = (arg == y) ? 1.0f : 0.0f;
+  }
+  __syncthreads();                                       // z[y] read above before anyone overwrites it
+  for (int i = tid; i < N; i += 256) z[i] = (expf(z[i] - mx) * inv - (i == y ? 1.0f : 0.0f)) * inv_batch;
+}
+// stats[0] = sum of row losses, stats[1] = number of correct rows (rows folded in index order)
+__global__ void rowstat_fold_kernel(const float* __restrict__ rowstat, int B, float* __restrict__ stats) {
+  if (threadIdx.x < 2 && blockIdx.x == 0) {
+    float v = 0.0f;
+    for (int b = 0; b < B; ++b) v += rowstat[2 * b + threadIdx.x];
+    stats[threadIdx.x] = v;
+  }
+}
+
 // Adam whose step index lives in device memory: a captured hipGraph replays the same launch every step, so lr_t cannot be a kernel
 // argument.  step_inc_kernel runs once per step before the Adam launches that share the counter.
 __global__ void step_inc_kernel(int* __restrict__ step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
@@ -955,6 +1004,15 @@ int mkws_op_row_scale_add(const float* a, const float* row_scale, const float* c
 int mkws_op_axpy(float* y, const float* x, float alpha, int64_t n, void* stream) {
   MKWS_REQ(y && x && n > 0, "axpy: bad arguments");
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, static_cast<hipStream_t>(stream), y, x, alpha, (size_t)n);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_softmax_ce(float* logits, const int32_t* labels, int B, int N, float* rowstat, float* stats, void* stream) {
+  MKWS_REQ(logits && labels && rowstat && stats && B > 0 && N > 0, "softmax_ce: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(256), 0, s, logits, labels, rowstat, N, 1.0f / (float)B);
+  hipLaunchKernelGGL(rowstat_fold_kernel, dim3(1), dim3(64), 0, s, rowstat, B, stats);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
