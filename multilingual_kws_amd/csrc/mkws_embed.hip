@@ -1858,10 +1858,15 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 #endif
   // ---- phase C2: gate^T[Cexp, clips] = We2^T . r^T, tiles over waves (columns c >= G are don't-care) ----
   // phase D's weight stream is requested first: this wave owns project tiles wave, wave + NWAVES, ...
-  const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0;
+  // NTp = NWAVES / 2 + 1 (blocks 4b / 4c: 5 projection tiles, 8 waves): waves 0 and 4 share SIMD 0, which would then run two whole
+  // tiles while SIMDs 1..3 run one (14.2 us against a 6.4 us MFMA floor).  The last tile is therefore split by ROW tile over waves
+  // NWAVES/2 .. NWAVES/2 + MTO - 1, one row tile each: every SIMD gets MTO + 1 (tile, row tile) units at most.
+  const bool d_rowsplit = (a.NTp == NWAVES / 2 + 1) && (MTO > 1) && (MTO <= NWAVES / 2 - 1);
+  const int d_ntw = d_rowsplit ? ((wave < NWAVES / 2) ? 1 : 0) : ((a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0);
+  const int d_row = (d_rowsplit && wave >= NWAVES / 2 && wave < NWAVES / 2 + MTO) ? wave - NWAVES / 2 : -1;     // this wave's row tile of the last tile
   const WBuf d_w(a.WpP, loff);
   f32x4 wqd[4][3];
-  if (d_ntw > 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);
+  if (d_ntw > 0 || d_row >= 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);   // (tiles past NTp clamp to the last one)
   {
     const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
     auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
@@ -1937,7 +1942,21 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
       }
     };
     // Cout/16 <= 20 tiles over NWAVES waves: each wave runs exactly the 0..3 tiles it owns
-    if (d_ntw == 1) run(std::integral_constant<int, 1>{});
+    if (d_row >= 0) {
+      // one row tile of the last projection tile (see d_rowsplit above)
+      const float* er = erow[0];
+#pragma unroll
+      for (int m = 1; m < MTO; ++m) er = (d_row == m) ? erow[m] : er;
+      auto xload1 = [&](int j, int) { return *reinterpret_cast<const f32x4*>(er + 16 * j); };
+      f32x4 acc1[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
+      stream_mfma<1, 4, 1, true>(acc1, wqd, d_w, cstride, a.NTp - 1, NWAVES, a.NTp, KCx, xload1, xmake);
+      const int n = (a.NTp - 1) * 16 + 4 * g, r = d_row * 16 + c;
+      if (r < rows_out) {
+        f32x4 y = acc1[0][0] * *reinterpret_cast<const f32x4*>(a.scP + n) + *reinterpret_cast<const f32x4*>(a.shP + n);
+        if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + n);
+        *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+      }
+    } else if (d_ntw == 1) run(std::integral_constant<int, 1>{});
     else if (d_ntw == 2) run(std::integral_constant<int, 2>{});
     else if (d_ntw >= 3) run(std::integral_constant<int, 3>{});
   }
