@@ -33,18 +33,21 @@ struct HeadTable { const float* p[kHeadsPerLaunch]; };
 // ascending chunks of 16, so a row's result depends on nothing but that row and the head's parameters (bit-identical across batch
 // sizes, and between the single-head and the multi-head entry point).  Lane (g, c) supplies W1[16j + 4g + s][16 nt + c] (four
 // dword loads 72 B apart: the Keras [in, hid] layout is kept, the heads stay trainable in place) and x[row c][16j + 4g .. + 3]
-// (one float4).  Epilogue in registers: tanh, the hid x cls second layer as per-lane partial sums folded across the four lane
+// (one float4).  The four waves of a workgroup share ONE row tile and split K (wave w walks chunks [w * KC/4, (w+1) * KC/4)): a
+// single window then waits for 16 dependent chunk steps instead of 64 (batch-1 serving: 15 -> ~5 us), and 256 windows give 800
+// workgroups instead of 200; the four partial tiles meet in LDS and are added in wave order, so the split is the same for every
+// batch size.  Epilogue (wave 0) in registers: tanh, the hid x cls second layer as per-lane partial sums folded across the four lane
 // groups by two xor-shuffles, softmax on every lane, lane group 0 stores.  Needs in % 16 == 0 and hid <= 32.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <int NT, bool MULTI>
 __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(HeadDims d, const float* __restrict__ params, const float* __restrict__ x, int B,
                                                             float* __restrict__ probs, HeadTable table) {
+  __shared__ float s_part[3][NT][64][4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int row0 = (blockIdx.x * 4 + wave) * 16;
-  if (row0 >= B) return;
+  const int row0 = blockIdx.x * 16;
   if (MULTI) {
     params = table.p[blockIdx.y];
     probs += (size_t)blockIdx.y * B * d.cls;
@@ -70,16 +73,19 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(HeadDims d, const fl
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int KC = d.in / 16;
+  const int KCall = d.in / 16;
+  const int kper = (KCall + 3) / 4;                      // K chunks per wave
+  const int kc0 = wave * kper;
+  const int KC = (kc0 + kper <= KCall) ? kper : (KCall > kc0 ? KCall - kc0 : 0);
   constexpr int D = 4;                           // chunks in flight per wave
   f32x4 xq[D];
   float wq[D][NT][4];
   auto load = [&](int j, f32x4& xv, float (&wv)[NT][4]) {
-    xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, xoff, 64u * (unsigned)j, 0));
+    xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, xoff, 64u * (unsigned)(kc0 + j), 0));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) wv[nt][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, woff[nt][s], wchunk * (unsigned)j, 0));
+      for (int s = 0; s < 4; ++s) wv[nt][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, woff[nt][s], wchunk * (unsigned)(kc0 + j), 0));
   };
   auto compute = [&](const f32x4& xv, const float (&wv)[NT][4]) {
 #pragma unroll
@@ -115,6 +121,21 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(HeadDims d, const fl
       compute(xq[0], wq[0]);
     }
   }
+  // the K slices of waves 1..3 join wave 0's in wave order
+  if (wave > 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_part[wave - 1][nt][lane][r] = acc[nt][r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[nt][r] += s_part[w][nt][lane][r];
   // acc[nt][r] = pre-activation of hidden unit 16 nt + 4 g + r for row c
   float z[kMaxClasses];
 #pragma unroll
@@ -500,9 +521,9 @@ int mkws_head_forward(mkws_head* hd, const float* d_emb, int B, float* d_probs, 
   if (!d_emb || !d_probs) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
   if (hd->d.in % 16 == 0) {        // matrix-core path (the same kernel serves mkws_heads_forward: results are bit-identical between the two)
     if (hd->d.hid <= 16)
-      hipLaunchKernelGGL((head_fwd_mfma_kernel<1, false>), dim3((B + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb, B, d_probs, HeadTable());
+      hipLaunchKernelGGL((head_fwd_mfma_kernel<1, false>), dim3((B + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb, B, d_probs, HeadTable());
     else
-      hipLaunchKernelGGL((head_fwd_mfma_kernel<2, false>), dim3((B + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb, B, d_probs, HeadTable());
+      hipLaunchKernelGGL((head_fwd_mfma_kernel<2, false>), dim3((B + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb, B, d_probs, HeadTable());
   } else {
     hipLaunchKernelGGL((head_rows_kernel<false>), dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hd->d, hd->params, d_emb,
                        nullptr, B, d_probs, nullptr, nullptr, nullptr, nullptr);
@@ -528,10 +549,10 @@ int mkws_heads_forward(mkws_head* const* heads, int n_heads, const float* d_emb,
     for (int i = 0; i < kHeadsPerLaunch; ++i) t.p[i] = heads[h0 + (i < n ? i : 0)]->params;
     if (d.in % 16 == 0) {
       if (d.hid <= 16)
-        hipLaunchKernelGGL((head_fwd_mfma_kernel<1, true>), dim3((B + 63) / 64, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb, B,
+        hipLaunchKernelGGL((head_fwd_mfma_kernel<1, true>), dim3((B + 15) / 16, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb, B,
                            d_probs + (size_t)h0 * B * d.cls, t);
       else
-        hipLaunchKernelGGL((head_fwd_mfma_kernel<2, true>), dim3((B + 63) / 64, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb, B,
+        hipLaunchKernelGGL((head_fwd_mfma_kernel<2, true>), dim3((B + 15) / 16, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb, B,
                            d_probs + (size_t)h0 * B * d.cls, t);
     } else {
       hipLaunchKernelGGL((head_rows_kernel<false, true, 4>), dim3((B + 15) / 16, n), dim3(256), 0, static_cast<hipStream_t>(stream), d, nullptr, d_emb,
