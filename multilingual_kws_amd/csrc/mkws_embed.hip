@@ -2376,6 +2376,283 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cluster kernel for the tiny-image blocks of SMALL-batch handles (live serving: one window at a time).  At batch 1 a whole-block
+// kernel is one workgroup streaming the block's 0.75-2.2 MB of weights through ONE CU (~41 GB/s): 24-36 us per block, 11 blocks = 313
+// of the 489 us a window costs (tools/latency_profile.py).  Here P = 6 workgroups on 6 CUs of one XCD share ONE 16-row tile (one clip
+// of a 4x3 image, four clips of a 2x2 image) and split the block's expanded CHANNELS six ways (480, 672 and 1152 are all multiples of
+// 6 x 16): every CU streams a sixth of the weights and the phases shrink to their latencies.
+//   A   expand: the member's KH = Cexp/96 n-tiles                B   depthwise + SE means on its channels (local: depthwise is per channel)
+//   C1  partial r over its channels -> exchange 1: all six partial r vectors are added in member order by everyone
+//   C2  gate for its channels, applied in place                   D   partial projection over its K slice, ALL output tiles
+//   exchange 2: output tile t is finished by member t % 6 (the six partials added in member order, BN, residual)
+// Exchanges are the paired kernel's (plain stores, s_waitcnt vmcnt(0), barrier, relaxed agent-scope flag, L1-bypassing loads) with
+// GENERATION flags instead of consumer resets (six readers per flag): a member reads its own flag g0 when it starts, publishes g0 + 1
+// and waits for the other five to show g0 + 1 -- all six took part in the same launches, so they agree on g0; nothing to reset, and a
+// captured graph replays it.  Members of a cluster have linear workgroup ids that are congruent mod 8 (same XCD under the round-robin
+// dispatch probed at create); every member checks the others' XCC ids and a poll limit, and a failure takes the paired kernel's
+// exit: NaN output, sticky error words, handle moved to the plain whole-block kernels by the next mkws_embed_forward.
+constexpr int kClusterP = 6, kClXc1 = 256, kClMaxTiles = 20, kClusterChMax = 192;
+constexpr int kClusterLdsFloats = 12 * 256 + 16 * (kClusterChMax + 4) + 4 * kClusterChMax + 4 * 52 + 2 * kClusterChMax + 2 * 48 * kClusterChMax;
+struct ClusterArgs {
+  BlockArgs b;
+  const float* Wr;   // plain [Cexp][se]
+  const float* We;   // plain [se][Cexp]
+  float* xc1;        // [clusters][P][kClXc1]: 48 units x up to 4 clips of partial r; [255] = the member's XCC id
+  float* xd;         // [clusters][P][kClMaxTiles][256]: partial projection tiles, lane-linear
+  int* flags;        // [clusters][2 exchanges][8] generations (8-int rows: one 32 B line per exchange)
+  int* err_dev; int* err_host; int fault;
+};
+
+// thread 0: publish generation `gen` in `mine`, wait until the other members show it too.  0 = ok, 1 = timed out.
+__device__ __forceinline__ int cluster_signal_wait(int* row, int p, int gen) {
+  __hip_atomic_store(row + p, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int q = 0; q < kClusterP; ++q) {
+    if (q == p) continue;
+    int spins = 0;
+    while (__hip_atomic_load(row + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 21)) return 1;
+    }
+  }
+  return 0;
+}
+
+template <int KS, int S, int HT, int WT>
+__global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
+  constexpr int P = kClusterP, NTHR = 256, NW = 4;
+  constexpr int HW = HT * WT, G = 16 / HW;                       // clips per cluster: 1 (4x3) or 4 (2x2)
+  constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1), HoWo = HoT * WoT;
+  constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+  constexpr int CHMAX = kClusterChMax, LDEMAX = CHMAX + 4, LDR = 52;
+  extern __shared__ __attribute__((aligned(16))) float s_cl[];    // kClusterLdsFloats, carved for the largest block (CH = 192, 12 K chunks)
+  float* s_X = s_cl;                                             // block input as B-operand fragments [KCe][64 lanes][4]
+  float* s_E = s_X + 12 * 256;                                   // this member's expanded channels [16 rows][CH + 4]
+  float* s_S = s_E + 16 * LDEMAX;                                // SE means [G][CH], later the gate
+  float* s_R = s_S + 4 * CHMAX;                                  // r [G][52]
+  float* s_sc = s_R + 4 * LDR;                                   // expand BN scale / shift of the member's channels
+  float* s_sh = s_sc + CHMAX;
+  float* s_Wr = s_sh + CHMAX;                                    // the member's rows of the SE-reduce weights [CH][se]
+  float* s_We = s_Wr + CHMAX * 48;                               // its columns of the SE-expand weights [se][CH]
+  __shared__ int s_bad;
+  const BlockArgs& a = ca.b;
+  const int cl = (blockIdx.x / (8 * P)) * 8 + (blockIdx.x & 7), p = (blockIdx.x >> 3) % P;
+  const int b0 = cl * G;
+  if (b0 >= a.B) return;                                         // all members of a padding cluster leave together
+  const int Cexp = a.Cexp, CH = Cexp / P, KH = CH / 16, chan0 = p * CH, LDE = CH + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const unsigned loff = (unsigned)(g * 64 + c * 4);
+  const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
+  const int rows_in = gvalid * HW, rows_out = gvalid * HoWo;
+  const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 0xf;
+  int* frow = ca.flags + (size_t)cl * 16;                         // [2][8]
+  float* xc1 = ca.xc1 + (size_t)cl * P * kClXc1;
+  float* xd = ca.xd + (size_t)cl * P * kClMaxTiles * 256;
+  if (ca.fault == 2 && p == 1) return;                           // test hook: a member never arrives
+  int gen0 = 0, gen1 = 0;
+  if (tid == 0) {
+    s_bad = __hip_atomic_load(ca.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky: an earlier launch failed
+    gen0 = __hip_atomic_load(frow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    gen1 = __hip_atomic_load(frow + 8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  }
+  // ---- stage the input tile as fragments, the member's expand BN constants ----
+  for (int j = wave; j < a.KCe; j += NW) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < rows_in && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
+    *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = v;
+  }
+  for (int i = tid; i < CH; i += NTHR) { s_sc[i] = a.scE[chan0 + i]; s_sh[i] = a.shE[chan0 + i]; }
+  // the SE weights of the member's channels go to LDS now (coalesced; consumed three phases later)
+  for (int i = tid; i < CH * a.se / 4; i += NTHR)                  // [CH][se] rows chan0.. are contiguous; CH * se % 4 == 0 (CH % 16 == 0)
+    *reinterpret_cast<f32x4*>(s_Wr + 4 * i) = *reinterpret_cast<const f32x4*>(ca.Wr + (size_t)chan0 * a.se + 4 * i);
+  for (int i = tid; i < a.se * (CH / 4); i += NTHR) {
+    const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4;
+    *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = *reinterpret_cast<const f32x4*>(ca.We + (size_t)n * Cexp + chan0 + q4);
+  }
+  __syncthreads();
+  // ---- A: expand, tiles wave, wave + 4, ... of the member's KH ----
+  {
+    const int nruns = (KH > wave) ? (KH - wave + NW - 1) / NW : 0;
+    auto tile_of = [&](int r) { return p * KH + wave + NW * r; };
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)j * 64 + lane) * 4); };
+    auto xmake = [](const f32x4& v) { return v; };
+    auto epi = [&](int t0, const f32x4 (&acc)[1][1]) {
+      const int n = (t0 - p * KH) * 16 + 4 * g;                   // column inside the member's slice
+      f32x4 y = acc[0][0] * *reinterpret_cast<const f32x4*>(s_sc + n) + *reinterpret_cast<const f32x4*>(s_sh + n);
+      y = swish4_(y);
+      if (c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(s_E + (size_t)c * LDE + n) = y;
+    };
+    f32x4 wqa[4][1];
+    stream_mfma_runs<1, 4, 1, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
+  }
+  __syncthreads();
+  // ---- B: depthwise + BN + swish in place, SE means (thread = clip x channel quad of the member's slice) ----
+  {
+    const int Q = CH / 4;
+    for (int task = tid; task < G * Q; task += NTHR) {
+      const int gi = task / Q, q4 = (task - gi * Q) * 4;
+      float* Eg = s_E + (size_t)gi * HW * LDE + q4;
+      f32x4 ein[HW];
+#pragma unroll
+      for (int pix = 0; pix < HW; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(Eg + (size_t)pix * LDE);
+      f32x4 acc[HoWo];
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) {
+          bool used = false;
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+            }
+          if (!used) continue;
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + chan0 + q4);
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv;
+            }
+        }
+      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + chan0 + q4), sh = *reinterpret_cast<const f32x4*>(a.shD + chan0 + q4);
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) {
+        f32x4 y = acc[o] * sc + sh;
+        y = swish4_(y);
+        if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Eg + (size_t)o * LDE) = y;     // output o of clip gi lives in row gi*HW + o (in place)
+        ssum += y;
+        if (a.dbg_dw && gi < gvalid) *reinterpret_cast<f32x4*>(a.dbg_dw + (row0_out + gi * HoWo + o) * Cexp + chan0 + q4) = y;
+      }
+      *reinterpret_cast<f32x4*>(s_S + (size_t)gi * CH + q4) = ssum * (1.0f / (float)HoWo);
+    }
+  }
+  __syncthreads();
+  // ---- C1: partial r[unit n][clip] over the member's channels (thread = (n, clip), a.se <= 48), published for exchange 1 ----
+  if (tid < 48 * G) {
+    const int n = tid / G, clip = tid - n * G;
+    float v = 0.0f;
+    if (n < a.se) {
+      const float* wr = s_Wr + n;
+      const float* mrow = s_S + (size_t)clip * CH;
+      for (int ch = 0; ch < CH; ++ch) v += mrow[ch] * wr[ch * a.se];
+    }
+    xc1[(size_t)p * kClXc1 + tid] = v;
+  }
+  if (tid == 255) xc1[(size_t)p * kClXc1 + 255] = (float)(ca.fault == 1 && p == 1 ? (xcc ^ 1u) : xcc);
+  const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0 && s_bad == 0) {
+    if (cluster_signal_wait(frow, p, gen0)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
+  }
+  __syncthreads();
+  if (tid < 48 * G) {
+    const int n = tid / G, clip = tid - n * G;
+    float v = 0.0f;
+    if (n < a.se) {
+      for (int q = 0; q < P; ++q) v += __hip_atomic_load(xc1 + (size_t)q * kClXc1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = swishf_(v + br_pre);
+    }
+    s_R[clip * LDR + n] = v;
+  }
+  if (tid == 0 && s_bad == 0) {
+    for (int q = 0; q < P; ++q)
+      if ((unsigned)__hip_atomic_load(xc1 + (size_t)q * kClXc1 + 255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc) {
+        s_bad = 1;
+        pair_report(ca.err_dev, ca.err_host, kPairErrXcc);
+      }
+  }
+  __syncthreads();
+  // ---- C2: gate of the member's channels (thread = (clip, channel)), applied to the depthwise output in place ----
+  for (int t = tid; t < G * CH; t += NTHR) {
+    const int clip = t / CH, ch = t - clip * CH;
+    float v = 0.0f;
+    const float* we = s_We + ch;
+    const float* rr = s_R + clip * LDR;
+    for (int n = 0; n < a.se; ++n) v += rr[n] * we[n * CH];
+    v = sigmoidf_(v + a.be[chan0 + ch]);
+    s_S[(size_t)clip * CH + ch] = v;
+    if (a.dbg_gate && clip < gvalid) a.dbg_gate[(size_t)(b0 + clip) * Cexp + chan0 + ch] = v;
+  }
+  __syncthreads();
+  {
+    const int Q = CH / 4;
+    for (int i = tid; i < G * HoWo * Q; i += NTHR) {
+      const int ro = i / Q, q4 = (i - ro * Q) * 4;
+      const int clip = ro / HoWo;
+      float* e = s_E + (size_t)(clip * HW + (ro - clip * HoWo)) * LDE + q4;
+      *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_S + (size_t)clip * CH + q4);
+    }
+  }
+  __syncthreads();
+  // ---- D: partial projection over the member's K (KH chunks), every output tile; tiles wave, wave + 4, ... (at most 5 per wave) ----
+  {
+    int r = c;
+    if (r >= G * HoWo) r = G * HoWo - 1;
+    const int clip = r / HoWo;
+    const float* erow = s_E + (size_t)(clip * HW + (r - clip * HoWo)) * LDE + 4 * g;
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(erow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    const WBuf d_w(a.WpP + (size_t)(p * KH) * a.NTp * 256, loff);
+    const size_t cstride = (size_t)a.NTp * 256;
+    const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NW - 1) / NW : 0;      // this wave's tiles wave, wave + 4, ...: one pass over K for all of them
+    auto run = [&](auto ntw_tag) {
+      constexpr int NTW = decltype(ntw_tag)::value;
+      f32x4 acc[NTW][1], wqd[4][NTW];
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      stream_mfma<NTW, 4, 1, false>(acc, wqd, d_w, cstride, wave, NW, a.NTp, KH, xload, xmake);
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        const int t = wave + NW * q;
+        if (t < a.NTp) *reinterpret_cast<f32x4*>(xd + ((size_t)(p * kClMaxTiles + t) * 64 + lane) * 4) = acc[q][0];
+      }
+    };
+    if (d_ntw == 1) run(std::integral_constant<int, 1>{});
+    else if (d_ntw == 2) run(std::integral_constant<int, 2>{});
+    else if (d_ntw == 3) run(std::integral_constant<int, 3>{});
+    else if (d_ntw == 4) run(std::integral_constant<int, 4>{});
+    else if (d_ntw >= 5) run(std::integral_constant<int, 5>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0 && s_bad == 0) {
+    if (cluster_signal_wait(frow + 8, p, gen1)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
+  }
+  __syncthreads();
+  // ---- exchange 2: member t % P finishes output tile t (partials of all members in member order) ----
+  {
+    const bool bad = s_bad != 0;
+    for (int k = wave; p + P * k < a.NTp; k += NW) {
+      const int t = p + P * k;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < P; ++q) v += ld_agent_x4(xd + ((size_t)(q * kClMaxTiles + t) * 64 + lane) * 4);
+      const int n = t * 16 + 4 * g;
+      if (c < rows_out) {
+        f32x4 y = v * *reinterpret_cast<const f32x4*>(a.scP + n) + *reinterpret_cast<const f32x4*>(a.shP + n);
+        if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + n);
+        if (bad) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        *reinterpret_cast<f32x4*>(a.Y + (row0_out + c) * a.Cout + n) = y;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // SE: mean = sums/HW; r = swish(mean @ Wr + br); gate = sigmoid(r @ We + be).
 // Both FCs run on the fp32 MFMA as (weights x 16 clips) tiles with pack_gemm-packed weights, and both are
 // spread over the whole chip (a single block per 16 clips would stream up to 442 KB of SE weights through
@@ -2552,6 +2829,8 @@ struct mkws_embed {
   size_t pair_flag_count = 0;
   int pair_fault = 0;              // test hook, see PairArgs::fault
   int pair_degraded = 0;           // how many times this handle left the paired kernel because an exchange failed
+  int fuse_cluster = 0;            // small-batch handles: tiny-image blocks on mbconv_cluster_kernel (6 workgroups per 16-row tile split the channels)
+  float* cl_xc1 = nullptr; float* cl_xd = nullptr; int* cl_flags = nullptr; size_t cl_flag_count = 0;   // its exchange buffers / generation flags
   int pair_mt = 2;                 // row tiles per pair (2 = 8 clips, 1 = 4 clips): pair_row_tiles(max_batch)
   int block_mt43 = 3;              // row tiles per workgroup of the 4x3 whole-block kernels (3 = 4 clips, 2 = 2 clips): same rule
   BlockPlan blocks[kNumBlocks];
@@ -2994,6 +3273,55 @@ int launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const Pair
   return MKWS_OK;
 }
 
+// Cluster kernel (mbconv_cluster_kernel): tiny-image blocks of small-batch handles.
+constexpr int kClusterMaxBatch = 32;                 // handles up to this size plan the cluster kernel (tools/plan_sweep.py)
+static int cluster_count(int B, int clips_per_cluster) { return (((B + clips_per_cluster - 1) / clips_per_cluster) + 7) / 8 * 8; }   // whole groups of 8 clusters
+bool cluster_supported(const BlockPlan& b) {
+  const int ks = b.spec.kernel, st = b.spec.stride;
+  if (!b.has_expand || b.ce % (16 * kClusterP) != 0 || b.ce / kClusterP > kClusterChMax || b.expand.KC > 12) return false;
+  if (b.project.NTtot > kClMaxTiles || b.se.se > 48 || b.spec.out_ch % 16 != 0) return false;
+  if (b.H == 4 && b.W == 3) return (ks == 3 && st == 1) || (ks == 5 && st == 1) || (ks == 5 && st == 2);
+  if (b.H == 2 && b.W == 2) return (ks == 5 && st == 1) || (ks == 3 && st == 1);
+  return false;
+}
+
+int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, const mkws_embed* em, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+  ClusterArgs ca;
+  BlockArgs& a = ca.b;
+  a.X = X; a.Cin = b.spec.in_ch;
+  a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KCe = b.expand.KC; a.NTe = b.expand.NTtot;
+  a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift;
+  a.WrP = b.se.WrP; a.br = b.se.br; a.NTR = b.se.NTR; a.We2P = b.se.WeP; a.be = b.se.be;
+  a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift; a.NTp = b.project.NTtot;
+  a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
+  a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
+  a.B = B; a.Cexp = b.ce; a.se = b.se.se;
+#ifdef MKWS_FRONT_TIMING
+  a.dbg_t = nullptr;
+#endif
+  ca.Wr = b.se.Wr; ca.We = b.se.We;
+  ca.xc1 = em->cl_xc1; ca.xd = em->cl_xd; ca.flags = em->cl_flags;
+  ca.err_dev = em->pair_err_dev; ca.err_host = em->pair_err_host; ca.fault = em->pair_fault;
+  const int G = 16 / (b.H * b.W);
+  const dim3 grid(cluster_count(B, G) * kClusterP);
+  const size_t lds = (size_t)kClusterLdsFloats * sizeof(float);
+  const int ks = b.spec.kernel, st = b.spec.stride;
+  ProfScope ps(stage, std::string("mbconv_cluster_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
+#define MKWS_CLUSTER(KS, S, H_, W_) do { \
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_cluster_kernel<KS, S, H_, W_>), 160 * 1024)) return rc_; \
+    hipLaunchKernelGGL((mbconv_cluster_kernel<KS, S, H_, W_>), grid, dim3(256), lds, s, ca); } while (0)
+  if (b.H == 4) {
+    if (ks == 3) MKWS_CLUSTER(3, 1, 4, 3);
+    else if (st == 1) MKWS_CLUSTER(5, 1, 4, 3);
+    else MKWS_CLUSTER(5, 2, 4, 3);
+  } else {
+    if (ks == 5) MKWS_CLUSTER(5, 1, 2, 2);
+    else MKWS_CLUSTER(3, 1, 2, 2);
+  }
+#undef MKWS_CLUSTER
+  return MKWS_OK;
+}
+
 // Whole-block kernel for the big-image blocks 2a..4a (mbconv_mid_kernel): one instance per layer geometry.
 bool mid_supported(const BlockPlan& b) {
   if (!b.has_expand || b.se.se > 10) return false;
@@ -3127,11 +3455,13 @@ int check_pair_health(mkws_embed* em, hipStream_t s) {
   const int code = *reinterpret_cast<volatile int*>(em->pair_err_host);
   if (code == 0) return MKWS_OK;
   em->fuse_pair = 0;
+  em->fuse_cluster = 0;
   em->pair_fault = 0;
   ++em->pair_degraded;
   *reinterpret_cast<volatile int*>(em->pair_err_host) = 0;
   MKWS_HIP(hipMemsetAsync(em->pair_flags, 0, em->pair_flag_count * sizeof(int), s));
   MKWS_HIP(hipMemsetAsync(em->pair_err_dev, 0, sizeof(int), s));
+  if (em->cl_flags) MKWS_HIP(hipMemsetAsync(em->cl_flags, 0, em->cl_flag_count * sizeof(int), s));
   return fail(MKWS_ERR_EXCHANGE, "paired whole-block kernel: %s in an earlier forward of this handle -- that forward's embeddings are NaN-poisoned; "
               "the handle now uses one workgroup per 4 clips (fuse_pair = 0): repeat the call",
               code == kPairErrXcc ? "the two halves of a pair ran on different XCDs" : "a half timed out waiting for its partner");
@@ -3192,7 +3522,9 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
-      if (em->fuse_pair && pair_supported(b)) {
+      if (em->fuse_cluster && cluster_supported(b) && em->cl_flags) {
+        if (int rc = launch_cluster(s, p.c_str(), b, em, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
+      } else if (em->fuse_pair && pair_supported(b)) {
         PairWs pw; pw.xc1 = em->pair_xc1; pw.xd = em->pair_xd; pw.flags = em->pair_flags; pw.mt = em->pair_mt;
         pw.err_dev = em->pair_err_dev; pw.err_host = em->pair_err_host; pw.fault = em->pair_fault;
         if (int rc = launch_pair(s, p.c_str(), b, pw, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
@@ -3321,6 +3653,8 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->fuse_mid = 1;
   em->fuse_back = 1;
   em->fuse_pair = pair_layout_ok() ? 1 : 0;
+  // small-batch (live serving) handles: the tiny-image blocks on the 6-way cluster kernel, same dispatch-order premise as the pairs
+  em->fuse_cluster = (max_batch <= kClusterMaxBatch && em->fuse_pair) ? 1 : 0;
   em->pair_mt = pair_row_tiles(max_batch);
   em->block_mt43 = (em->pair_mt == 1) ? 2 : 3;
   (void)hipGetDevice(&em->device);
@@ -3414,7 +3748,10 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // workspace
   const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 20480 + 9 * 48;
   const size_t pair_floats = pair_ws_floats(max_batch, em->pair_mt);
-  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4;
+  // cluster exchange buffers exist for handles that may ever use the kernel (the option can be set after create up to 64 clips)
+  const size_t ncl = (max_batch <= 64) ? (size_t)cluster_count(max_batch, 1) : 0;
+  const size_t cluster_floats = ncl * ((size_t)kClusterP * kClXc1 + (size_t)kClusterP * kClMaxTiles * 256 + 16);
+  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4 + cluster_floats;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
   }
@@ -3436,6 +3773,15 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
       (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "setting up the pair flags failed");
     }
     *em->pair_err_host = 0;
+    if (ncl > 0) {
+      em->cl_xc1 = w; w += ncl * kClusterP * kClXc1;
+      em->cl_xd = w; w += ncl * kClusterP * kClMaxTiles * 256;
+      em->cl_flags = reinterpret_cast<int*>(w); w += ncl * 16;
+      em->cl_flag_count = ncl * 16;
+      if (hipMemset(em->cl_flags, 0, ncl * 16 * sizeof(int)) != hipSuccess) {
+        (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); (void)hipHostFree(em->pair_err_host); delete em; return fail(MKWS_ERR_HIP, "clearing the cluster flags failed");
+      }
+    }
   }
   *out = em;
   return MKWS_OK;
@@ -3470,6 +3816,10 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
   if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
   if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_cluster") == 0) {
+    if (value && !em->cl_flags) return fail(MKWS_ERR_UNSUPPORTED, "fuse_cluster needs a handle of at most 64 clips (max_batch = %d)", em->max_batch);
+    em->fuse_cluster = value; return MKWS_OK;
+  }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
   if (strcmp(name, "pair_fault") == 0) { em->pair_fault = value; return MKWS_OK; }     // test hook: forces the paired kernel's failure paths
@@ -3483,6 +3833,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_mid") == 0) return em->fuse_mid;
   if (strcmp(name, "fuse_back") == 0) return em->fuse_back;
   if (strcmp(name, "fuse_pair") == 0) return em->fuse_pair;
+  if (strcmp(name, "fuse_cluster") == 0) return em->fuse_cluster;
   if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
   if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;
   if (strcmp(name, "pair_degraded") == 0) return em->pair_degraded;

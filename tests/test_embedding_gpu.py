@@ -243,8 +243,8 @@ def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault):
     assert _rel(em2.forward(x).cpu().numpy(), ref) < REL_TOL and em2.get_option("pair_degraded") == 1
 
 
-@pytest.mark.parametrize("plan", ["default", "multi-kernel"])
-@pytest.mark.parametrize("max_batch", [1, 2, 256])
+@pytest.mark.parametrize("plan", ["default", "multi-kernel", "no-cluster"])
+@pytest.mark.parametrize("max_batch", [1, 2, 5, 32, 256])
 def test_serving_handle_plans(ctx, max_batch, plan):
     """The handles bench.py's streaming config builds (BASELINE configs[4]: max_batch 1 for the latency leg, 256 for throughput)
     against the oracle, with batch-size invariance inside the handle -- on the shipped plan (whole-block kernels for every handle
@@ -255,10 +255,14 @@ def test_serving_handle_plans(ctx, max_batch, plan):
     x = torch.from_numpy(spec).to(ctx["dev"])
     em = EmbeddingModel(ctx["blob"], max_batch=max_batch)
     if plan == "multi-kernel":
-        for k in ("fuse_block", "fuse_mid", "fuse_back", "fuse_pair"):
+        for k in ("fuse_block", "fuse_mid", "fuse_back", "fuse_pair", "fuse_cluster"):
             em.set_option(k, 0)
+    elif plan == "no-cluster":
+        em.set_option("fuse_cluster", 0)
     else:
         assert em.get_option("fuse_block") == 2 and em.get_option("fuse_mid") == 1
+        # live-serving handles (<= 32 clips) run the tiny-image blocks on the 6-way cluster kernel (when the dispatch probe passed)
+        assert em.get_option("fuse_cluster") == (1 if max_batch <= 32 and em.get_option("fuse_pair") else 0)
     out = em.forward(x)
     ref = ctx["oracle"].forward(spec).numpy()
     assert _rel(out.cpu().numpy(), ref) < REL_TOL and np.array_equal(out.cpu().numpy().argmax(1), ref.argmax(1))
@@ -271,3 +275,43 @@ def test_serving_handle_plans(ctx, max_batch, plan):
         idx = np.arange(0, 256, 23)
         assert _rel(of[idx].cpu().numpy(), ctx["oracle"].forward(full[idx]).numpy()) < REL_TOL
         assert torch.equal(em.forward(xf[:n]), of[:n])
+
+
+def test_cluster_kernel_taps_and_failure_contract(ctx):
+    """mbconv_cluster_kernel (small-batch handles: six workgroups share one 16-row tile and split the expanded channels): inner taps of
+    every block it runs against the oracle, ragged clip counts (1 clip per cluster on 4x3 images, 4 on 2x2), graph-free repeat calls
+    (generation flags), and the shared failure contract (forced XCC mismatch / missing member -> NaN, MKWS_ERR_EXCHANGE, degraded)."""
+    from multilingual_kws_amd import _lib
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    spec = _spec(np.random.default_rng(77), 7)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    em = EmbeddingModel(ctx["blob"], max_batch=7)
+    if em.get_option("fuse_cluster") != 1:
+        pytest.skip("dispatch probe failed on this device: the cluster kernel is not in use")
+    taps = {}
+    ref = ctx["oracle"].forward(spec, taps).numpy()
+    for name in ("block4b_dw", "block4b_gate", "block4b", "block4c", "block5a_dw", "block5a", "block5b_gate", "block5b", "block5c", "block6a_dw", "block6a_gate",
+                 "block6a", "block6b_dw", "block6b_gate", "block6b", "block6c", "block6d", "block7a_dw", "block7a_gate", "block7a"):
+        got = em.tap(x, name).cpu().numpy().reshape(taps[name].shape)
+        assert _rel(got, taps[name]) < REL_TOL, name
+    out = em.forward(x)
+    assert _rel(out.cpu().numpy(), ref) < REL_TOL
+    for b in (1, 2, 3, 4, 5, 6):
+        assert torch.equal(em.forward(x[:b]), out[:b]), b                     # and 20+ launches per call exercise the generation flags
+    for fault in (1, 2):
+        emf = EmbeddingModel(ctx["blob"], max_batch=7)
+        emf.set_option("pair_fault", fault)
+        bad = emf.forward(x)
+        torch.cuda.synchronize()
+        assert torch.isnan(bad).all()
+        emf.set_option("pair_fault", 0)
+        emb = torch.empty((7, 1024), device=ctx["dev"])
+        rc = emf.L.mkws_embed_forward(emf.h, x.data_ptr(), 7, emb.data_ptr(), _lib.current_stream_ptr())
+        assert rc == _lib.MKWS_ERR_EXCHANGE and emf.get_option("fuse_cluster") == 0 and emf.get_option("fuse_pair") == 0
+        again = emf.forward(x)
+        assert torch.isfinite(again).all() and _rel(again.cpu().numpy(), ref) < REL_TOL
+        emf.set_option("fuse_cluster", 1)                                      # re-armed after the reset: flags were cleared in stream order
+        assert _rel(emf.forward(x).cpu().numpy(), ref) < REL_TOL
+    big = EmbeddingModel(ctx["blob"], max_batch=128)
+    with pytest.raises(_lib.MkwsError):
+        big.set_option("fuse_cluster", 1)                                      # no exchange buffers above 64 clips

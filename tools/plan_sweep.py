@@ -9,18 +9,26 @@ import torch
 from multilingual_kws_amd import weights
 from multilingual_kws_amd.embedding_model import EmbeddingModel
 
-PLANS = {"multi": dict(fuse_block=0, fuse_mid=0, fuse_back=0, fuse_pair=0),
-         "whole": dict(fuse_block=2, fuse_mid=1, fuse_back=1, fuse_pair=0),
-         "whole+pair": dict(fuse_block=2, fuse_mid=1, fuse_back=1, fuse_pair=1)}
+PLANS = {"multi": dict(fuse_block=0, fuse_mid=0, fuse_back=0, fuse_pair=0, fuse_cluster=0),
+         "whole": dict(fuse_block=2, fuse_mid=1, fuse_back=1, fuse_pair=0, fuse_cluster=0),
+         "whole+pair": dict(fuse_block=2, fuse_mid=1, fuse_back=1, fuse_pair=1, fuse_cluster=0),
+         "cluster": dict(fuse_block=2, fuse_mid=1, fuse_back=1, fuse_pair=1, fuse_cluster=1)}
+if os.environ.get("PLANS"):
+    PLANS = {k: v for k, v in PLANS.items() if k in os.environ["PLANS"].split(",")}
 blob = weights.synthetic_blob()
 dev = torch.device("cuda:0")
 for mb in (int(x) for x in (sys.argv[1:] or ["1", "8", "32", "64", "128", "256"])):
     for plan, opts in PLANS.items():
         for lanes in (1, 4):
             ems = [EmbeddingModel(blob, max_batch=mb) for _ in range(lanes)]
-            for em in ems:
-                for k, v in opts.items():
-                    em.set_option(k, v)
+            try:
+                for em in ems:
+                    for k, v in opts.items():
+                        if not (k == "fuse_cluster" and v == 0 and mb > 64):
+                            em.set_option(k, v)
+            except Exception as exc:
+                print(f"max_batch {mb:4d} plan {plan}: not available ({exc})")
+                continue
             xs = [torch.rand((mb, 49, 40), device=dev) * 26 for _ in range(lanes)]
             outs = [torch.empty((mb, 1024), device=dev) for _ in range(lanes)]
             side = [torch.cuda.Stream() for _ in range(lanes)]
