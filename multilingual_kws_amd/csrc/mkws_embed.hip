@@ -3308,7 +3308,7 @@ int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, const m
   const int ks = b.spec.kernel, st = b.spec.stride;
   ProfScope ps(stage, std::string("mbconv_cluster_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
 #define MKWS_CLUSTER(KS, S, H_, W_) do { \
-    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_cluster_kernel<KS, S, H_, W_>), 160 * 1024)) return rc_; \
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_cluster_kernel<KS, S, H_, W_>), (int)lds)) return rc_;   /* (+ 16 B static) */ \
     hipLaunchKernelGGL((mbconv_cluster_kernel<KS, S, H_, W_>), grid, dim3(256), lds, s, ca); } while (0)
   if (b.H == 4) {
     if (ks == 3) MKWS_CLUSTER(3, 1, 4, 3);
