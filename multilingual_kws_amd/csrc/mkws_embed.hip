@@ -2392,7 +2392,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
 // dispatch probed at create); every member checks the others' XCC ids and a poll limit, and a failure takes the paired kernel's
 // exit: NaN output, sticky error words, handle moved to the plain whole-block kernels by the next mkws_embed_forward.
 constexpr int kClusterP = 6, kClXc1 = 256, kClMaxTiles = 20, kClusterChMax = 192;
-constexpr int kClusterLdsFloats = 12 * 256 + 16 * (kClusterChMax + 4) + 4 * kClusterChMax + 4 * 52 + 2 * kClusterChMax + 2 * 48 * kClusterChMax;
+constexpr int kClusterLdsFloats = 12 * 256 + 16 * (kClusterChMax + 4) + 4 * kClusterChMax + 4 * 52 + 2 * kClusterChMax + 48 * (kClusterChMax + 4) + 48 * kClusterChMax;
 struct ClusterArgs {
   BlockArgs b;
   const float* Wr;   // plain [Cexp][se]
@@ -2431,8 +2431,8 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   float* s_R = s_S + 4 * CHMAX;                                  // r [G][52]
   float* s_sc = s_R + 4 * LDR;                                   // expand BN scale / shift of the member's channels
   float* s_sh = s_sc + CHMAX;
-  float* s_Wr = s_sh + CHMAX;                                    // the member's rows of the SE-reduce weights [CH][se]
-  float* s_We = s_Wr + CHMAX * 48;                               // its columns of the SE-expand weights [se][CH]
+  float* s_Wr = s_sh + CHMAX;                                    // the member's rows of the SE-reduce weights, TRANSPOSED: [se][CH + 4]
+  float* s_We = s_Wr + 48 * (CHMAX + 4);                         // its columns of the SE-expand weights [se][CH]
   __shared__ int s_bad;
   const BlockArgs& a = ca.b;
   const int cl = (blockIdx.x / (8 * P)) * 8 + (blockIdx.x & 7), p = (blockIdx.x >> 3) % P;
@@ -2467,8 +2467,17 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   }
   for (int i = tid; i < CH; i += NTHR) { s_sc[i] = a.scE[chan0 + i]; s_sh[i] = a.shE[chan0 + i]; }
   // the SE weights of the member's channels go to LDS now (coalesced; consumed three phases later)
-  for (int i = tid; i < CH * a.se / 4; i += NTHR)                  // [CH][se] rows chan0.. are contiguous; CH * se % 4 == 0 (CH % 16 == 0)
-    *reinterpret_cast<f32x4*>(s_Wr + 4 * i) = *reinterpret_cast<const f32x4*>(ca.Wr + (size_t)chan0 * a.se + 4 * i);
+  const int LDW = CH + 4;
+  if ((a.se & 3) == 0) {                                            // [CH][se] rows chan0.. are contiguous in global memory; float4 = 4 units of one channel
+    for (int i = tid; i < CH * a.se / 4; i += NTHR) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ca.Wr + (size_t)chan0 * a.se + 4 * i);
+      const int ch = (4 * i) / a.se, n = 4 * i - ch * a.se;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_Wr[(n + k) * LDW + ch] = v[k];
+    }
+  } else {
+    for (int i = tid; i < CH * a.se; i += NTHR) { const int ch = i / a.se, n = i - ch * a.se; s_Wr[n * LDW + ch] = ca.Wr[(size_t)chan0 * a.se + i]; }
+  }
   for (int i = tid; i < a.se * (CH / 4); i += NTHR) {
     const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4;
     *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = *reinterpret_cast<const f32x4*>(ca.We + (size_t)n * Cexp + chan0 + q4);
@@ -2546,9 +2555,12 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     const int n = tid / G, clip = tid - n * G;
     float v = 0.0f;
     if (n < a.se) {
-      const float* wr = s_Wr + n;
+      const float* wr = s_Wr + n * LDW;
       const float* mrow = s_S + (size_t)clip * CH;
-      for (int ch = 0; ch < CH; ++ch) v += mrow[ch] * wr[ch * a.se];
+      f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int ch = 0; ch < CH; ch += 4) acc4 += *reinterpret_cast<const f32x4*>(mrow + ch) * *reinterpret_cast<const f32x4*>(wr + ch);
+      v = (acc4.x + acc4.y) + (acc4.z + acc4.w);
     }
     xc1[(size_t)p * kClXc1 + tid] = v;
   }
@@ -2578,15 +2590,16 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   }
   __syncthreads();
   // ---- C2: gate of the member's channels (thread = (clip, channel)), applied to the depthwise output in place ----
-  for (int t = tid; t < G * CH; t += NTHR) {
-    const int clip = t / CH, ch = t - clip * CH;
-    float v = 0.0f;
+  for (int t = tid; t < G * (CH / 4); t += NTHR) {                  // thread = (clip, channel quad)
+    const int clip = t / (CH / 4), ch = (t - clip * (CH / 4)) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float* we = s_We + ch;
     const float* rr = s_R + clip * LDR;
-    for (int n = 0; n < a.se; ++n) v += rr[n] * we[n * CH];
-    v = sigmoidf_(v + a.be[chan0 + ch]);
-    s_S[(size_t)clip * CH + ch] = v;
-    if (a.dbg_gate && clip < gvalid) a.dbg_gate[(size_t)(b0 + clip) * Cexp + chan0 + ch] = v;
+#pragma unroll 4
+    for (int n = 0; n < a.se; ++n) v += *reinterpret_cast<const f32x4*>(we + n * CH) * rr[n];
+    v = sigmoid4_(v + *reinterpret_cast<const f32x4*>(a.be + chan0 + ch));
+    *reinterpret_cast<f32x4*>(s_S + (size_t)clip * CH + ch) = v;
+    if (a.dbg_gate && clip < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + clip) * Cexp + chan0 + ch) = v;
   }
   __syncthreads();
   {
