@@ -1643,9 +1643,13 @@ __device__ __forceinline__ void stream_mfma_runs(f32x4 (&wq)[DEPTH][NTW], WP wla
     for (int d = 0; d < DEPTH; ++d)
       if (it + d < T) compute(d, wq[d]);
   } else {
+    // short stream (fewer chunks than ring slots): request everything, then compute (one latency, not T of them)
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-      if (d < T) { load(wq[d]); compute(d, wq[d]); }
+      if (d < T) load(wq[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < T) compute(d, wq[d]);
   }
 }
 
@@ -2392,7 +2396,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
 // dispatch probed at create); every member checks the others' XCC ids and a poll limit, and a failure takes the paired kernel's
 // exit: NaN output, sticky error words, handle moved to the plain whole-block kernels by the next mkws_embed_forward.
 constexpr int kClusterP = 6, kClXc1 = 256, kClMaxTiles = 20, kClusterChMax = 192;
-constexpr int kClusterLdsFloats = 12 * 256 + 16 * (kClusterChMax + 4) + 4 * kClusterChMax + 4 * 52 + 2 * kClusterChMax + 48 * (kClusterChMax + 4) + 48 * kClusterChMax;
+constexpr int kClusterLdsFloats = 12 * 256 + 16 * (kClusterChMax + 4) + 4 * kClusterChMax + 4 * 52 + 2 * kClusterChMax + 48 * (kClusterChMax + 4) + 48 * kClusterChMax +
+                                  27 * kClusterChMax;     // + depthwise taps [25][CH] and its BN scale / shift
 struct ClusterArgs {
   BlockArgs b;
   const float* Wr;   // plain [Cexp][se]
@@ -2433,6 +2438,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   float* s_sh = s_sc + CHMAX;
   float* s_Wr = s_sh + CHMAX;                                    // the member's rows of the SE-reduce weights, TRANSPOSED: [se][CH + 4]
   float* s_We = s_Wr + 48 * (CHMAX + 4);                         // its columns of the SE-expand weights [se][CH]
+  float* s_Wd = s_We + 48 * CHMAX;                               // depthwise taps of its channels [KS*KS][CH], then BN scale [CH], shift [CH]
   __shared__ int s_bad;
   const BlockArgs& a = ca.b;
   const int cl = (blockIdx.x / (8 * P)) * 8 + (blockIdx.x & 7), p = (blockIdx.x >> 3) % P;
@@ -2482,6 +2488,11 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4;
     *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = *reinterpret_cast<const f32x4*>(ca.We + (size_t)n * Cexp + chan0 + q4);
   }
+  for (int i = tid; i < (KS * KS + 2) * (CH / 4); i += NTHR) {     // depthwise taps and BN constants of the member's channels
+    const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4;
+    const float* src = (t < KS * KS) ? a.Wd + (size_t)t * Cexp : (t == KS * KS ? a.scD : a.shD);
+    *reinterpret_cast<f32x4*>(s_Wd + (size_t)t * CH + q4) = *reinterpret_cast<const f32x4*>(src + chan0 + q4);
+  }
   __syncthreads();
   // ---- A: expand, tiles wave, wave + 4, ... of the member's KH ----
   {
@@ -2496,9 +2507,15 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
       if (c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(s_E + (size_t)c * LDE + n) = y;
     };
-    f32x4 wqa[4][1];
-    stream_mfma_runs<1, 4, 1, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
+    // 12 fragments in flight per wave: with six CUs awake the stream is latency-bound (4 in flight: ~550 cycles per 128-cycle chunk)
+    f32x4 wqa[12][1];
+    stream_mfma_runs<1, 12, 1, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
   }
+  // phase D's weight stream (K = the member's KH chunks, tiles wave, wave + 4, ...) is requested now: it lands under phases B and C
+  const WBuf d_w(a.WpP + (size_t)(p * KH) * a.NTp * 256, loff);
+  const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NW - 1) / NW : 0;
+  f32x4 wqd[4][5];
+  if (d_ntw > 0) stream_mfma_prefetch<5, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NW, a.NTp, KH);
   __syncthreads();
   // ---- B: depthwise + BN + swish in place, SE means (thread = clip x channel quad of the member's slice) ----
   {
@@ -2525,7 +2542,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
               used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
             }
           if (!used) continue;
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + chan0 + q4);
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(s_Wd + (size_t)(i * KS + jx) * CH + q4);
 #pragma unroll
           for (int oh = 0; oh < HoT; ++oh)
 #pragma unroll
@@ -2535,7 +2552,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
             }
         }
       }
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + chan0 + q4), sh = *reinterpret_cast<const f32x4*>(a.shD + chan0 + q4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(s_Wd + (size_t)(KS * KS) * CH + q4), sh = *reinterpret_cast<const f32x4*>(s_Wd + (size_t)(KS * KS + 1) * CH + q4);
       f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < HoWo; ++o) {
@@ -2620,15 +2637,13 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     const float* erow = s_E + (size_t)(clip * HW + (r - clip * HoWo)) * LDE + 4 * g;
     auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(erow + 16 * j); };
     auto xmake = [](const f32x4& v) { return v; };
-    const WBuf d_w(a.WpP + (size_t)(p * KH) * a.NTp * 256, loff);
     const size_t cstride = (size_t)a.NTp * 256;
-    const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NW - 1) / NW : 0;      // this wave's tiles wave, wave + 4, ...: one pass over K for all of them
-    auto run = [&](auto ntw_tag) {
+    auto run = [&](auto ntw_tag) {                                  // this wave's tiles wave, wave + 4, ...: one pass over K for all of them
       constexpr int NTW = decltype(ntw_tag)::value;
-      f32x4 acc[NTW][1], wqd[4][NTW];
+      f32x4 acc[NTW][1];
 #pragma unroll
       for (int q = 0; q < NTW; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      stream_mfma<NTW, 4, 1, false>(acc, wqd, d_w, cstride, wave, NW, a.NTp, KH, xload, xmake);
+      stream_mfma<NTW, 4, 1, true>(acc, wqd, d_w, cstride, wave, NW, a.NTp, KH, xload, xmake);
 #pragma unroll
       for (int q = 0; q < NTW; ++q) {
         const int t = wave + NW * q;
