@@ -2465,51 +2465,94 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     gen0 = __hip_atomic_load(frow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     gen1 = __hip_atomic_load(frow + 8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   }
-  // ---- stage the input tile as fragments, the member's expand BN constants ----
-  for (int j = wave; j < a.KCe; j += NW) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (c < rows_in && 16 * j + 4 * g < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
-    *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = v;
-  }
-  for (int i = tid; i < CH; i += NTHR) { s_sc[i] = a.scE[chan0 + i]; s_sh[i] = a.shE[chan0 + i]; }
-  // the SE weights of the member's channels go to LDS now (coalesced; consumed three phases later)
+#ifdef MKWS_FRONT_TIMING
+  const long long dbg_c0 = clock64();
+  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
+#define MKWS_CL_STAMP(k) if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();
+#else
+#define MKWS_CL_STAMP(k)
+#endif
+  // ---- stage: input tile as fragments, expand BN constants, SE weights and depthwise taps of the member's channels.
+  //      Every global load of the phase is issued before the first LDS store (fixed trip counts, predicated): a load -> store loop
+  //      pays one memory latency per iteration (9 iterations = 9 us measured); this way the ~100 KB arrive in one ----
   const int LDW = CH + 4;
-  if ((a.se & 3) == 0) {                                            // [CH][se] rows chan0.. are contiguous in global memory; float4 = 4 units of one channel
-    for (int i = tid; i < CH * a.se / 4; i += NTHR) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ca.Wr + (size_t)chan0 * a.se + 4 * i);
-      const int ch = (4 * i) / a.se, n = 4 * i - ch * a.se;
+  {
+    constexpr int NX = 3, NR = 9, NE = 9, ND = 6;                 // float4 per thread: X (12 chunks / 4 waves), Wr, We (48 * 192 / 4 / 256), taps (27 * 48 / 256)
+    f32x4 rx[NX], rr[NR], re[NE], rd[ND];
+    const int nWr = (a.se & 3) == 0 ? CH * a.se / 4 : 0, nWe = a.se * (CH / 4), nWd = (KS * KS + 2) * (CH / 4);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s_Wr[(n + k) * LDW + ch] = v[k];
+    for (int k = 0; k < NX; ++k) {
+      const int j = wave + NW * k;
+      rx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (j < a.KCe && c < rows_in && 16 * j + 4 * g < a.Cin) rx[k] = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
     }
-  } else {
-    for (int i = tid; i < CH * a.se; i += NTHR) { const int ch = i / a.se, n = i - ch * a.se; s_Wr[n * LDW + ch] = ca.Wr[(size_t)chan0 * a.se + i]; }
-  }
-  for (int i = tid; i < a.se * (CH / 4); i += NTHR) {
-    const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4;
-    *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = *reinterpret_cast<const f32x4*>(ca.We + (size_t)n * Cexp + chan0 + q4);
-  }
-  for (int i = tid; i < (KS * KS + 2) * (CH / 4); i += NTHR) {     // depthwise taps and BN constants of the member's channels
-    const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4;
-    const float* src = (t < KS * KS) ? a.Wd + (size_t)t * Cexp : (t == KS * KS ? a.scD : a.shD);
-    *reinterpret_cast<f32x4*>(s_Wd + (size_t)t * CH + q4) = *reinterpret_cast<const f32x4*>(src + chan0 + q4);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { const int i = tid + NTHR * k; if (i < nWr) rr[k] = *reinterpret_cast<const f32x4*>(ca.Wr + (size_t)chan0 * a.se + 4 * i); }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = tid + NTHR * k;
+      if (i < nWe) { const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4; re[k] = *reinterpret_cast<const f32x4*>(ca.We + (size_t)n * Cexp + chan0 + q4); }
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const int i = tid + NTHR * k;
+      if (i < nWd) {
+        const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4;
+        const float* src = (t < KS * KS) ? a.Wd + (size_t)t * Cexp : (t == KS * KS ? a.scD : a.shD);
+        rd[k] = *reinterpret_cast<const f32x4*>(src + chan0 + q4);
+      }
+    }
+    for (int i = tid; i < CH; i += NTHR) { s_sc[i] = a.scE[chan0 + i]; s_sh[i] = a.shE[chan0 + i]; }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) { const int j = wave + NW * k; if (j < a.KCe) *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = rx[k]; }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {                                  // Wr [CH][se] -> transposed [se][CH + 4]; float4 = 4 units of one channel (se % 4 == 0)
+      const int i = tid + NTHR * k;
+      if (i < nWr) {
+        const int ch = (4 * i) / a.se, n = 4 * i - ch * a.se;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_Wr[(n + q) * LDW + ch] = rr[k][q];
+      }
+    }
+    if ((a.se & 3) != 0)
+      for (int i = tid; i < CH * a.se; i += NTHR) { const int ch = i / a.se, n = i - ch * a.se; s_Wr[n * LDW + ch] = ca.Wr[(size_t)chan0 * a.se + i]; }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = tid + NTHR * k;
+      if (i < nWe) { const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = re[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const int i = tid + NTHR * k;
+      if (i < nWd) { const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_Wd + (size_t)t * CH + q4) = rd[k]; }
+    }
   }
   __syncthreads();
-  // ---- A: expand, tiles wave, wave + 4, ... of the member's KH ----
+  MKWS_CL_STAMP(1)
+  // ---- A: expand: runs of NTWA tiles (independent accumulators: one accumulator per wave would wait out the MFMA's dependent
+  //      latency on every k step) dealt over the four waves ----
   {
-    const int nruns = (KH > wave) ? (KH - wave + NW - 1) / NW : 0;
-    auto tile_of = [&](int r) { return p * KH + wave + NW * r; };
+    constexpr int NTWA = (HW == 4) ? 3 : 2;                       // KH = 12 (2x2 images) / 5 or 7 (4x3): at most one run per wave
+    const int ngroups = (KH + NTWA - 1) / NTWA;
+    const int nruns = (ngroups > wave) ? (ngroups - wave + NW - 1) / NW : 0;
+    auto tile_of = [&](int r) { return p * KH + (wave + NW * r) * NTWA; };
     auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)j * 64 + lane) * 4); };
     auto xmake = [](const f32x4& v) { return v; };
-    auto epi = [&](int t0, const f32x4 (&acc)[1][1]) {
-      const int n = (t0 - p * KH) * 16 + 4 * g;                   // column inside the member's slice
-      f32x4 y = acc[0][0] * *reinterpret_cast<const f32x4*>(s_sc + n) + *reinterpret_cast<const f32x4*>(s_sh + n);
-      y = swish4_(y);
-      if (c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(s_E + (size_t)c * LDE + n) = y;
+    auto epi = [&](int t0, const f32x4 (&acc)[NTWA][1]) {
+#pragma unroll
+      for (int q = 0; q < NTWA; ++q) {
+        const int tl = t0 + q - p * KH;                           // tile inside the member's slice (a run's tail may reach past it)
+        if (tl < KH) {
+          const int n = tl * 16 + 4 * g;
+          f32x4 y = acc[q][0] * *reinterpret_cast<const f32x4*>(s_sc + n) + *reinterpret_cast<const f32x4*>(s_sh + n);
+          y = swish4_(y);
+          if (c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(s_E + (size_t)c * LDE + n) = y;
+        }
+      }
     };
-    // 12 fragments in flight per wave: with six CUs awake the stream is latency-bound (4 in flight: ~550 cycles per 128-cycle chunk)
-    f32x4 wqa[12][1];
-    stream_mfma_runs<1, 12, 1, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
+    f32x4 wqa[6][NTWA];                                            // 6 chunks x NTWA fragments in flight per wave
+    stream_mfma_runs<NTWA, 6, 1, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
   }
   // phase D's weight stream (K = the member's KH chunks, tiles wave, wave + 4, ...) is requested now: it lands under phases B and C
   const WBuf d_w(a.WpP + (size_t)(p * KH) * a.NTp * 256, loff);
@@ -2517,6 +2560,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   f32x4 wqd[4][5];
   if (d_ntw > 0) stream_mfma_prefetch<5, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NW, a.NTp, KH);
   __syncthreads();
+  MKWS_CL_STAMP(2)
   // ---- B: depthwise + BN + swish in place, SE means (thread = clip x channel quad of the member's slice) ----
   {
     const int Q = CH / 4;
@@ -2567,6 +2611,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     }
   }
   __syncthreads();
+  MKWS_CL_STAMP(3)
   // ---- C1: partial r[unit n][clip] over the member's channels (thread = (n, clip), a.se <= 48), published for exchange 1 ----
   if (tid < 48 * G) {
     const int n = tid / G, clip = tid - n * G;
@@ -2606,6 +2651,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
       }
   }
   __syncthreads();
+  MKWS_CL_STAMP(4)
   // ---- C2: gate of the member's channels (thread = (clip, channel)), applied to the depthwise output in place ----
   for (int t = tid; t < G * (CH / 4); t += NTHR) {                  // thread = (clip, channel quad)
     const int clip = t / (CH / 4), ch = (t - clip * (CH / 4)) * 4;
@@ -2629,6 +2675,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     }
   }
   __syncthreads();
+  MKWS_CL_STAMP(5)
   // ---- D: partial projection over the member's K (KH chunks), every output tile; tiles wave, wave + 4, ... (at most 5 per wave) ----
   {
     int r = c;
@@ -2678,6 +2725,11 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
       }
     }
   }
+#ifdef MKWS_FRONT_TIMING
+  __syncthreads();
+  if (threadIdx.x == 0) { a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64(); a.dbg_t[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - dbg_c0); }
+#endif
+#undef MKWS_CL_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3325,7 +3377,9 @@ int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, const m
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
 #ifdef MKWS_FRONT_TIMING
-  a.dbg_t = nullptr;
+  unsigned long long* d_bt = block_timing_buffer();
+  (void)hipMemsetAsync(d_bt, 0, sizeof(unsigned long long) * 8 * 4096, s);
+  a.dbg_t = d_bt;
 #endif
   ca.Wr = b.se.Wr; ca.We = b.se.We;
   ca.xc1 = em->cl_xc1; ca.xd = em->cl_xd; ca.flags = em->cl_flags;
@@ -3347,6 +3401,23 @@ int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, const m
     else MKWS_CLUSTER(3, 1, 2, 2);
   }
 #undef MKWS_CLUSTER
+#ifdef MKWS_FRONT_TIMING
+  {   // members of live clusters only (padding workgroups leave before the first stamp)
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)grid.x * 8);
+    (void)hipMemcpy(h.data(), d_bt, h.size() * 8, hipMemcpyDeviceToHost);
+    double ph[6] = {0, 0, 0, 0, 0, 0}; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t i = 0; i < grid.x; ++i) {
+      if (h[8 * i + 6] == 0) continue;
+      for (int k = 0; k < 6; ++k) ph[k] += (double)(h[8 * i + k + 1] - h[8 * i + k]);
+      if (h[8 * i] < t0) t0 = h[8 * i];
+      if (h[8 * i + 6] > t1) t1 = h[8 * i + 6];
+      ++n;
+    }
+    if (n) fprintf(stderr, "[cluster-timing] %s members %d: stage %.2f  A %.2f  B %.2f  C1+x1 %.2f  C2 %.2f  D+x2 %.2f us; span %.2f us\n", stage, n, ph[0] / n / 100.0, ph[1] / n / 100.0,
+                   ph[2] / n / 100.0, ph[3] / n / 100.0, ph[4] / n / 100.0, ph[5] / n / 100.0, (double)(t1 - t0) / 100.0);
+  }
+#endif
   return MKWS_OK;
 }
 
