@@ -1012,10 +1012,13 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
     for (int d = 0; d < DEPTH; ++d)
       if (j + d < KC) compute(d, j + d, wq[d]);
   } else {
-    // short stream (KC < DEPTH): chunk j uses ring slot j, so the fragment buffers still alternate
+    // short stream (KC < DEPTH): chunk j uses ring slot j, so the fragment buffers still alternate; all requests first (one latency)
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-      if (d < KC) { load(d, wq[d]); compute(d, d, wq[d]); }
+      if (d < KC) load(d, wq[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < KC) compute(d, d, wq[d]);
   }
   if (SPLIT) acc[0][0] += acc_odd;
 }
@@ -2382,20 +2385,20 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
 // ------------------------------------------------------------------------------------------------
 // Cluster kernel for the tiny-image blocks of SMALL-batch handles (live serving: one window at a time).  At batch 1 a whole-block
 // kernel is one workgroup streaming the block's 0.75-2.2 MB of weights through ONE CU (~41 GB/s): 24-36 us per block, 11 blocks = 313
-// of the 489 us a window costs (tools/latency_profile.py).  Here P = 6 workgroups on 6 CUs of one XCD share ONE 16-row tile (one clip
-// of a 4x3 image, four clips of a 2x2 image) and split the block's expanded CHANNELS six ways (480, 672 and 1152 are all multiples of
-// 6 x 16): every CU streams a sixth of the weights and the phases shrink to their latencies.
-//   A   expand: the member's KH = Cexp/96 n-tiles                B   depthwise + SE means on its channels (local: depthwise is per channel)
-//   C1  partial r over its channels -> exchange 1: all six partial r vectors are added in member order by everyone
+// of the 489 us a window costs (tools/latency_profile.py).  Here P workgroups on P CUs of one XCD share ONE 16-row tile (one clip of a
+// 4x3 image, four clips of a 2x2 image) and split the block's expanded CHANNELS P ways -- P = 10 / 14 / 12 for Cexp = 480 / 672 / 1152,
+// three or six 16-channel tiles per member: every CU pulls a tenth of the weights and the phases shrink towards their latencies.
+//   A   expand: the member's KH = Cexp/(16 P) n-tiles            B   depthwise + SE means on its channels (local: depthwise is per channel)
+//   C1  partial r over its channels -> exchange 1: all P partial r vectors are added in member order by everyone
 //   C2  gate for its channels, applied in place                   D   partial projection over its K slice, ALL output tiles
-//   exchange 2: output tile t is finished by member t % 6 (the six partials added in member order, BN, residual)
+//   exchange 2: output tile t is finished by member t % P (the P partials added in member order, BN, residual)
 // Exchanges are the paired kernel's (plain stores, s_waitcnt vmcnt(0), barrier, relaxed agent-scope flag, L1-bypassing loads) with
-// GENERATION flags instead of consumer resets (six readers per flag): a member reads its own flag g0 when it starts, publishes g0 + 1
-// and waits for the other five to show g0 + 1 -- all six took part in the same launches, so they agree on g0; nothing to reset, and a
+// GENERATION flags instead of consumer resets (P - 1 readers per flag): a member reads its own flag g0 when it starts, publishes g0 + 1
+// and waits for the others to show g0 + 1 -- all members took part in the same launches, so they agree on g0; nothing to reset, and a
 // captured graph replays it.  Members of a cluster have linear workgroup ids that are congruent mod 8 (same XCD under the round-robin
 // dispatch probed at create); every member checks the others' XCC ids and a poll limit, and a failure takes the paired kernel's
 // exit: NaN output, sticky error words, handle moved to the plain whole-block kernels by the next mkws_embed_forward.
-constexpr int kClusterP = 6, kClXc1 = 256, kClMaxTiles = 20, kClusterChMax = 192;
+constexpr int kClusterPMax = 14, kClXc1 = 256, kClMaxTiles = 20, kClusterChMax = 192, kClFlagRow = 16;
 constexpr int kClusterLdsFloats = 12 * 256 + 16 * (kClusterChMax + 4) + 4 * kClusterChMax + 4 * 52 + 2 * kClusterChMax + 48 * (kClusterChMax + 4) + 48 * kClusterChMax +
                                   27 * kClusterChMax;     // + depthwise taps [25][CH] and its BN scale / shift
 struct ClusterArgs {
@@ -2404,14 +2407,15 @@ struct ClusterArgs {
   const float* We;   // plain [se][Cexp]
   float* xc1;        // [clusters][P][kClXc1]: 48 units x up to 4 clips of partial r; [255] = the member's XCC id
   float* xd;         // [clusters][P][kClMaxTiles][256]: partial projection tiles, lane-linear
-  int* flags;        // [clusters][2 exchanges][8] generations (8-int rows: one 32 B line per exchange)
+  int* flags;        // [clusters][2 exchanges][kClFlagRow] generations
   int* err_dev; int* err_host; int fault;
+  int P;             // members per cluster: 10 (Cexp 480), 14 (672), 12 (1152) -- Cexp / (16 P) whole tiles per member
 };
 
 // thread 0: publish generation `gen` in `mine`, wait until the other members show it too.  0 = ok, 1 = timed out.
-__device__ __forceinline__ int cluster_signal_wait(int* row, int p, int gen) {
+__device__ __forceinline__ int cluster_signal_wait(int* row, int p, int P, int gen) {
   __hip_atomic_store(row + p, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int q = 0; q < kClusterP; ++q) {
+  for (int q = 0; q < P; ++q) {
     if (q == p) continue;
     int spins = 0;
     while (__hip_atomic_load(row + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
@@ -2424,8 +2428,9 @@ __device__ __forceinline__ int cluster_signal_wait(int* row, int p, int gen) {
 
 template <int KS, int S, int HT, int WT>
 __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
-  constexpr int P = kClusterP, NTHR = 256, NW = 4;
+  constexpr int NTHR = 256, NW = 4;
   constexpr int HW = HT * WT, G = 16 / HW;                       // clips per cluster: 1 (4x3) or 4 (2x2)
+  const int P = ca.P;
   constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1), HoWo = HoT * WoT;
   constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
   constexpr int CHMAX = kClusterChMax, LDEMAX = CHMAX + 4, LDR = 52;
@@ -2455,15 +2460,15 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 0xf;
-  int* frow = ca.flags + (size_t)cl * 16;                         // [2][8]
-  float* xc1 = ca.xc1 + (size_t)cl * P * kClXc1;
-  float* xd = ca.xd + (size_t)cl * P * kClMaxTiles * 256;
+  int* frow = ca.flags + (size_t)cl * 2 * kClFlagRow;             // [2][kClFlagRow]
+  float* xc1 = ca.xc1 + (size_t)cl * kClusterPMax * kClXc1;
+  float* xd = ca.xd + (size_t)cl * kClusterPMax * kClMaxTiles * 256;
   if (ca.fault == 2 && p == 1) return;                           // test hook: a member never arrives
   int gen0 = 0, gen1 = 0;
   if (tid == 0) {
     s_bad = __hip_atomic_load(ca.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky: an earlier launch failed
     gen0 = __hip_atomic_load(frow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    gen1 = __hip_atomic_load(frow + 8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    gen1 = __hip_atomic_load(frow + kClFlagRow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   }
 #ifdef MKWS_FRONT_TIMING
   const long long dbg_c0 = clock64();
@@ -2532,7 +2537,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   // ---- A: expand: runs of NTWA tiles (independent accumulators: one accumulator per wave would wait out the MFMA's dependent
   //      latency on every k step) dealt over the four waves ----
   {
-    constexpr int NTWA = (HW == 4) ? 3 : 2;                       // KH = 12 (2x2 images) / 5 or 7 (4x3): at most one run per wave
+    constexpr int NTWA = (HW == 4) ? 2 : 1;                       // KH = 6 tiles per member (2x2 images, 12 members) / 3 (4x3, 10 or 14): one run per wave
     const int ngroups = (KH + NTWA - 1) / NTWA;
     const int nruns = (ngroups > wave) ? (ngroups - wave + NW - 1) / NW : 0;
     auto tile_of = [&](int r) { return p * KH + (wave + NW * r) * NTWA; };
@@ -2631,7 +2636,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0 && s_bad == 0) {
-    if (cluster_signal_wait(frow, p, gen0)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
+    if (cluster_signal_wait(frow, p, P, gen0)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
   }
   __syncthreads();
   if (tid < 48 * G) {
@@ -2706,7 +2711,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0 && s_bad == 0) {
-    if (cluster_signal_wait(frow + 8, p, gen1)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
+    if (cluster_signal_wait(frow + kClFlagRow, p, P, gen1)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
   }
   __syncthreads();
   // ---- exchange 2: member t % P finishes output tile t (partials of all members in member order) ----
@@ -3356,9 +3361,16 @@ int launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const Pair
 // Cluster kernel (mbconv_cluster_kernel): tiny-image blocks of small-batch handles.
 constexpr int kClusterMaxBatch = 32;                 // handles up to this size plan the cluster kernel (tools/plan_sweep.py)
 static int cluster_count(int B, int clips_per_cluster) { return (((B + clips_per_cluster - 1) / clips_per_cluster) + 7) / 8 * 8; }   // whole groups of 8 clusters
+// Members per cluster: as many as leave every member whole 16-channel tiles (3 to 6 of them) -- the members pull their weights from
+// the Infinity Cache / HBM at a latency-bound ~13 GB/s per CU (measured: 100 KB in 7.5 us), so the split is what shortens the phases.
+static int cluster_members(int ce) {
+  for (int P = kClusterPMax; P >= 2; --P)
+    if (ce % (16 * P) == 0 && ce / P >= 48 && ce / P <= kClusterChMax) return P;
+  return 0;
+}
 bool cluster_supported(const BlockPlan& b) {
   const int ks = b.spec.kernel, st = b.spec.stride;
-  if (!b.has_expand || b.ce % (16 * kClusterP) != 0 || b.ce / kClusterP > kClusterChMax || b.expand.KC > 12) return false;
+  if (!b.has_expand || cluster_members(b.ce) == 0 || b.expand.KC > 12) return false;
   if (b.project.NTtot > kClMaxTiles || b.se.se > 48 || b.spec.out_ch % 16 != 0) return false;
   if (b.H == 4 && b.W == 3) return (ks == 3 && st == 1) || (ks == 5 && st == 1) || (ks == 5 && st == 2);
   if (b.H == 2 && b.W == 2) return (ks == 5 && st == 1) || (ks == 3 && st == 1);
@@ -3384,8 +3396,9 @@ int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, const m
   ca.Wr = b.se.Wr; ca.We = b.se.We;
   ca.xc1 = em->cl_xc1; ca.xd = em->cl_xd; ca.flags = em->cl_flags;
   ca.err_dev = em->pair_err_dev; ca.err_host = em->pair_err_host; ca.fault = em->pair_fault;
+  ca.P = cluster_members(b.ce);
   const int G = 16 / (b.H * b.W);
-  const dim3 grid(cluster_count(B, G) * kClusterP);
+  const dim3 grid(cluster_count(B, G) * ca.P);
   const size_t lds = (size_t)kClusterLdsFloats * sizeof(float);
   const int ks = b.spec.kernel, st = b.spec.stride;
   ProfScope ps(stage, std::string("mbconv_cluster_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
@@ -3849,7 +3862,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   const size_t pair_floats = pair_ws_floats(max_batch, em->pair_mt);
   // cluster exchange buffers exist for handles that may ever use the kernel (the option can be set after create up to 64 clips)
   const size_t ncl = (max_batch <= 64) ? (size_t)cluster_count(max_batch, 1) : 0;
-  const size_t cluster_floats = ncl * ((size_t)kClusterP * kClXc1 + (size_t)kClusterP * kClMaxTiles * 256 + 16);
+  const size_t cluster_floats = ncl * ((size_t)kClusterPMax * kClXc1 + (size_t)kClusterPMax * kClMaxTiles * 256 + 2 * kClFlagRow);
   const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4 + cluster_floats;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
@@ -3873,11 +3886,11 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     }
     *em->pair_err_host = 0;
     if (ncl > 0) {
-      em->cl_xc1 = w; w += ncl * kClusterP * kClXc1;
-      em->cl_xd = w; w += ncl * kClusterP * kClMaxTiles * 256;
-      em->cl_flags = reinterpret_cast<int*>(w); w += ncl * 16;
-      em->cl_flag_count = ncl * 16;
-      if (hipMemset(em->cl_flags, 0, ncl * 16 * sizeof(int)) != hipSuccess) {
+      em->cl_xc1 = w; w += ncl * kClusterPMax * kClXc1;
+      em->cl_xd = w; w += ncl * kClusterPMax * kClMaxTiles * 256;
+      em->cl_flags = reinterpret_cast<int*>(w); w += ncl * 2 * kClFlagRow;
+      em->cl_flag_count = ncl * 2 * kClFlagRow;
+      if (hipMemset(em->cl_flags, 0, ncl * 2 * kClFlagRow * sizeof(int)) != hipSuccess) {
         (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); (void)hipHostFree(em->pair_err_host); delete em; return fail(MKWS_ERR_HIP, "clearing the cluster flags failed");
       }
     }
