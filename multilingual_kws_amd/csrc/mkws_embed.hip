@@ -3377,7 +3377,7 @@ bool cluster_supported(const BlockPlan& b) {
   return false;
 }
 
-int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, const mkws_embed* em, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, int block_index, const mkws_embed* em, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
   ClusterArgs ca;
   BlockArgs& a = ca.b;
   a.X = X; a.Cin = b.spec.in_ch;
@@ -3394,7 +3394,8 @@ int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, const m
   a.dbg_t = d_bt;
 #endif
   ca.Wr = b.se.Wr; ca.We = b.se.We;
-  ca.xc1 = em->cl_xc1; ca.xd = em->cl_xd; ca.flags = em->cl_flags;
+  // generation flags are PER BLOCK: a member's generation counts the launches it took part in, and blocks differ in their member count
+  ca.xc1 = em->cl_xc1; ca.xd = em->cl_xd; ca.flags = em->cl_flags + (size_t)block_index * (em->cl_flag_count / kNumBlocks);
   ca.err_dev = em->pair_err_dev; ca.err_host = em->pair_err_host; ca.fault = em->pair_fault;
   ca.P = cluster_members(b.ce);
   const int G = 16 / (b.H * b.W);
@@ -3635,7 +3636,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
       if (em->fuse_cluster && cluster_supported(b) && em->cl_flags) {
-        if (int rc = launch_cluster(s, p.c_str(), b, em, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
+        if (int rc = launch_cluster(s, p.c_str(), b, i, em, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
       } else if (em->fuse_pair && pair_supported(b)) {
         PairWs pw; pw.xc1 = em->pair_xc1; pw.xd = em->pair_xd; pw.flags = em->pair_flags; pw.mt = em->pair_mt;
         pw.err_dev = em->pair_err_dev; pw.err_host = em->pair_err_host; pw.fault = em->pair_fault;
@@ -3862,7 +3863,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   const size_t pair_floats = pair_ws_floats(max_batch, em->pair_mt);
   // cluster exchange buffers exist for handles that may ever use the kernel (the option can be set after create up to 64 clips)
   const size_t ncl = (max_batch <= 64) ? (size_t)cluster_count(max_batch, 1) : 0;
-  const size_t cluster_floats = ncl * ((size_t)kClusterPMax * kClXc1 + (size_t)kClusterPMax * kClMaxTiles * 256 + 2 * kClFlagRow);
+  const size_t cluster_floats = ncl * ((size_t)kClusterPMax * kClXc1 + (size_t)kClusterPMax * kClMaxTiles * 256 + (size_t)kNumBlocks * 2 * kClFlagRow);
   const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4 + cluster_floats;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
@@ -3888,9 +3889,9 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     if (ncl > 0) {
       em->cl_xc1 = w; w += ncl * kClusterPMax * kClXc1;
       em->cl_xd = w; w += ncl * kClusterPMax * kClMaxTiles * 256;
-      em->cl_flags = reinterpret_cast<int*>(w); w += ncl * 2 * kClFlagRow;
-      em->cl_flag_count = ncl * 2 * kClFlagRow;
-      if (hipMemset(em->cl_flags, 0, ncl * 2 * kClFlagRow * sizeof(int)) != hipSuccess) {
+      em->cl_flags = reinterpret_cast<int*>(w); w += ncl * 2 * kClFlagRow * kNumBlocks;
+      em->cl_flag_count = ncl * 2 * kClFlagRow * kNumBlocks;
+      if (hipMemset(em->cl_flags, 0, em->cl_flag_count * sizeof(int)) != hipSuccess) {
         (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); (void)hipHostFree(em->pair_err_host); delete em; return fail(MKWS_ERR_HIP, "clearing the cluster flags failed");
       }
     }
