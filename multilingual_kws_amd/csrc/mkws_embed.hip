@@ -2412,18 +2412,18 @@ struct ClusterArgs {
   int P;             // members per cluster: 10 (Cexp 480), 14 (672), 12 (1152) -- Cexp / (16 P) whole tiles per member
 };
 
-// thread 0: publish generation `gen` in `mine`, wait until the other members show it too.  0 = ok, 1 = timed out.
+// Wave 0 (all 64 lanes): lane p publishes generation `gen`, lanes q < P poll one member's flag each IN PARALLEL (one poll is an L2
+// round trip of ~0.5 us: thirteen of them one after the other cost more than the phases they separate).  0 = ok, 1 = timed out.
 __device__ __forceinline__ int cluster_signal_wait(int* row, int p, int P, int gen) {
-  __hip_atomic_store(row + p, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int q = 0; q < P; ++q) {
-    if (q == p) continue;
-    int spins = 0;
-    while (__hip_atomic_load(row + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 21)) return 1;
-    }
+  const int lane = threadIdx.x & 63;
+  if (lane == p) __hip_atomic_store(row + p, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while (true) {
+    const int v = (lane < P && lane != p) ? __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gen;
+    if (__builtin_amdgcn_ballot_w64(v != gen) == 0) return 0;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 21)) return 1;
   }
-  return 0;
 }
 
 template <int KS, int S, int HT, int WT>
@@ -2464,12 +2464,10 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   float* xc1 = ca.xc1 + (size_t)cl * kClusterPMax * kClXc1;
   float* xd = ca.xd + (size_t)cl * kClusterPMax * kClMaxTiles * 256;
   if (ca.fault == 2 && p == 1) return;                           // test hook: a member never arrives
-  int gen0 = 0, gen1 = 0;
-  if (tid == 0) {
-    s_bad = __hip_atomic_load(ca.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky: an earlier launch failed
-    gen0 = __hip_atomic_load(frow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    gen1 = __hip_atomic_load(frow + kClFlagRow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-  }
+  if (tid == 0) s_bad = __hip_atomic_load(ca.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky: an earlier launch failed
+  // this launch's generations = the member's own last ones + 1 (uniform scalar loads; used by wave 0 at the exchanges)
+  const int gen0 = __hip_atomic_load(frow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int gen1 = __hip_atomic_load(frow + kClFlagRow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
 #ifdef MKWS_FRONT_TIMING
   const long long dbg_c0 = clock64();
   if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
@@ -2635,25 +2633,27 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0 && s_bad == 0) {
-    if (cluster_signal_wait(frow, p, P, gen0)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
+  if (wave == 0 && s_bad == 0) {
+    const int to = cluster_signal_wait(frow, p, P, gen0);
+    if (to && lane == 0) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
   }
   __syncthreads();
   if (tid < 48 * G) {
     const int n = tid / G, clip = tid - n * G;
     float v = 0.0f;
     if (n < a.se) {
-      for (int q = 0; q < P; ++q) v += __hip_atomic_load(xc1 + (size_t)q * kClXc1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float part[kClusterPMax];                                     // all members' partials requested together, added in member order
+#pragma unroll
+      for (int q = 0; q < kClusterPMax; ++q) part[q] = (q < P) ? __hip_atomic_load(xc1 + (size_t)q * kClXc1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+#pragma unroll
+      for (int q = 0; q < kClusterPMax; ++q) v += part[q];
       v = swishf_(v + br_pre);
     }
     s_R[clip * LDR + n] = v;
   }
-  if (tid == 0 && s_bad == 0) {
-    for (int q = 0; q < P; ++q)
-      if ((unsigned)__hip_atomic_load(xc1 + (size_t)q * kClXc1 + 255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc) {
-        s_bad = 1;
-        pair_report(ca.err_dev, ca.err_host, kPairErrXcc);
-      }
+  if (wave == 3 && s_bad == 0) {                                     // lane q checks member q's XCC id
+    const unsigned theirs = (lane < P) ? (unsigned)__hip_atomic_load(xc1 + (size_t)lane * kClXc1 + 255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xcc;
+    if (__builtin_amdgcn_ballot_w64(theirs != xcc) != 0 && lane == 0) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrXcc); }
   }
   __syncthreads();
   MKWS_CL_STAMP(4)
@@ -2710,8 +2710,9 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0 && s_bad == 0) {
-    if (cluster_signal_wait(frow + kClFlagRow, p, P, gen1)) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
+  if (wave == 0 && s_bad == 0) {
+    const int to = cluster_signal_wait(frow + kClFlagRow, p, P, gen1);
+    if (to && lane == 0) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
   }
   __syncthreads();
   // ---- exchange 2: member t % P finishes output tile t (partials of all members in member order) ----
@@ -2719,8 +2720,11 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     const bool bad = s_bad != 0;
     for (int k = wave; p + P * k < a.NTp; k += NW) {
       const int t = p + P * k;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < P; ++q) v += ld_agent_x4(xd + ((size_t)(q * kClMaxTiles + t) * 64 + lane) * 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, part[kClusterPMax];
+#pragma unroll
+      for (int q = 0; q < kClusterPMax; ++q) part[q] = (q < P) ? ld_agent_x4(xd + ((size_t)(q * kClMaxTiles + t) * 64 + lane) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < kClusterPMax; ++q) v += part[q];
       const int n = t * 16 + 4 * g;
       if (c < rows_out) {
         f32x4 y = v * *reinterpret_cast<const f32x4*>(a.scP + n) + *reinterpret_cast<const f32x4*>(a.shP + n);
