@@ -2475,20 +2475,24 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
 #else
 #define MKWS_CL_STAMP(k)
 #endif
-  // ---- stage: input tile as fragments, expand BN constants, SE weights and depthwise taps of the member's channels.
-  //      Every global load of the phase is issued before the first LDS store (fixed trip counts, predicated): a load -> store loop
-  //      pays one memory latency per iteration (9 iterations = 9 us measured); this way the ~100 KB arrive in one ----
+  // ---- stage: input tile as fragments + expand BN constants (phase A needs them) -> LDS now; the SE weights and depthwise taps of
+  //      the member's channels (phases B / C) are REQUESTED now and stored to LDS after phase A: they travel while the expand runs.
+  //      Every global load is issued before the first LDS store (fixed trip counts, predicated): a load -> store loop pays one
+  //      memory latency per iteration (9 iterations = 9 us measured) ----
   const int LDW = CH + 4;
+  constexpr int NX = 3, NR = 9, NE = 9, ND = 6;                   // float4 per thread: X (12 chunks / 4 waves), Wr, We (48 * 192 / 4 / 256), taps (27 * 48 / 256)
+  f32x4 rr[NR], re[NE], rd[ND];
+  const int nWr = (a.se & 3) == 0 ? CH * a.se / 4 : 0, nWe = a.se * (CH / 4), nWd = (KS * KS + 2) * (CH / 4);
   {
-    constexpr int NX = 3, NR = 9, NE = 9, ND = 6;                 // float4 per thread: X (12 chunks / 4 waves), Wr, We (48 * 192 / 4 / 256), taps (27 * 48 / 256)
-    f32x4 rx[NX], rr[NR], re[NE], rd[ND];
-    const int nWr = (a.se & 3) == 0 ? CH * a.se / 4 : 0, nWe = a.se * (CH / 4), nWd = (KS * KS + 2) * (CH / 4);
+    f32x4 rx[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int j = wave + NW * k;
       rx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (j < a.KCe && c < rows_in && 16 * j + 4 * g < a.Cin) rx[k] = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
     }
+    float sce = 0.0f, she = 0.0f;
+    if (tid < CH) { sce = a.scE[chan0 + tid]; she = a.shE[chan0 + tid]; }       // CH <= 192 < NTHR
 #pragma unroll
     for (int k = 0; k < NR; ++k) { const int i = tid + NTHR * k; if (i < nWr) rr[k] = *reinterpret_cast<const f32x4*>(ca.Wr + (size_t)chan0 * a.se + 4 * i); }
 #pragma unroll
@@ -2505,30 +2509,9 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
         rd[k] = *reinterpret_cast<const f32x4*>(src + chan0 + q4);
       }
     }
-    for (int i = tid; i < CH; i += NTHR) { s_sc[i] = a.scE[chan0 + i]; s_sh[i] = a.shE[chan0 + i]; }
+    if (tid < CH) { s_sc[tid] = sce; s_sh[tid] = she; }
 #pragma unroll
     for (int k = 0; k < NX; ++k) { const int j = wave + NW * k; if (j < a.KCe) *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = rx[k]; }
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {                                  // Wr [CH][se] -> transposed [se][CH + 4]; float4 = 4 units of one channel (se % 4 == 0)
-      const int i = tid + NTHR * k;
-      if (i < nWr) {
-        const int ch = (4 * i) / a.se, n = 4 * i - ch * a.se;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s_Wr[(n + q) * LDW + ch] = rr[k][q];
-      }
-    }
-    if ((a.se & 3) != 0)
-      for (int i = tid; i < CH * a.se; i += NTHR) { const int ch = i / a.se, n = i - ch * a.se; s_Wr[n * LDW + ch] = ca.Wr[(size_t)chan0 * a.se + i]; }
-#pragma unroll
-    for (int k = 0; k < NE; ++k) {
-      const int i = tid + NTHR * k;
-      if (i < nWe) { const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = re[k]; }
-    }
-#pragma unroll
-    for (int k = 0; k < ND; ++k) {
-      const int i = tid + NTHR * k;
-      if (i < nWd) { const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_Wd + (size_t)t * CH + q4) = rd[k]; }
-    }
   }
   __syncthreads();
   MKWS_CL_STAMP(1)
@@ -2554,8 +2537,30 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
         }
       }
     };
-    f32x4 wqa[6][NTWA];                                            // 6 chunks x NTWA fragments in flight per wave
-    stream_mfma_runs<NTWA, 6, 1, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
+    f32x4 wqa[12][NTWA];                                           // the whole run (<= 12 chunks x NTWA fragments) in flight: one latency
+    stream_mfma_runs<NTWA, 12, 1, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
+  }
+  // the SE weights / depthwise taps requested before phase A go to LDS now
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {                                    // Wr [CH][se] -> transposed [se][CH + 4]; float4 = 4 units of one channel (se % 4 == 0)
+    const int i = tid + NTHR * k;
+    if (i < nWr) {
+      const int ch = (4 * i) / a.se, n = 4 * i - ch * a.se;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s_Wr[(n + q) * LDW + ch] = rr[k][q];
+    }
+  }
+  if ((a.se & 3) != 0)
+    for (int i = tid; i < CH * a.se; i += NTHR) { const int ch = i / a.se, n = i - ch * a.se; s_Wr[n * LDW + ch] = ca.Wr[(size_t)chan0 * a.se + i]; }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int i = tid + NTHR * k;
+    if (i < nWe) { const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = re[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < ND; ++k) {
+    const int i = tid + NTHR * k;
+    if (i < nWd) { const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_Wd + (size_t)t * CH + q4) = rd[k]; }
   }
   // phase D's weight stream (K = the member's KH chunks, tiles wave, wave + 4, ...) is requested now: it lands under phases B and C
   const WBuf d_w(a.WpP + (size_t)(p * KH) * a.NTp * 256, loff);
