@@ -144,7 +144,7 @@ int mkws_embed_create(const float* h_weights, size_t n_floats, int max_batch, mk
 void mkws_embed_destroy(mkws_embed* em);
 /* d_spec float32 [B,49,40,1] (NHWC, i.e. the frontend's output) -> d_emb float32 [B,1024]. */
 int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, void* stream);
-/* Failure contract of the paired whole-block kernel ("fuse_pair", below).  Its two workgroups find each other through the
+/* Failure contract of the paired whole-block kernel ("fuse_pair", below) and of the cluster kernel ("fuse_cluster").  Its two workgroups find each other through the
  * GPU's dispatch order (workgroups are dealt round-robin over the 8 XCDs, so linear ids b and b^8 run on one XCD, adjacent in
  * its queue).  That order is observed, probed at create and re-checked by every pair at run time, but it is NOT a documented
  * guarantee (CU masking, CPX/DPX partitions, a second process holding CUs can break it).  When a pair finds itself on two XCDs,
@@ -168,6 +168,11 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 mkws_embed_create turns it on only after a probe launch has shown that workgroups b and b^8 share an XCD on this device.
  *                 Handles with max_batch <= 512 pair 4 clips (and give the 4x3-image whole-block kernels 2 clips per workgroup) so that
  *                 every CU still gets a workgroup.
+ *   "fuse_cluster" (default 1 for handles with max_batch <= 32 when the probe at create passed; settable up to 64): the tiny-image
+ *                 blocks (4b..7a) run on the CLUSTER kernel: P = 10 / 14 / 12 workgroups on CUs of one XCD share one 16-row tile (one
+ *                 clip of a 4x3 image, four of a 2x2 image) and split the block's expanded channels, so that a single live window no
+ *                 longer waits for one CU to pull a whole block's weights (batch-1 embedding 0.44 -> 0.30 ms); two in-kernel exchanges
+ *                 with generation flags (graph-replayable).  Same failure contract as the paired kernel (above).
  *   "fuse_back" (default 1): blocks 2a, 2b, 3b run squeeze-excite + gated projection as
  *                 ONE kernel behind the fused expand+depthwise kernel (the clip's depthwise output is staged in LDS once);
  *                 0 = se_reduce + se_expand + projection GEMM launches.
