@@ -11,6 +11,8 @@ O=$GRAFT_REPO_ROOT/gpurun_out/train_stats; rm -rf $O; mkdir -p $O
 ( cd /tmp && MKWS_TRAIN_BENCH_NO_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O -o s -- python $GRAFT_REPO_ROOT/tools/train_bench.py 64 > $O/log.txt 2>&1 )
 cp $(find $O -name "*kernel_stats.csv" | head -1) gpurun_out/r03_kernel_stats_train64.csv
 timeout 300 python tools/train_bench.py 64 512 2>&1 | grep "B=" > gpurun_out/r03_train_bench.txt; cat gpurun_out/r03_train_bench.txt
+# rocprof of the batch-1 serving chain (frontend -> embedding on the cluster plan -> 50 heads, 300 graph replays)
+bash tools/gpu/latency_stats.sh 1 > gpurun_out/r03_latency_stats.txt 2>&1; cp $(find gpurun_out/lat_stats -name "*kernel_stats.csv" | head -1) gpurun_out/r03_kernel_stats_latency.csv; tail -3 gpurun_out/r03_latency_stats.txt
 python - <<'PY'
 import json
 for c in ("embed","frontend","finetune","stream"):
