@@ -24,6 +24,7 @@
 #include "mkws_common.h"
 #include "mkws_embed_arch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -81,6 +82,39 @@ __device__ __forceinline__ f32x4 apply_act4(f32x4 v, int act) {
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifdef MKWS_FRONT_TIMING
+// timing build: every workgroup of the early-block kernels leaves (start, end, CU id) so that the host can rebuild the per-CU
+// timeline: how many workgroups were resident at a time and how long a CU's slots sat empty between workgroups.
+__device__ unsigned long long* g_wgtrace = nullptr;
+__device__ __forceinline__ void wg_trace_begin() {
+  if (threadIdx.x == 0 && g_wgtrace) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* p = g_wgtrace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+    p[0] = wall_clock64();
+    p[2] = ((unsigned long long)(xcc & 15) << 8) | ((hw >> 8) & 0xff);
+  }
+}
+__device__ __forceinline__ void wg_trace_end() {
+  __syncthreads();
+  if (threadIdx.x == 0 && g_wgtrace) g_wgtrace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + 1] = wall_clock64();
+}
+// per-phase shader-clock sums of a persistent workgroup (thread 0): MKWS_PH_DECL; MKWS_PH(k) after phase k; MKWS_PH_STORE at the end
+#define MKWS_PH_DECL long long ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t_ = clock64()
+#define MKWS_PH(k) do { const long long n_ = clock64(); ph_acc_[k] += n_ - ph_t_; ph_t_ = n_; } while (0)
+#define MKWS_PH_STORE() do { if (threadIdx.x == 0 && g_wgtrace) { unsigned long long* p_ = g_wgtrace + 3 * 131072 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8; \
+    for (int k_ = 0; k_ < 8; ++k_) p_[k_] = (unsigned long long)ph_acc_[k_]; } } while (0)
+#define MKWS_WG_BEGIN() wg_trace_begin()
+#define MKWS_WG_END() wg_trace_end()
+#else
+#define MKWS_WG_BEGIN()
+#define MKWS_WG_END()
+#define MKWS_PH_DECL
+#define MKWS_PH(k)
+#define MKWS_PH_STORE()
+#endif
+
 // stem: spec [B,49,40] -> [B,25,20,32]; ZeroPadding2D(((1,1),(0,1))) + Conv2D(32,3,s2,valid) + BN + swish
 // 8 threads per output pixel, each 4 output channels (float4 store, fully coalesced).
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ spec, const float* __restrict__ w /*[9][32]*/,
@@ -131,143 +165,208 @@ __global__ __launch_bounds__(512) void stem_block1a_kernel(const float* __restri
                                                            const float* __restrict__ shD, const float* __restrict__ Wr /*[32][se]*/,
                                                            const float* __restrict__ br, const float* __restrict__ We /*[se][32]*/,
                                                            const float* __restrict__ be, int se, const float* __restrict__ WpP,
-                                                           const float* __restrict__ scP, const float* __restrict__ shP, float* __restrict__ Y) {
+                                                           const float* __restrict__ scP, const float* __restrict__ shP, float* __restrict__ Y, int B) {
   constexpr int H = kInH, W = kInW, Ho = 25, Wo = 20, C = 32, CO = 16, NTHR = 512;
+  MKWS_WG_BEGIN();
   constexpr int TH = H + 2, TW = W + 1;                 // input tile with halo: rows -1..49, cols 0..40
   constexpr int EH = Ho + 2, EW = Wo + 2;               // stem-output tile with a 1-pixel zero halo
   constexpr int LDD = C + 4;                            // depthwise-output row stride (conflict-free MFMA operand reads)
+  constexpr int NIN = (TH * TW + NTHR - 1) / NTHR;      // input-tile elements per thread
+  constexpr int NRT = (Ho * Wo + 15) / 16, RTW = NRT / (NTHR / 64);      // projection row tiles, per wave
+  static_assert(RTW * (NTHR / 64) == NRT, "every wave owns the same number of projection row tiles");
   extern __shared__ __attribute__((aligned(16))) float s_sb[];
   float* s_in = s_sb;                                   // [TH][TW]
   float* s_E = s_in + ((TH * TW + 3) & ~3);             // [EH][EW][C]
   float* s_D = s_E + EH * EW * C;                       // [Ho*Wo][LDD]
   f32x4* s_red = reinterpret_cast<f32x4*>(s_D + Ho * Wo * LDD);   // [8 waves][8 quads]
-  float* s_mean = reinterpret_cast<float*>(s_red + 64);  // [32] means, [16] r, [32] gate
-  float* s_r = s_mean + C;
-  float* s_gate = s_r + 16;
+  float* s_gate = reinterpret_cast<float*>(s_red + 64);  // [32]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform by construction: keeps wave-dependent offsets / branches on the scalar unit
-  const size_t b = blockIdx.x;
-  const float* img = spec + b * H * W;
-  for (int i = tid; i < TH * TW; i += NTHR) {
+  // The workgroup is PERSISTENT: it walks clips blockIdx.x, + gridDim.x, ... (one workgroup per CU fits: 157 KB of LDS), so the
+  // constants below are fetched once per CU instead of once per clip, and the NEXT clip's spectrogram is requested (into registers)
+  // while this clip computes: the ~2 us a lone workgroup waited for its input at the top of every clip are gone.
+  int ioff[NIN];                                        // this thread's input-tile elements: image offset, -1 = zero halo, -2 = none
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) {
+    const int i = tid + k * NTHR;
     const int r = i / TW - 1, cc = i % TW;
-    float v = 0.0f;
-    if (r >= 0 && r < H && cc < W) v = __fdiv_rn(img[r * W + cc] * (1.0f / 255.0f) - norm_mean, norm_std);
-    s_in[i] = v;
+    ioff[k] = (i < TH * TW) ? ((r >= 0 && r < H && cc < W) ? r * W + cc : -1) : -2;
   }
-  for (int i = tid; i < EH * EW * C / 4; i += NTHR) {    // zero the halo (interior is overwritten below)
+  float pre[NIN];
+  auto request = [&](size_t clip) {
+    const float* img = spec + clip * H * W;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) pre[k] = (ioff[k] >= 0) ? img[ioff[k]] : 0.0f;
+  };
+  if (blockIdx.x < (unsigned)B) request(blockIdx.x);
+  for (int i = tid; i < EH * EW * C / 4; i += NTHR) {    // zero the halo once (the interior is overwritten by every clip)
     const int pix = i / (C / 4);
     const int r = pix / EW, cc = pix % EW;
     if (r == 0 || r == EH - 1 || cc == 0 || cc == EW - 1) reinterpret_cast<f32x4*>(s_E)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  // SE and projection constants are requested now and consumed after the convolutions
   const int q = tid & 7;                                 // channel quad of this thread
   const int g = lane >> 4, c = lane & 15;
-  const float wr_pre = (tid < C * 8 && (tid & 7) < se) ? Wr[(tid >> 3) * se + (tid & 7)] : 0.0f;    // thread (ch = tid>>3, n = tid&7)
-  const float we_pre = (tid < 8 * C && (tid >> 5) < se) ? We[tid] : 0.0f;                            // thread (n = tid>>5, ch = tid&31)
-  const float br_pre = (tid < se) ? br[tid] : 0.0f;
-  const float be_pre = (tid < C) ? be[tid] : 0.0f;
+  // SE constants of wave 0.  Reduce: lane = (channel group cg = lane >> 3 of 4 channels, unit n = lane & 7);  expand: lane = channel.
+  const int se_n = lane & 7, se_cg = lane >> 3, ch = lane & 31;
+  float wr4[4] = {0.f, 0.f, 0.f, 0.f}, we8[8], br_n = 0.0f, be_c = 0.0f;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) we8[n] = 0.0f;
+  if (wave == 0) {
+    if (se_n < se) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wr4[i] = Wr[(4 * se_cg + i) * se + se_n];
+      br_n = br[se_n];
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+      if (n < se) we8[n] = We[n * C + ch];
+    be_c = be[ch];
+  }
   f32x4 wp[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) wp[j] = *reinterpret_cast<const f32x4*>(WpP + ((size_t)j * 4 + g) * 64 + c * 4);
   const f32x4 scp = *reinterpret_cast<const f32x4*>(scP + 4 * g), shp = *reinterpret_cast<const f32x4*>(shP + 4 * g);
-  // both convolutions' taps and BN constants too (requested before the barriers they would otherwise wait behind)
   f32x4 wk[9], wkd[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) { wk[t] = *reinterpret_cast<const f32x4*>(w + t * C + q * 4); wkd[t] = *reinterpret_cast<const f32x4*>(Wd + t * C + q * 4); }
   const f32x4 sc_s = *reinterpret_cast<const f32x4*>(scale + q * 4), sh_s = *reinterpret_cast<const f32x4*>(shift + q * 4);
   const f32x4 sc_d = *reinterpret_cast<const f32x4*>(scD + q * 4), sh_d = *reinterpret_cast<const f32x4*>(shD + q * 4);
-  __syncthreads();
-  {
-    const f32x4 sc = sc_s, sh = sh_s;
-    for (int pix = tid >> 3; pix < Ho * Wo; pix += NTHR / 8) {
-      const int oh = pix / Wo, ow = pix % Wo;
-      const float* in0 = s_in + (2 * oh) * TW + 2 * ow;   // tile row 2*oh == image row 2*oh - 1
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // input tile of a clip: Rescaling(1/255) + Normalization on the way from the prefetch registers into LDS
+  auto stage = [&]() {
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc += wk[i * 3 + j] * in0[i * TW + j];
-      f32x4 y = acc * sc + sh;
-      y = swish4_(y);
-      *reinterpret_cast<f32x4*>(s_E + ((size_t)(oh + 1) * EW + (ow + 1)) * C + q * 4) = y;
-    }
+    for (int k = 0; k < NIN; ++k)
+      if (ioff[k] != -2) s_in[tid + k * NTHR] = (ioff[k] >= 0) ? __fdiv_rn(pre[k] * (1.0f / 255.0f) - norm_mean, norm_std) : 0.0f;
+  };
+  MKWS_PH_DECL;
+  if (blockIdx.x < (unsigned)B) {
+    stage();
+    if (blockIdx.x + gridDim.x < (unsigned)B) request((size_t)blockIdx.x + gridDim.x);
   }
   __syncthreads();
-  f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
-  {
-    const f32x4 sc = sc_d, sh = sh_d;
-    for (int pix = tid >> 3; pix < Ho * Wo; pix += NTHR / 8) {
-      const int oh = pix / Wo, ow = pix % Wo;
-      const float* e0 = s_E + ((size_t)oh * EW + ow) * C + q * 4;     // top-left tap (halo offset cancels the -1)
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  MKWS_PH(0);
+
+  for (size_t b = blockIdx.x; b < (size_t)B; b += gridDim.x) {
+    // 1. stem conv (s_in holds this clip; the clip after it is on its way into the prefetch registers)
+    {
+      const f32x4 sc = sc_s, sh = sh_s;
+      for (int pix = tid >> 3; pix < Ho * Wo; pix += NTHR / 8) {
+        const int oh = pix / Wo, ow = pix % Wo;
+        const float* in0 = s_in + (2 * oh) * TW + 2 * ow;   // tile row 2*oh == image row 2*oh - 1
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc += *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + j) * C) * wkd[i * 3 + j];
-      f32x4 y = acc * sc + sh;
-      y = swish4_(y);
-      *reinterpret_cast<f32x4*>(s_D + (size_t)pix * LDD + q * 4) = y;
-      ssum += y;
-    }
-  }
-  // channel sums: lanes of a wave that share the quad fold by shuffles, the 8 wave partials in fixed order
-#pragma unroll
-  for (int m = 8; m < 64; m <<= 1) {
-    ssum.x += __shfl_xor(ssum.x, m); ssum.y += __shfl_xor(ssum.y, m);
-    ssum.z += __shfl_xor(ssum.z, m); ssum.w += __shfl_xor(ssum.w, m);
-  }
-  if (lane < 8) s_red[wave * 8 + lane] = ssum;
-  __syncthreads();
-  if (tid < 8) {
-    f32x4 t = s_red[tid];
-    for (int k = 1; k < NTHR / 64; ++k) t += s_red[k * 8 + tid];
-    *reinterpret_cast<f32x4*>(s_mean + tid * 4) = t * (1.0f / (Ho * Wo));
-  }
-  __syncthreads();
-  // SE reduce: thread (ch, n) contributes mean[ch]*Wr[ch][n]; the 32 channels of a unit fold by shuffles
-  if (tid < C * 8) {
-    float v = s_mean[tid >> 3] * wr_pre;
-#pragma unroll
-    for (int m = 8; m < 64; m <<= 1) v += __shfl_xor(v, m);                 // 8 channels per wave
-    if (lane < 8) reinterpret_cast<float*>(s_red)[wave * 8 + lane] = v;      // waves 0..3 hold channels 8w..8w+7
-  }
-  __syncthreads();
-  if (tid < 8) {
-    const float* pr = reinterpret_cast<const float*>(s_red);
-    const float v = ((pr[tid] + pr[8 + tid]) + (pr[16 + tid] + pr[24 + tid])) + br_pre;
-    s_r[tid] = (tid < se) ? swishf_(v) : 0.0f;
-  }
-  __syncthreads();
-  // SE expand: thread (n, ch) -> r[n]*We[n][ch]; the 8 units of a channel live in 8 different half-waves
-  if (tid < 8 * C) reinterpret_cast<float*>(s_red)[tid] = s_r[tid >> 5] * we_pre;
-  __syncthreads();
-  if (tid < C) {
-    const float* pe = reinterpret_cast<const float*>(s_red);
-    float v = 0.0f;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) v += pe[n * C + tid];
-    s_gate[tid] = sigmoidf_(v + be_pre);
-  }
-  __syncthreads();
-  // projection: Y[500, 16] = BN((D * gate)[500, 32] . Wp[32, 16])
-  {
-    f32x4 gq[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) gq[j] = *reinterpret_cast<const f32x4*>(s_gate + 16 * j + 4 * g);
-    float* yout = Y + b * Ho * Wo * CO;
-    for (int t = wave; t < (Ho * Wo + 15) / 16; t += NTHR / 64) {
-      const int row = t * 16 + c;
-      const int rr = row < Ho * Wo ? row : Ho * Wo - 1;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(s_D + (size_t)rr * LDD + 16 * j + 4 * g) * gq[j];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][s4], x[s4], acc, 0, 0, 0);
+          for (int j = 0; j < 3; ++j) acc += wk[i * 3 + j] * in0[i * TW + j];
+        f32x4 y = acc * sc + sh;
+        y = swish4_(y);
+        *reinterpret_cast<f32x4*>(s_E + ((size_t)(oh + 1) * EW + (ow + 1)) * C + q * 4) = y;
       }
-      if (row < Ho * Wo) *reinterpret_cast<f32x4*>(yout + (size_t)row * CO + 4 * g) = acc * scp + shp;
     }
+    __syncthreads();
+    MKWS_PH(1);
+    // 2. depthwise conv in row strips: an item = SEG adjacent outputs of one row and one channel quad reads its 3 x (SEG + 2)
+    //    inputs once (4.5 LDS reads per output instead of 9: the phase was LDS-bound)
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int SEG = 4, NSG = Wo / SEG;
+      static_assert(NSG * SEG == Wo && NTHR % 8 == 0, "strips tile the output row; an item's channel quad is the thread's");
+      const f32x4 sc = sc_d, sh = sh_d;
+      for (int item = tid; item < Ho * NSG * 8; item += NTHR) {
+        const int sp = item >> 3;
+        const int oh = sp / NSG, ow0 = (sp - oh * NSG) * SEG;
+        const float* e0 = s_E + ((size_t)oh * EW + ow0) * C + q * 4;     // top-left tap (halo offset cancels the -1)
+        f32x4 acc[SEG];
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          f32x4 v[SEG + 2];
+#pragma unroll
+          for (int ci = 0; ci < SEG + 2; ++ci) v[ci] = *reinterpret_cast<const f32x4*>(e0 + ((size_t)i * EW + ci) * C);
+#pragma unroll
+          for (int o = 0; o < SEG; ++o)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[o] += v[o + j] * wkd[i * 3 + j];
+        }
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
+          f32x4 y = acc[o] * sc + sh;
+          y = swish4_(y);
+          *reinterpret_cast<f32x4*>(s_D + (size_t)(oh * Wo + ow0 + o) * LDD + q * 4) = y;
+          ssum += y;
+        }
+      }
+    }
+    // the next clip's input tile goes to LDS now (s_in was last read by the stem conv above, one barrier ago) and the clip after
+    // that is requested: by the time anybody waits for these loads again, a whole clip of work has passed
+    if (b + gridDim.x < (size_t)B) {
+      stage();
+      if (b + 2 * (size_t)gridDim.x < (size_t)B) request(b + 2 * (size_t)gridDim.x);
+    }
+    // channel sums: lanes of a wave that share the quad fold by shuffles, the 8 wave partials in fixed order
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {
+      ssum.x += __shfl_xor(ssum.x, m); ssum.y += __shfl_xor(ssum.y, m);
+      ssum.z += __shfl_xor(ssum.z, m); ssum.w += __shfl_xor(ssum.w, m);
+    }
+    if (lane < 8) s_red[wave * 8 + lane] = ssum;
+    __syncthreads();
+    MKWS_PH(2);
+    // 3. SE on ONE wave without further barriers; meanwhile every wave requests its projection operands
+    if (wave == 0) {
+      f32x4 m4 = s_red[se_cg];
+#pragma unroll
+      for (int k = 1; k < NTHR / 64; ++k) m4 += s_red[k * 8 + se_cg];
+      m4 = m4 * (1.0f / (Ho * Wo));
+      float pr = ((m4.x * wr4[0] + m4.y * wr4[1]) + m4.z * wr4[2]) + m4.w * wr4[3];
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) pr += __shfl_xor(pr, m);          // over the 8 channel groups: every lane of a unit ends with the same sum
+      const float rn = (se_n < se) ? swishf_(pr + br_n) : 0.0f;
+      float v = be_c;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) v += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rn), n)) * we8[n];      // units in fixed order
+      if (lane < C) s_gate[ch] = sigmoidf_(v);
+    }
+    constexpr int NWV = NTHR / 64;
+    f32x4 x[RTW][2];
+#pragma unroll
+    for (int i = 0; i < RTW; ++i) {
+      const int row = (wave + i * NWV) * 16 + c;
+      const int rr = row < Ho * Wo ? row : Ho * Wo - 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) x[i][j] = *reinterpret_cast<const f32x4*>(s_D + (size_t)rr * LDD + 16 * j + 4 * g);
+    }
+    __syncthreads();
+    MKWS_PH(3);
+    // 4. projection: Y[500, 16] = BN(D[500, 32] . (gate * Wp)[32, 16]): the gate scales the K rows of the weight fragments (8 multiplies
+    //    per lane instead of 8 per row tile); a wave's row tiles and K chunks are independent accumulation chains
+    {
+      f32x4 wpg[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wpg[j] = wp[j] * *reinterpret_cast<const f32x4*>(s_gate + 16 * j + 4 * g);
+      float* yout = Y + b * Ho * Wo * CO;
+      f32x4 acc[RTW][2];
+#pragma unroll
+      for (int i = 0; i < RTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int i = 0; i < RTW; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpg[j][s4], x[i][j][s4], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RTW; ++i) {
+        const int row = (wave + i * NWV) * 16 + c;
+        if (row < Ho * Wo) *reinterpret_cast<f32x4*>(yout + (size_t)row * CO + 4 * g) = (acc[i][0] + acc[i][1]) * scp + shp;
+      }
+    }
+    MKWS_PH(4);
+    // (no barrier here: every LDS write of the next clip sits behind one of its own barriers, and s_in was refilled two barriers ago)
   }
+  MKWS_PH_STORE();
+  MKWS_WG_END();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,6 +689,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   const int gvalid = (a.B - b0 < a.G) ? (a.B - b0) : a.G;
   const int rows = gvalid * HW;
   const int ch0 = blockIdx.y * CC;             // first expanded channel of this block
+  MKWS_WG_BEGIN();
   if (tid < LDE / 4) *reinterpret_cast<f32x4*>(s_front + (size_t)a.G * HW * LDE + 4 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifdef MKWS_FRONT_TIMING
   unsigned long long* dbgp = a.dbg_t + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
@@ -901,6 +1001,7 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   __syncthreads();
   if (tid == 0) dbgp[3] = wall_clock64();
 #endif
+  MKWS_WG_END();
 }
 
 // Where a weight stream comes from.  The stream helpers below only call ld(idx) (idx = float index of the fragment: tile and
@@ -1106,6 +1207,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
   static_assert(NTHR % 64 == 0 && NTHR >= CEXP && NTHR >= 16 * G && RS >= 1, "thread roles");
   static_assert(NTHR * G <= KCT * MTI * 256 && G * RS * CEXP <= GM::oD - GM::oS1, "aliased scratch fits");
   extern __shared__ __attribute__((aligned(16))) float s_mid[];
+  MKWS_WG_BEGIN();
   float* s_X = s_mid + GM::oX;
   float* s_part = s_X;                                           // [NSL][16][G] SE reduce partials (X fragments are dead by then)
   float* s_W = s_mid + GM::oS1;                                  // [KCT][NTC][256] expand weight fragments
@@ -1376,6 +1478,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
   __syncthreads();
   if (tid == 0) { const unsigned long long t = wall_clock64(); dbgp[1] = t_p1; dbgp[2] = t_p2; dbgp[3] = t_red; dbgp[4] = t - t_mark; dbgp[5] = t; }
 #endif
+  MKWS_WG_END();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1405,6 +1508,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_back_kernel(BackArgs a) {
   constexpr int PD = (KC >= 8) ? 8 : 4;
   static_assert(RS * CQ <= NTHR && NTHR >= CEXP && NWP >= 1, "thread roles");
   extern __shared__ __attribute__((aligned(16))) float s_bk[];
+  MKWS_WG_BEGIN();
   float* s_D = s_bk;                                             // [HOWO][LDD]
   float* s_mean = s_D + HOWO * LDD;                              // [CEXP]
   float* s_gate = s_mean + CEXP;                                 // [CEXP]
@@ -1521,6 +1625,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_back_kernel(BackArgs a) {
       }
     }
   }
+  MKWS_WG_END();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3151,6 +3256,72 @@ bool front_supported(const BlockPlan& b) {
   return false;
 }
 
+#ifdef MKWS_FRONT_TIMING
+// timing build: per-CU timeline of the last launch from the (start, end, CU) triples the workgroups left (wg_trace_begin / _end)
+static unsigned long long* wg_trace_buffer() {
+  static unsigned long long* d = nullptr;
+  if (!d) {
+    (void)hipMalloc(&d, sizeof(unsigned long long) * (3 + 8) * 131072);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgtrace), &d, sizeof(d));
+  }
+  return d;
+}
+static void wg_trace_report(hipStream_t s, const char* stage, const char* kernel, size_t nblk) {
+  (void)hipStreamSynchronize(s);
+  std::vector<unsigned long long> h(nblk * 3);
+  (void)hipMemcpy(h.data(), wg_trace_buffer(), h.size() * 8, hipMemcpyDeviceToHost);
+  std::map<unsigned, std::vector<std::pair<unsigned long long, unsigned long long>>> cu;
+  unsigned long long t0 = ~0ull, t1 = 0; double dur = 0;
+  for (size_t i = 0; i < nblk; ++i) {
+    cu[(unsigned)h[3 * i + 2]].push_back({h[3 * i], h[3 * i + 1]});
+    if (h[3 * i] < t0) t0 = h[3 * i];
+    if (h[3 * i + 1] > t1) t1 = h[3 * i + 1];
+    dur += (double)(h[3 * i + 1] - h[3 * i]);
+  }
+  // per CU: peak number of resident workgroups, time with >= 1 resident, slot time = peak x (last end - first start)
+  size_t wmin = ~(size_t)0, wmax = 0; int peak_all = 0; double busy1 = 0, first = 0, last = 0, gap = 0; size_t ngap = 0;
+  for (auto& kv : cu) {
+    auto& v = kv.second;
+    if (v.size() < wmin) wmin = v.size();
+    if (v.size() > wmax) wmax = v.size();
+    std::vector<std::pair<unsigned long long, int>> ev;
+    for (auto& w : v) { ev.push_back({w.first, +1}); ev.push_back({w.second, -1}); }
+    std::sort(ev.begin(), ev.end());
+    int cur = 0, peak = 0; unsigned long long prev = ev[0].first; double b1 = 0;
+    for (auto& e : ev) { if (cur > 0) b1 += (double)(e.first - prev); prev = e.first; cur += e.second; if (cur > peak) peak = cur; }
+    if (peak > peak_all) peak_all = peak;
+    busy1 += b1;
+    first += (double)(ev.front().first - t0); last += (double)(t1 - ev.back().first);
+    // gap between a workgroup's end and the next start on the same CU (slots paired greedily in time order)
+    std::sort(v.begin(), v.end());
+    std::vector<unsigned long long> ends;
+    for (auto& w : v) {
+      size_t best = ends.size();
+      for (size_t k = 0; k < ends.size(); ++k) if (ends[k] <= w.first && (best == ends.size() || ends[k] > ends[best])) best = k;
+      if (best == ends.size()) ends.push_back(w.second);
+      else { gap += (double)(w.first - ends[best]); ++ngap; ends[best] = w.second; }
+    }
+  }
+  const double span = (double)(t1 - t0), ncu = (double)cu.size();
+  fprintf(stderr, "[wg-trace] %s %s: %zu workgroups on %zu CUs (%zu-%zu per CU, peak %d resident); mean workgroup %.2f us; span %.2f us; "
+                  "mean residency %.2f; CU busy (>=1 resident) %.2f of span; first start +%.2f us, last end -%.2f us; slot gap %.2f us (n %zu)\n",
+          stage, kernel, nblk, cu.size(), wmin, wmax, peak_all, dur / nblk / 100.0, span / 100.0, dur / (ncu * span), busy1 / (ncu * span),
+          first / ncu / 100.0, last / ncu / 100.0, ngap ? gap / ngap / 100.0 : 0.0, ngap);
+}
+static void wg_phase_report(const char* stage, size_t nblk, int nph) {
+  std::vector<unsigned long long> h(nblk * 8);
+  (void)hipMemcpy(h.data(), wg_trace_buffer() + 3 * 131072, h.size() * 8, hipMemcpyDeviceToHost);
+  fprintf(stderr, "[wg-phase] %s: shader-clock cycles per workgroup (mean):", stage);
+  for (int k = 0; k < nph; ++k) { double t = 0; for (size_t i = 0; i < nblk; ++i) t += (double)h[8 * i + k]; fprintf(stderr, " %d: %.0f", k, t / nblk); }
+  fprintf(stderr, "\n");
+}
+#define MKWS_WG_TRACE_ARM() (void)wg_trace_buffer()
+#define MKWS_WG_TRACE_REPORT(s, stage, kernel, nblk) wg_trace_report(s, stage, kernel, nblk)
+#else
+#define MKWS_WG_TRACE_ARM()
+#define MKWS_WG_TRACE_REPORT(s, stage, kernel, nblk)
+#endif
+
 void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
   FrontArgs a;
   a.X = X; a.Cin = b.spec.in_ch; a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KC = b.expand.KC;
@@ -3180,6 +3351,7 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   if (!d_t) (void)hipMalloc(&d_t, sizeof(unsigned long long) * 4 * 65536);
   a.dbg_t = d_t;
 #endif
+  MKWS_WG_TRACE_ARM();
 #define MKWS_FRONT(KS, S, C_, KC_, H_, W_) \
   hipLaunchKernelGGL((mbconv_front_kernel<KS, S, C_, KC_, H_, W_>), grid, dim3((KC_) > 0 ? 256 : 512), lds, s, a)
   if (!tiny) {
@@ -3212,6 +3384,7 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
     fprintf(stderr, "[front-timing] %s ks%d s%d blocks %zu: phase1 %.2f us  barrier %.2f us  phase2 %.2f us  kernel span %.2f us\n", stage, ks, st, nblk,
             p1 / nblk / 100.0, bar / nblk / 100.0, p2 / nblk / 100.0, (double)(t1 - t0) / 100.0);
   }
+  MKWS_WG_TRACE_REPORT(s, stage, "front", nblk);
 #endif
 }
 
@@ -3480,6 +3653,7 @@ int launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
   static unsigned long long* d_t = nullptr;
   if (!d_t) (void)hipMalloc(&d_t, sizeof(unsigned long long) * 8 * 65536);
   MidArgs at = a; at.dbg_t = d_t;
+  MKWS_WG_TRACE_ARM();
   hipLaunchKernelGGL(fn, grid, dim3(NTHR), lds, s, at);
   (void)hipStreamSynchronize(s);
   std::vector<unsigned long long> h((size_t)grid.x * 8);
@@ -3492,6 +3666,7 @@ int launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
   }
   fprintf(stderr, "[mid-timing] %s CC %d G %d: %u workgroups x %d thr, lds %zu: expand %.2f  depthwise %.2f  SE %.2f  project %.2f  total %.2f us per workgroup; span %.2f us\n",
           stage, CC, G, grid.x, NTHR, lds, p1 / grid.x / 100.0, p2 / grid.x / 100.0, se / grid.x / 100.0, pj / grid.x / 100.0, tot / grid.x / 100.0, (double)(t1 - t0) / 100.0);
+  MKWS_WG_TRACE_REPORT(s, stage, "mid", (size_t)grid.x);
 #else
   hipLaunchKernelGGL(fn, grid, dim3(NTHR), lds, s, a);
 #endif
@@ -3538,7 +3713,9 @@ int launch_back_inst(hipStream_t s, const char* stage, const BackArgs& a) {
   auto* fn = &mbconv_back_kernel<HOWO, CEXP, NTP, RS, NTHR, WPE>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024)) return rc;
   ProfScope ps(stage, std::string("mbconv_back_kernel<") + std::to_string(HOWO) + "," + std::to_string(CEXP) + "," + std::to_string(NTP) + "," + std::to_string(NTHR) + ">");
+  MKWS_WG_TRACE_ARM();
   hipLaunchKernelGGL(fn, dim3(a.B), dim3(NTHR), lds, s, a);
+  MKWS_WG_TRACE_REPORT(s, stage, "back", (size_t)a.B);
   return MKWS_OK;
 }
 
@@ -3620,9 +3797,14 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     ProfScope ps("block1a", "stem_block1a_kernel");
     const size_t lds = ((size_t)((51 * 41 + 3) & ~3) + 27 * 22 * 32 + 500 * 36 + 64 * 4 + 32 + 16 + 32) * sizeof(float);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&stem_block1a_kernel), 160 * 1024)) return rc;
-    hipLaunchKernelGGL(stem_block1a_kernel, dim3(B), dim3(512), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
+    MKWS_WG_TRACE_ARM();
+    hipLaunchKernelGGL(stem_block1a_kernel, dim3(B < device_cu_count() ? B : device_cu_count()), dim3(512), lds, s, d_spec, em->stem_w, em->stem_scale, em->stem_shift, em->norm_mean,
                        em->norm_std, blk1a.dw.Wd, blk1a.dw.scale, blk1a.dw.shift, blk1a.se.Wr, blk1a.se.br, blk1a.se.We, blk1a.se.be,
-                       blk1a.se.se, blk1a.project.Wp, blk1a.project.scale, blk1a.project.shift, em->bufB);
+                       blk1a.se.se, blk1a.project.Wp, blk1a.project.scale, blk1a.project.shift, em->bufB, B);
+    MKWS_WG_TRACE_REPORT(s, "block1a", "stem_block1a", (size_t)(B < device_cu_count() ? B : device_cu_count()));
+#ifdef MKWS_FRONT_TIMING
+    wg_phase_report("block1a: prologue / stem / depthwise + next stage / SE / projection", (size_t)(B < device_cu_count() ? B : device_cu_count()), 5);
+#endif
   } else {
     const long pix = (long)B * 500;
     int grid = (int)((pix + 31) / 32);
@@ -3956,6 +4138,10 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
     em->fuse_cluster = value; return MKWS_OK;
   }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
+  if (strcmp(name, "big_tiles") == 0) {      // A/B: 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (fewer, larger workgroups: the workspaces still fit)
+    if (value) { em->pair_mt = 2; em->block_mt43 = 3; } else { em->pair_mt = pair_row_tiles(em->max_batch); em->block_mt43 = (em->pair_mt == 1) ? 2 : 3; }
+    return MKWS_OK;
+  }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
   if (strcmp(name, "pair_fault") == 0) { em->pair_fault = value; return MKWS_OK; }     // test hook: forces the paired kernel's failure paths
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);

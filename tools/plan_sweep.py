@@ -15,17 +15,21 @@ PLANS = {"multi": dict(fuse_block=0, fuse_mid=0, fuse_back=0, fuse_pair=0, fuse_
          "cluster": dict(fuse_block=2, fuse_mid=1, fuse_back=1, fuse_pair=1, fuse_cluster=1)}
 if os.environ.get("PLANS"):
     PLANS = {k: v for k, v in PLANS.items() if k in os.environ["PLANS"].split(",")}
+LANES = [int(x) for x in os.environ.get("LANES", "1,4").split(",")]
+BIG = int(os.environ.get("BIG_TILES", "0"))       # 1: "big_tiles" option on every handle (8-clip pairs, 4-clip 4x3 workgroups)
 blob = weights.synthetic_blob()
 dev = torch.device("cuda:0")
 for mb in (int(x) for x in (sys.argv[1:] or ["1", "8", "32", "64", "128", "256"])):
     for plan, opts in PLANS.items():
-        for lanes in (1, 4):
+        for lanes in LANES:
             ems = [EmbeddingModel(blob, max_batch=mb) for _ in range(lanes)]
             try:
                 for em in ems:
                     for k, v in opts.items():
                         if not (k == "fuse_cluster" and v == 0 and mb > 64):
                             em.set_option(k, v)
+                    if BIG:
+                        em.set_option("big_tiles", 1)
             except Exception as exc:
                 print(f"max_batch {mb:4d} plan {plan}: not available ({exc})")
                 continue
