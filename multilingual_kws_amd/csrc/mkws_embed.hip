@@ -63,6 +63,14 @@ __device__ __forceinline__ f32x4 sigmoid4_(f32x4 v) {
   return t;
 }
 __device__ __forceinline__ f32x4 swish4_(f32x4 v) { return v * sigmoid4_(v); }
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 swish2_(f32x2 v) {          // the same operations per element as swish4_ / swishf_
+  f32x2 t = v * -1.4426950408889634f;
+  t.x = __builtin_amdgcn_exp2f(t.x); t.y = __builtin_amdgcn_exp2f(t.y);
+  t = t + 1.0f;
+  t.x = __builtin_amdgcn_rcpf(t.x); t.y = __builtin_amdgcn_rcpf(t.y);
+  return v * t;
+}
 // value the optimizer cannot see through (stops loop-invariant hoisting of cheap index arithmetic into spilled registers)
 __device__ __forceinline__ int opaque_(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -86,6 +94,8 @@ __device__ __forceinline__ f32x4 apply_act4(f32x4 v, int act) {
 // timing build: every workgroup of the early-block kernels leaves (start, end, CU id) so that the host can rebuild the per-CU
 // timeline: how many workgroups were resident at a time and how long a CU's slots sat empty between workgroups.
 __device__ unsigned long long* g_wgtrace = nullptr;
+__device__ int g_ablate = 0;            // MKWS_ABLATE bit mask: phases a kernel SKIPS (wrong results, honest timing of what is left)
+#define MKWS_ABLATE(bit) (g_ablate & (bit))
 __device__ __forceinline__ void wg_trace_begin() {
   if (threadIdx.x == 0 && g_wgtrace) {
     unsigned hw, xcc;
@@ -110,6 +120,7 @@ __device__ __forceinline__ void wg_trace_end() {
 #else
 #define MKWS_WG_BEGIN()
 #define MKWS_WG_END()
+#define MKWS_ABLATE(bit) false
 #define MKWS_PH_DECL
 #define MKWS_PH(k)
 #define MKWS_PH_STORE()
@@ -1190,7 +1201,7 @@ struct MidGeom {
   static_assert(CEXP % CC == 0 && CC % 16 == 0, "chunks are whole MFMA tiles");
 };
 
-template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int NTP, int G, int SEG, int NTHR, int WPE>
+template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int NTP, int G, int SEG, int NTHR, int WPE, bool PAIR = false>
 __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
   using GM = MidGeom<KS, S, KCT, HT, WT, CEXP, CC, G, SEG>;
   constexpr int HW = GM::HW, HoT = GM::HoT, WoT = GM::WoT, HoWo = GM::HoWo, PT = GM::PT, PLF = GM::PLF;
@@ -1284,7 +1295,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
     // ---- P1: expand this chunk into LDS ----
     load2(chn);
     {
-      const int ntasks = ((rows + 15) / 16) * NTC;
+      const int ntasks = MKWS_ABLATE(1) ? 0 : ((rows + 15) / 16) * NTC;
       for (int t = wave; t < ntasks; t += NW) {
         const int rt = t / NTC, ntl = t - rt * NTC;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1310,9 +1321,57 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
 #endif
     // ---- P2: depthwise from LDS -> D[:, chunk] ----
     if (chn + 1 < NCH) load1(chn + 1);
-    {
+    if constexpr (PAIR) {
+      // Channel PAIRS x row strips.  With one output pixel x channel quad per item (below) the phase is LDS-bound: 25 input + 25 tap
+      // ds_read_b128 per output of a 5x5 kernel, 336 KB per chunk of block 3a = 2 600 LDS cycles, twice that with the CU's second
+      // workgroup in the same phase (measured 2.5 us per chunk).  A strip reads each input of its rows once and each tap once per
+      // strip (90 reads for 5 outputs), and pairs instead of quads keep three waves busy instead of one and a half.
+      constexpr int Q2 = CC / 2;
       const int zrow = G * HW;
-      const int nitems = gvalid * HoT * NSEG * Q;
+      const int nitems = MKWS_ABLATE(2) ? 0 : gvalid * HoT * NSEG * Q2;
+      for (int item = tid; item < nitems; item += NTHR) {
+        int r = item / Q2;
+        const int tp = item - r * Q2;
+        const int sg = r % NSEG; r /= NSEG;
+        const int oh = r % HoT, gi = r / HoT;
+        const float* E0 = s_E + 2 * tp;
+        const int ih0 = oh * S - PT, iw0 = sg * SEG * S - PLF;
+        int coff[NC];
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) coff[ci] = ((unsigned)(iw0 + ci) < (unsigned)WT) ? iw0 + ci : -1;
+        f32x2 acc[SEG];
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) acc[o] = (f32x2){0.f, 0.f};
+#pragma unroll TAP_ROW_UNROLL
+        for (int i = 0; i < KS; ++i) {
+          const int ih = ih0 + i;
+          const bool rok = (unsigned)ih < (unsigned)HT;
+          const int rbase = gi * HW + ih * WT;
+          f32x2 v[NC], w[KS];
+#pragma unroll
+          for (int ci = 0; ci < NC; ++ci) {
+            const int row = (rok && coff[ci] >= 0) ? rbase + coff[ci] : zrow;
+            v[ci] = *reinterpret_cast<const f32x2*>(E0 + (size_t)row * LDE);
+          }
+#pragma unroll
+          for (int jx = 0; jx < KS; ++jx) w[jx] = *reinterpret_cast<const f32x2*>(s_wd + (i * KS + jx) * CC + 2 * tp);
+#pragma unroll
+          for (int o = 0; o < SEG; ++o)
+#pragma unroll
+            for (int jx = 0; jx < KS; ++jx) acc[o] += v[o * S + jx] * w[jx];
+        }
+        const f32x2 scd = *reinterpret_cast<const f32x2*>(s_scD + 2 * tp), shd = *reinterpret_cast<const f32x2*>(s_scD + CC + 2 * tp);
+        float* dout = s_D + (size_t)(gi * HoWo + oh * WoT + sg * SEG) * LDD + ch0 + 2 * tp;
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
+          f32x2 y = acc[o] * scd + shd;
+          y = swish2_(y);
+          *reinterpret_cast<f32x2*>(dout + (size_t)o * LDD) = y;
+        }
+      }
+    } else {
+      const int zrow = G * HW;
+      const int nitems = MKWS_ABLATE(2) ? 0 : gvalid * HoT * NSEG * Q;
       for (int item = tid; item < nitems; item += NTHR) {
         int r = item / Q;
         const int tq = item - r * Q;
@@ -1388,6 +1447,7 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
       *reinterpret_cast<f32x4*>(a.dbg_dw + (row0_out + r) * CEXP + q4) = *reinterpret_cast<const f32x4*>(s_D + (size_t)r * LDD + q4);
     }
   }
+  if (!MKWS_ABLATE(4)) {
   // ---- SE squeeze: column sums of D in two fixed-order steps (row slices, then slices) ----
   if (tid < G * RS * CQ) {
     const int q = tid % CQ, rs = (tid / CQ) % RS, gi = tid / (CQ * RS);
@@ -1439,11 +1499,12 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
     }
   }
   __syncthreads();
+  }
 #ifdef MKWS_FRONT_TIMING
   if (tid == 0) { const unsigned long long t = wall_clock64(); t_red += t - t_mark; t_mark = t; }
 #endif
   // ---- gated projection (+ BN, residual): every weight fragment of the stream feeds this wave's MTW row tiles ----
-  if (rlp < NWP) {
+  if (rlp < NWP && !MKWS_ABLATE(8)) {
     const float* erow[MTW];
     const float* grow[MTW];
 #pragma unroll
@@ -3263,6 +3324,9 @@ static unsigned long long* wg_trace_buffer() {
   if (!d) {
     (void)hipMalloc(&d, sizeof(unsigned long long) * (3 + 8) * 131072);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgtrace), &d, sizeof(d));
+    const char* ab = getenv("MKWS_ABLATE");
+    const int abv = ab ? atoi(ab) : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &abv, sizeof(abv));
   }
   return d;
 }
@@ -3639,12 +3703,12 @@ bool mid_supported(const BlockPlan& b) {
          (b.H == 7 && b.W == 5 && ks == 3 && st == 2 && ci == 40 && co == 80);
 }
 
-template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int NTP, int G, int SEG, int NTHR, int WPE>
+template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int NTP, int G, int SEG, int NTHR, int WPE, bool PAIR = false>
 int launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
   using GM = MidGeom<KS, S, KCT, HT, WT, CEXP, CC, G, SEG>;
   constexpr size_t lds = (size_t)GM::lds_floats * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS carve exceeds one CU");
-  auto* fn = &mbconv_mid_kernel<KS, S, KCT, HT, WT, CEXP, CC, NTP, G, SEG, NTHR, WPE>;
+  auto* fn = &mbconv_mid_kernel<KS, S, KCT, HT, WT, CEXP, CC, NTP, G, SEG, NTHR, WPE, PAIR>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024)) return rc;
   ProfScope ps(stage, std::string("mbconv_mid_kernel<") + std::to_string(KS) + "," + std::to_string(S) + "," + std::to_string(HT) + "," + std::to_string(WT) +
                           "," + std::to_string(CEXP) + "," + std::to_string(CC) + "," + std::to_string(G) + "," + std::to_string(NTHR) + ">");
@@ -3694,9 +3758,9 @@ int launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const float
   //                              KS S KCT  H   W  CEXP CC NTP G SEG NTHR WPE
   if (b.H == 25) return launch_mid_inst<3, 2, 1, 25, 20, 96, 16, 2, 1, 1, 1024, 4>(s, stage, a);                  // 2a
   if (b.H == 13 && ks == 3) return launch_mid_inst<3, 1, 2, 13, 10, 144, 48, 2, 1, 2, 1024, 4>(s, stage, a);     // 2b
-  if (b.H == 13) return launch_mid_inst<5, 2, 2, 13, 10, 144, 48, 3, 1, 1, 512, 4>(s, stage, a);                  // 3a
+  if (b.H == 13) return launch_mid_inst<5, 2, 2, 13, 10, 144, 48, 3, 1, 5, 512, 4, true>(s, stage, a);            // 3a: pair strips of a whole output row
   if (st == 1) return launch_mid_inst<5, 1, 3, 7, 5, 240, 48, 3, 1, 1, 512, 4>(s, stage, a);                      // 3b
-  return launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 1, 512, 4>(s, stage, a);                                   // 4a
+  return launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 3, 512, 4, true>(s, stage, a);                             // 4a: the same
 }
 
 // Back half (SE + gated projection in one launch) for the blocks that keep mbconv_front_kernel: 2a, 2b, 3b.
