@@ -180,8 +180,10 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 project as ONE kernel per block (depthwise output of all channels resident in LDS): 1 = blocks 3a and 4a
  *                 (where it measured faster than the three-kernel path), 2 = all of 2a..4a, 0 = never.
  *   "fuse_gap" (default 1): global average pool fused into the top conv epilogue (its [B*4,1280] output is never stored).
- *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (one clip per workgroup, both 25x20x32
- *                 activations stay in LDS); 0 = separate kernels. */
+ *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (persistent workgroups, one per CU, each walking
+ *                 clips blockIdx, blockIdx + grid, ... with the next clip's spectrogram prefetched; both 25x20x32 activations stay
+ *                 in LDS); 0 = separate kernels.
+ *   "big_tiles" (A/B aid, default 0): 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (what handles above 512 clips use). */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
 /* Current value of an option above, or of "pair_degraded" (times the handle left the paired kernel after a failed exchange) /
  * "max_batch"; negative mkws_status for an unknown name.  ("pair_fault" is a write-only test hook that forces those failures.) */
