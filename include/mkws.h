@@ -308,6 +308,12 @@ int mkws_op_bn_stats(const float* d_Z, int M, int C, float* d_mean, float* d_var
  * d_mean / d_var receive the batch statistics the backward pass needs. */
 int mkws_op_bn_train_fwd(const float* d_Z, int M, int C, const float* d_gamma, const float* d_beta, float eps, int act, float momentum,
                          float* d_moving_mean, float* d_moving_var, float* d_mean, float* d_var, float* d_A, void* stream);
+/* The same with the residual branch of an MBConv block in the second launch (reference: the `layers.add([x, inputs])` behind Keras'
+ * drop-connect Dropout(noise_shape=(None,1,1,1)), train_multilingual_embedding.py:58-83 via keras/applications/efficientnet.py):
+ * A[r] = keep[r / group] * act(BN(Z)[r]) + d_res[r];  d_row_scale may be NULL (keep = 1), d_res NULL = plain mkws_op_bn_train_fwd. */
+int mkws_op_bn_train_fwd_res(const float* d_Z, int M, int C, const float* d_gamma, const float* d_beta, float eps, int act, float momentum,
+                             float* d_moving_mean, float* d_moving_var, float* d_mean, float* d_var, float* d_A, const float* d_res,
+                             const float* d_row_scale, int group, void* stream);
 /* A = act(gamma * (Z - mean) / sqrt(var + eps) + beta) */
 int mkws_op_bn_act_fwd(const float* d_Z, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, float eps, int act,
                        float* d_A, int M, int C, void* stream);
@@ -315,6 +321,13 @@ int mkws_op_bn_act_fwd(const float* d_Z, const float* d_mean, const float* d_var
  * d_dgamma / d_dbeta [C] are written; d_scratch: 2*C floats. */
 int mkws_op_bn_act_bwd(const float* d_Z, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, float eps, int act,
                        float* d_dA, float* d_dgamma, float* d_dbeta, float* d_scratch, int M, int C, void* stream);
+/* The same with the incoming gradient assembled on the fly (saves the launches that used to build it):
+ *   dLoss/dA[r] = d_src[r] * d_row_scale[r / group] + d_bcast[r / group][:] * bscale      (each term optional; at least one of src / bcast)
+ * e.g. the drop-connect scale of a residual block (src = gradient of the block output, kept intact for the shortcut), or the squeeze-excite
+ * mean's gradient broadcast over the pixels (src = d_dA, bcast = dLoss/dmean, bscale = 1 / HW).  d_dA receives dLoss/dZ. */
+int mkws_op_bn_act_bwd_ex(const float* d_Z, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, float eps, int act,
+                          float* d_dA, const float* d_src, const float* d_row_scale, const float* d_bcast, float bscale, int group, float* d_dgamma,
+                          float* d_dbeta, int M, int C, void* stream);
 /* moving = momentum * moving + (1 - momentum) * batch; the variance enters Bessel-corrected (M/(M-1)) as in Keras' fused BN. */
 int mkws_op_bn_update_moving(float* d_moving_mean, float* d_moving_var, const float* d_mean, const float* d_var, float momentum, int M, int C, void* stream);
 /* Depthwise k x k conv (k = 3, 5; stride 1, 2) with explicit top / left padding (Keras "same" or correct_pad), raw output. */

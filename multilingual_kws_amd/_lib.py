@@ -74,6 +74,7 @@ SYMBOLS = [
     # training operators (backprop_into_embedding)
     ("mkws_op_set_scratch", _I, [_P, _SZ]),
     ("mkws_op_bn_train_fwd", _I, [_P, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P]),
+    ("mkws_op_bn_train_fwd_res", _I, [_P, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     ("mkws_op_step_inc", _I, [_P, _P]),
     ("mkws_op_softmax_ce", _I, [_P, _P, _I, _I, _P, _P, _P]),
     ("mkws_op_dense_fwd", _I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
@@ -82,6 +83,7 @@ SYMBOLS = [
     ("mkws_op_bn_stats", _I, [_P, _I, _I, _P, _P, _P]),
     ("mkws_op_bn_act_fwd", _I, [_P, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),
     ("mkws_op_bn_act_bwd", _I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P]),
+    ("mkws_op_bn_act_bwd_ex", _I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _P]),
     ("mkws_op_bn_update_moving", _I, [_P, _P, _P, _P, _F, _I, _I, _P]),
     ("mkws_op_dwconv_fwd", _I, [_P, _P, _P] + [_I] * 10 + [_P]),
     ("mkws_op_dwconv_bwd", _I, [_P, _P, _P, _P, _P] + [_I] * 10 + [_P]),

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ part, int chunks, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int act, float momentum, float* __restrict__ mmean,
                                                            float* __restrict__ mvar, float* __restrict__ mean, float* __restrict__ var, float* __restrict__ A, int M,
-                                                           int C) {
+                                                           int C, const float* __restrict__ res, const float* __restrict__ row_scale, int group) {
   __shared__ float s_q[4][64][3], s_sh[64], s_var[64], s_sc[64];
   const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
   bn_fold_slab(part, chunks, M, C, blockIdx.x, s_q, s_sh, s_var);          // s_sh = mean
@@ -301,6 +301,12 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
     f32x4 y;
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = act_fwd(g[i] * ((z[i] - mu[i]) * inv[i]) + bt[i], act);
+    if (res) {                                         // residual branch of an MBConv block: out = keep[row / group] * BN(Z) + shortcut (mkws_op_bn_train_fwd_res)
+      const float ks = row_scale ? row_scale[r / group] : 1.0f;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(res + (size_t)r * C + c0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = y[i] * ks + x[i];
+    }
     *reinterpret_cast<f32x4*>(A + (size_t)r * C + c0) = y;
   }
 }
@@ -345,7 +351,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 // (block = 16 channel quads x 16 row lanes, float4 rows; lanes fold in lane order)
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
-                                                                float* __restrict__ dA, float* __restrict__ part /*[chunks][2][C]*/, int M, int C) {
+                                                                float* __restrict__ dA, float* __restrict__ part /*[chunks][2][C]*/, int M, int C,
+                                                                const float* __restrict__ src, const float* __restrict__ row_scale,
+                                                                const float* __restrict__ bcast, float bscale, int group) {
   __shared__ float s1[16][16][4], s2[16][16][4];
   const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c0 = blockIdx.x * 64 + 4 * ql;
@@ -362,7 +370,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
     for (int r = r0 + rl; r < r1; r += 16) {
       const size_t o = (size_t)r * C + c0;
       const f32x4 z = *reinterpret_cast<const f32x4*>(Z + o);
-      f32x4 d = *reinterpret_cast<const f32x4*>(dA + o);
+      // incoming gradient (mkws_op_bn_act_bwd_ex): src (or dA itself; neither = zero) * row_scale[row / group] + bcast[row / group][c] * bscale
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      if (src) d = *reinterpret_cast<const f32x4*>(src + o);
+      if (row_scale) { const float ks = row_scale[r / group]; d = d * ks; }
+      if (bcast) { const f32x4 bv = *reinterpret_cast<const f32x4*>(bcast + (size_t)(r / group) * C + c0); d = d + bv * bscale; }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float xh = (z[i] - mu[i]) * inv[i];
@@ -858,7 +870,13 @@ int mkws_op_bn_stats(const float* Z, int M, int C, float* mean, float* var, void
 
 int mkws_op_bn_train_fwd(const float* Z, int M, int C, const float* gamma, const float* beta, float eps, int act, float momentum, float* moving_mean,
                          float* moving_var, float* mean, float* var, float* A, void* stream) {
+  return mkws_op_bn_train_fwd_res(Z, M, C, gamma, beta, eps, act, momentum, moving_mean, moving_var, mean, var, A, nullptr, nullptr, 1, stream);
+}
+
+int mkws_op_bn_train_fwd_res(const float* Z, int M, int C, const float* gamma, const float* beta, float eps, int act, float momentum, float* moving_mean,
+                             float* moving_var, float* mean, float* var, float* A, const float* res, const float* row_scale, int group, void* stream) {
   MKWS_REQ(Z && gamma && beta && moving_mean && moving_var && mean && var && A && M > 0 && C > 0, "bn_train_fwd: bad arguments");
+  MKWS_REQ(group > 0 && (res || !row_scale), "bn_train_fwd_res: row_scale needs a residual input and a positive group");
   MKWS_REQ(C % 4 == 0, "bn_train_fwd: C must be a multiple of 4");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int chunks = row_chunks(M, 128);
@@ -866,7 +884,7 @@ int mkws_op_bn_train_fwd(const float* Z, int M, int C, const float* gamma, const
   MKWS_REQ(part, "bn_train_fwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, part, M, C);
   hipLaunchKernelGGL(bn_train_fwd_kernel, dim3((C + 63) / 64, row_chunks(M, 256)), dim3(256), 0, s, Z, part, chunks, gamma, beta, eps, act, momentum, moving_mean,
-                     moving_var, mean, var, A, M, C);
+                     moving_var, mean, var, A, M, C, res, row_scale, group);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -882,6 +900,15 @@ int mkws_op_bn_act_fwd(const float* Z, const float* mean, const float* var, cons
 
 int mkws_op_bn_act_bwd(const float* Z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, float* dA, float* dgamma,
                        float* dbeta, float* scratch, int M, int C, void* stream) {
+  MKWS_REQ(scratch, "bn_act_bwd: bad arguments");
+  return mkws_op_bn_act_bwd_ex(Z, mean, var, gamma, beta, eps, act, dA, dA, nullptr, nullptr, 0.0f, 1, dgamma, dbeta, M, C, stream);
+}
+
+int mkws_op_bn_act_bwd_ex(const float* Z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, float* dA,
+                          const float* src, const float* row_scale, const float* bcast, float bscale, int group, float* dgamma, float* dbeta, int M, int C,
+                          void* stream) {
+  float* scratch = dA;                                 // (placeholder for the check below; the partial sums live in the scratch arena)
+  MKWS_REQ(group > 0 && (src || bcast), "bn_act_bwd_ex: needs an incoming gradient (src and / or bcast) and a positive group");
   MKWS_REQ(Z && mean && var && gamma && beta && dA && dgamma && dbeta && scratch && M > 0 && C > 0, "bn_act_bwd: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
   MKWS_REQ(C % 4 == 0, "bn_act_bwd: C must be a multiple of 4");
@@ -889,7 +916,8 @@ int mkws_op_bn_act_bwd(const float* Z, const float* mean, const float* var, cons
   float* part = ::scratch((size_t)chunks * 2 * C);
   MKWS_REQ(part, "bn_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
   (void)scratch;                                       // (the 2*C-float argument of round 2's atomics path; kept in the signature)
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, part, M, C);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, part, M, C, src, row_scale, bcast,
+                     bscale, group);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((C + 63) / 64, row_chunks(M, 256)), dim3(256), 0, s, Z, mean, var, gamma, eps, dA, part, chunks, dgamma, dbeta, M, C);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;

@@ -112,21 +112,27 @@ class EmbeddingTrainer:
         return self.params.cpu().numpy()
 
     # ---- layers ---------------------------------------------------------------------------------------------------------
-    def _bn_fwd(self, Z, M, C, prefix, act):
+    def _bn_fwd(self, Z, M, C, prefix, act, res=None, row_scale=None, group=1):
+        """Training-mode BN + activation; res / row_scale [M // group]: the residual branch A = row_scale * act(BN(Z)) + res in the same launch."""
         mean, var = self.new(C), self.new(C)
         A = self.new(M, C)
         # batch statistics + moving-average update (Keras does it during the training-mode forward pass) + normalise / activate
-        _lib.check(self.L.mkws_op_bn_train_fwd(self._p(Z), M, C, self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")), BN_EPS, act, BN_MOMENTUM,
-                                               self._p(self.P(prefix + "/moving_mean")), self._p(self.P(prefix + "/moving_variance")), self._p(mean), self._p(var),
-                                               self._p(A), self._s()))
+        _lib.check(self.L.mkws_op_bn_train_fwd_res(self._p(Z), M, C, self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")), BN_EPS, act, BN_MOMENTUM,
+                                                   self._p(self.P(prefix + "/moving_mean")), self._p(self.P(prefix + "/moving_variance")), self._p(mean), self._p(var),
+                                                   self._p(A), self._p(res) if res is not None else None, self._p(row_scale) if row_scale is not None else None,
+                                                   group, self._s()))
         return A, (Z, mean, var, M, C, prefix, act)
 
-    def _bn_bwd(self, rec, dA):
-        """dA [M,C] (dLoss/dA) -> overwritten with dLoss/dZ; writes dgamma / dbeta."""
+    def _bn_bwd(self, rec, dA, src="same", row_scale=None, bcast=None, bscale=0.0, group=1):
+        """dLoss/dA -> dLoss/dZ in dA [M,C]; writes dgamma / dbeta.  The incoming gradient is src (default: dA itself; None: none)
+        * row_scale[row // group] + bcast[row // group] * bscale, assembled inside the first launch."""
         Z, mean, var, M, C, prefix, act = rec
-        scratch = self.new(2 * C)
-        _lib.check(self.L.mkws_op_bn_act_bwd(self._p(Z), self._p(mean), self._p(var), self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")), BN_EPS, act,
-                                             self._p(dA), self._p(self.G(prefix + "/gamma")), self._p(self.G(prefix + "/beta")), self._p(scratch), M, C, self._s()))
+        if src == "same":
+            src = dA
+        _lib.check(self.L.mkws_op_bn_act_bwd_ex(self._p(Z), self._p(mean), self._p(var), self._p(self.P(prefix + "/gamma")), self._p(self.P(prefix + "/beta")), BN_EPS, act,
+                                                self._p(dA), self._p(src) if src is not None else None, self._p(row_scale) if row_scale is not None else None,
+                                                self._p(bcast) if bcast is not None else None, float(bscale), group,
+                                                self._p(self.G(prefix + "/gamma")), self._p(self.G(prefix + "/beta")), M, C, self._s()))
         return dA
 
     def _conv_fwd(self, X, M, K, N, wname):
@@ -134,11 +140,15 @@ class EmbeddingTrainer:
         self.gemm(X, self.P(wname), Z, M, N, K, K, N, N)
         return Z
 
-    def _conv_bwd(self, X, dZ, M, K, N, wname, need_dx=True):
-        """dW += X^T dZ (the long reduction over the rows is split by the library), dX = dZ W^T."""
+    def _conv_bwd(self, X, dZ, M, K, N, wname, need_dx=True, add_into=None):
+        """dW += X^T dZ (the long reduction over the rows is split by the library), dX = dZ W^T (+ add_into, in place: the shortcut's
+        gradient of a residual block joins in the GEMM epilogue instead of a separate launch)."""
         self.gemm(X, dZ, self.G(wname), K, N, M, K, N, N, ta=1, tb=0, acc=1)
         if not need_dx:
             return None
+        if add_into is not None:
+            self.gemm(dZ, self.P(wname), add_into, M, K, N, N, N, K, ta=0, tb=1, acc=1)
+            return add_into
         dX = self.new(M, K)
         self.gemm(dZ, self.P(wname), dX, M, K, N, N, N, K, ta=0, tb=1)
         return dX
@@ -201,7 +211,6 @@ class EmbeddingTrainer:
             _lib.check(self.L.mkws_op_scale_channels(self._p(Ad), self._p(Gt), self._p(As), B, Ho * Wo, ce, self._s()))
             rec.update(Ad=Ad, Gt=Gt, As=As)
             Zp = self._conv_fwd(As, Mout, ce, cout, p + "_project_conv/kernel")
-            Pj, rec["project_bn"] = self._bn_fwd(Zp, Mout, cout, p + "_project_bn", ACT_NONE)
             rec["residual"] = (s == 1 and cin == cout)
             if rec["residual"]:
                 scale = self._views.get(("ones", B))
@@ -213,11 +222,10 @@ class EmbeddingTrainer:
                     rate = DROP_CONNECT_RATE * bi / len(BLOCKS)
                     scale = torch.as_tensor(np.asarray(drop_masks[name]), device=self.device).to(torch.float32) / (1.0 - rate)
                 rec["keep_scale"] = scale.contiguous()
-                out = self.new(Mout, cout)
-                _lib.check(self.L.mkws_op_row_scale_add(self._p(Pj), self._p(rec["keep_scale"]), self._p(x), self._p(out), B, Ho * Wo * cout, self._s()))
-                x = out
+                # out = keep * BN(project) + shortcut, inside the BN launch
+                x, rec["project_bn"] = self._bn_fwd(Zp, Mout, cout, p + "_project_bn", ACT_NONE, res=x, row_scale=rec["keep_scale"], group=Ho * Wo)
             else:
-                x = Pj
+                x, rec["project_bn"] = self._bn_fwd(Zp, Mout, cout, p + "_project_bn", ACT_NONE)
             tape["blocks"].append(rec)
             H, W = Ho, Wo
         HW = H * W
@@ -252,9 +260,7 @@ class EmbeddingTrainer:
         d = self._fc_bwd(tape["dense"], d)
         HW = tape["HW"]
         dAt = self.new(B * HW, 1280)
-        dAt.zero_()
-        _lib.check(self.L.mkws_op_add_bcast(self._p(dAt), self._p(d), 1.0 / HW, B, HW, 1280, self._s()))
-        dZt = self._bn_bwd(tape["top_bn"], dAt)
+        dZt = self._bn_bwd(tape["top_bn"], dAt, src=None, bcast=d, bscale=1.0 / HW, group=HW)       # the pooled gradient spread over the pixels on the fly
         d = self._conv_bwd(tape["top_in"], dZt, B * HW, 320, 1280, "top_conv/kernel")
         if allreduce:
             self._allreduce_range(self.tensors["top_conv/kernel"]["offset"], self.tensors["dense_1/kernel"]["offset"])
@@ -264,28 +270,26 @@ class EmbeddingTrainer:
             Min, Mout = B * H * W, B * Ho * Wo
             d_out = d
             if rec["residual"]:
-                dP = self.new(Mout, cout)
-                _lib.check(self.L.mkws_op_row_scale_add(self._p(d_out), self._p(rec["keep_scale"]), None, self._p(dP), B, Ho * Wo * cout, self._s()))
+                # drop-connect scale applied while the BN backward reads the gradient; d_out stays intact for the shortcut
+                dZp = self._bn_bwd(rec["project_bn"], self.new(Mout, cout), src=d_out, row_scale=rec["keep_scale"], group=Ho * Wo)
             else:
-                dP = d_out
-            dZp = self._bn_bwd(rec["project_bn"], dP)
+                dZp = self._bn_bwd(rec["project_bn"], d_out)
             dAs = self._conv_bwd(rec["As"], dZp, Mout, ce, cout, p + "_project_conv/kernel")
             dAd, dG = self.new(Mout, ce), self.new(B, ce)
             _lib.check(self.L.mkws_op_se_bwd(self._p(rec["Ad"]), self._p(rec["Gt"]), self._p(dAs), self._p(dAd), self._p(dG), B, Ho * Wo, ce, self._s()))
             dR = self._fc_bwd(rec["se_expand"], dG)
             dmean = self._fc_bwd(rec["se_reduce"], dR)
-            _lib.check(self.L.mkws_op_add_bcast(self._p(dAd), self._p(dmean), 1.0 / (Ho * Wo), B, Ho * Wo, ce, self._s()))
-            dZd = self._bn_bwd(rec["dw_bn"], dAd)
+            dZd = self._bn_bwd(rec["dw_bn"], dAd, bcast=dmean, bscale=1.0 / (Ho * Wo), group=Ho * Wo)     # + the squeeze's gradient, spread over the pixels
             dAe = self.new(Min, ce)
             _lib.check(self.L.mkws_op_dwconv_bwd(self._p(rec["Ae"]), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(dZd), self._p(dAe),
                                                  self._p(self.G(p + "_dwconv/depthwise_kernel")), B, H, W, ce, k, s, rec["pt"], rec["pl"], Ho, Wo, self._s()))
             if "expand_bn" in rec:
                 dZe = self._bn_bwd(rec["expand_bn"], dAe)
-                d_in = self._conv_bwd(rec["inp"], dZe, Min, cin, ce, p + "_expand_conv/kernel")
+                d_in = self._conv_bwd(rec["inp"], dZe, Min, cin, ce, p + "_expand_conv/kernel", add_into=d_out if rec["residual"] else None)
             else:
                 d_in = dAe
-            if rec["residual"]:
-                _lib.check(self.L.mkws_op_axpy(self._p(d_in), self._p(d_out), 1.0, d_in.numel(), self._s()))
+                if rec["residual"]:
+                    _lib.check(self.L.mkws_op_axpy(self._p(d_in), self._p(d_out), 1.0, d_in.numel(), self._s()))
             d = d_in
         dZ0 = self._bn_bwd(tape["stem_bn"], d)
         _lib.check(self.L.mkws_op_stem_bwd_weight(self._p(tape["spec"]), self._p(dZ0), self.norm_mean, self.norm_std, self._p(self.G("stem_conv/kernel")), B, self._s()))
