@@ -1505,34 +1505,47 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
 #endif
   // ---- gated projection (+ BN, residual): every weight fragment of the stream feeds this wave's MTW row tiles ----
   if (rlp < NWP && !MKWS_ABLATE(8)) {
-    const float* erow[MTW];
-    const float* grow[MTW];
+    // Row-tile lanes past MTO - NWP * (MTW - 1) own one row tile fewer: they run the MTW - 1 instantiation instead of multiplying a
+    // padding tile (3a: lane 1 used to stream a whole extra tile = 25 % of the projection's MFMA time on the busiest SIMDs).
+    constexpr int MT_LO = MTO / NWP;
+    const int my_tiles = (MTO - rlp + NWP - 1) / NWP;
+    auto run = [&](auto mt_tag) {
+      constexpr int MT = decltype(mt_tag)::value;
+      const float* erow[MT];
+      const float* grow[MT];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      int r = (rlp + NWP * m) * 16 + c;
-      if (r >= G * HoWo) r = G * HoWo - 1;                       // padding rows / tiles past the end: any finite row, never stored
-      erow[m] = s_D + (size_t)r * LDD + 4 * g;
-      grow[m] = s_gate + (size_t)(r / HoWo) * CEXP + 4 * g;
-    }
-    struct EG { f32x4 e, g; };
-    auto xload = [&](int j, int m) { return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow[m] + 16 * j)}; };
-    auto xmake = [](const EG& v) { return v.e * v.g; };
-    f32x4 acc[1][MTW];
+      for (int m = 0; m < MT; ++m) {
+        int r = (rlp + NWP * m) * 16 + c;
+        if (r >= G * HoWo) r = G * HoWo - 1;                     // padding rows of the last tile: any finite row, never stored
+        erow[m] = s_D + (size_t)r * LDD + 4 * g;
+        grow[m] = s_gate + (size_t)(r / HoWo) * CEXP + 4 * g;
+      }
+      struct EG { f32x4 e, g; };
+      auto xload = [&](int j, int m) { return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow[m] + 16 * j)}; };
+      auto xmake = [](const EG& v) { return v.e * v.g; };
+      f32x4 acc[1][MT];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) acc[0][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    stream_mfma<1, PD, MTW, true>(acc, wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC, xload, xmake);
-    const int n = ntp * 16 + 4 * g;
-    if (n < a.Cout) {
-      const f32x4 scp = *reinterpret_cast<const f32x4*>(a.scP + n), shp = *reinterpret_cast<const f32x4*>(a.shP + n);
+      for (int m = 0; m < MT; ++m) acc[0][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      stream_mfma<1, PD, MT, true>(acc, wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC, xload, xmake);
+      const int n = ntp * 16 + 4 * g;
+      if (n < a.Cout) {
+        const f32x4 scp = *reinterpret_cast<const f32x4*>(a.scP + n), shp = *reinterpret_cast<const f32x4*>(a.shP + n);
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const int r = (rlp + NWP * m) * 16 + c;
-        if (r < rows_out) {
-          f32x4 y = acc[0][m] * scp + shp;
-          if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + n);
-          *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+        for (int m = 0; m < MT; ++m) {
+          const int r = (rlp + NWP * m) * 16 + c;
+          if (r < rows_out) {
+            f32x4 y = acc[0][m] * scp + shp;
+            if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + n);
+            *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+          }
         }
       }
+    };
+    if constexpr (MT_LO >= 1 && MT_LO < MTW) {
+      if (my_tiles >= MTW) run(std::integral_constant<int, MTW>{});
+      else run(std::integral_constant<int, MT_LO>{});
+    } else {
+      run(std::integral_constant<int, MTW>{});
     }
   }
 #ifdef MKWS_FRONT_TIMING
@@ -1657,33 +1670,46 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_back_kernel(BackArgs a) {
   __syncthreads();
   // ---- gated projection (+ BN, residual) ----
   if (rlp < NWP) {
-    const float* erow[MTW];
+    // row-tile lanes that own one row tile fewer run the MTW - 1 instantiation instead of multiplying a padding tile (2a / 2b: three of
+    // the four lanes, a third of their MFMAs; 3b: lane 1, half of them)
+    constexpr int MT_LO = MTO / NWP;
+    const int my_tiles = (MTO - rlp + NWP - 1) / NWP;
+    auto run = [&](auto mt_tag) {
+      constexpr int MT = decltype(mt_tag)::value;
+      const float* erow[MT];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      int r = (rlp + NWP * m) * 16 + c;
-      if (r >= HOWO) r = HOWO - 1;                               // padding rows / tiles past the end: any finite row, never stored
-      erow[m] = s_D + (size_t)r * LDD + 4 * g;
-    }
-    const float* grow = s_gate + 4 * g;
-    struct EG { f32x4 e, g; };
-    auto xload = [&](int j, int m) { return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow + 16 * j)}; };
-    auto xmake = [](const EG& v) { return v.e * v.g; };
-    f32x4 acc[1][MTW];
+      for (int m = 0; m < MT; ++m) {
+        int r = (rlp + NWP * m) * 16 + c;
+        if (r >= HOWO) r = HOWO - 1;                               // padding rows of the last tile: any finite row, never stored
+        erow[m] = s_D + (size_t)r * LDD + 4 * g;
+      }
+      const float* grow = s_gate + 4 * g;
+      struct EG { f32x4 e, g; };
+      auto xload = [&](int j, int m) { return EG{*reinterpret_cast<const f32x4*>(erow[m] + 16 * j), *reinterpret_cast<const f32x4*>(grow + 16 * j)}; };
+      auto xmake = [](const EG& v) { return v.e * v.g; };
+      f32x4 acc[1][MT];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) acc[0][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    stream_mfma<1, PD, MTW, true>(acc, wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC, xload, xmake);
-    const int n = ntp * 16 + 4 * g;
-    if (n < a.Cout) {
-      const f32x4 scp = *reinterpret_cast<const f32x4*>(a.scP + n), shp = *reinterpret_cast<const f32x4*>(a.shP + n);
+      for (int m = 0; m < MT; ++m) acc[0][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      stream_mfma<1, PD, MT, true>(acc, wqp, p_w, (size_t)NTP * 256, ntp, 1, NTP, KC, xload, xmake);
+      const int n = ntp * 16 + 4 * g;
+      if (n < a.Cout) {
+        const f32x4 scp = *reinterpret_cast<const f32x4*>(a.scP + n), shp = *reinterpret_cast<const f32x4*>(a.shP + n);
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const int r = (rlp + NWP * m) * 16 + c;
-        if (r < HOWO) {
-          f32x4 y = acc[0][m] * scp + shp;
-          if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (b * HOWO + r) * a.Cin + n);
-          *reinterpret_cast<f32x4*>(a.Y + (b * HOWO + r) * a.Cout + n) = y;
+        for (int m = 0; m < MT; ++m) {
+          const int r = (rlp + NWP * m) * 16 + c;
+          if (r < HOWO) {
+            f32x4 y = acc[0][m] * scp + shp;
+            if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (b * HOWO + r) * a.Cin + n);
+            *reinterpret_cast<f32x4*>(a.Y + (b * HOWO + r) * a.Cout + n) = y;
+          }
         }
       }
+    };
+    if constexpr (MT_LO >= 1 && MT_LO < MTW) {
+      if (my_tiles >= MTW) run(std::integral_constant<int, MTW>{});
+      else run(std::integral_constant<int, MT_LO>{});
+    } else {
+      run(std::integral_constant<int, MTW>{});
     }
   }
   MKWS_WG_END();
