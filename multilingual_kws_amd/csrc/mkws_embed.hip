@@ -1909,6 +1909,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   const long long dbg_c0 = clock64();
   if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
 #endif
+  // phase A's weight stream does not depend on the input tile: its first fragments are requested before the staging, so that their L2
+  // round trip runs under the tile's HBM round trip instead of after it
+  constexpr int NTWA = (MT >= 3) ? 1 : 2;       // one weight fragment already feeds 4*MT MFMAs; finer runs balance the waves
+  const int a_groups = (a.NTe + NTWA - 1) / NTWA;
+  const int a_runs = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
+  f32x4 wqa[4][NTWA];
+  stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, a_runs, a.KCe, a_tile_of);
   // ---- stage the input tiles as fragments: s_X[j][m][lane] = X[row = 16m + c][16j + 4g .. +3]; epilogue constants ----
   for (int jm = wave; jm < a.KCe * MT; jm += NWAVES) {
     const int j = jm / MT, m = jm - j * MT;
@@ -1925,10 +1933,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 #endif
   // ---- phase A: expand ----
   {
-    constexpr int NTW = (MT >= 3) ? 1 : 2;        // one weight fragment already feeds 4*MT MFMAs; finer runs balance the waves
-    const int ngroups = (a.NTe + NTW - 1) / NTW;
-    const int nruns = (ngroups > wave) ? (ngroups - wave + NWAVES - 1) / NWAVES : 0;
-    auto tile_of = [&](int r) { return (wave + NWAVES * r) * NTW; };
+    constexpr int NTW = NTWA;
+    const int nruns = a_runs;
+    auto tile_of = a_tile_of;
     auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
     auto xmake = [](const f32x4& v) { return v; };
     auto epi = [&](int t0, const f32x4 (&acc)[NTW][MT]) {
@@ -1947,8 +1954,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
         }
       }
     };
-    f32x4 wqa[4][NTW];
-    stream_mfma_runs<NTW, 4, MT, false>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
+    stream_mfma_runs<NTW, 4, MT, true>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, nruns, a.KCe, tile_of, xload, xmake, epi);
   }
   __syncthreads();
 
