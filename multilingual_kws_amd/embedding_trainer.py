@@ -141,9 +141,9 @@ class EmbeddingTrainer:
         return Z
 
     def _conv_bwd(self, X, dZ, M, K, N, wname, need_dx=True, add_into=None):
-        """dW += X^T dZ (the long reduction over the rows is split by the library), dX = dZ W^T (+ add_into, in place: the shortcut's
+        """dW = X^T dZ (the long reduction over the rows is split by the library), dX = dZ W^T (+ add_into, in place: the shortcut's
         gradient of a residual block joins in the GEMM epilogue instead of a separate launch)."""
-        self.gemm(X, dZ, self.G(wname), K, N, M, K, N, N, ta=1, tb=0, acc=1)
+        self.gemm(X, dZ, self.G(wname), K, N, M, K, N, N, ta=1, tb=0, acc=0)     # every weight is used once per step: written, not accumulated
         if not need_dx:
             return None
         if add_into is not None:
@@ -250,7 +250,8 @@ class EmbeddingTrainer:
             raise RuntimeError("backward() needs a forward_train() first")
         B = tape["B"]
         self._bind_stream()
-        self.grads.zero_()
+        # (no memset of the 52 MB gradient blob: every trainable tensor's gradient is WRITTEN by exactly one operator per step, and the slots
+        #  of the non-trainable tensors -- moving statistics, normalisation constants -- are never touched after the zero-initialisation)
         self._pending = []
         d = d_emb.to(self.device, dtype=torch.float32).contiguous().clone()
         d = self._fc_bwd(tape["dense_2"], d)
