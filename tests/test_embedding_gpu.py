@@ -116,6 +116,8 @@ def test_full_batch_properties(ctx):
     assert torch.isfinite(emb).all()
     big = torch.cat([x, x[:100]])                                       # B > max_batch is chunked by the host wrapper
     assert torch.equal(ctx["em"].forward(big)[1024:], emb[:100])
+    for b in (257, 300, 777):          # persistent stem workgroups with unequal clip counts (some walk one clip more than others)
+        assert torch.equal(ctx["em"].forward(x[:b]), emb[:b]), b
 
 
 def test_uncalibrated_weights_and_bad_blobs(ctx):
