@@ -298,6 +298,14 @@ int mkws_op_set_scratch(float* d_scratch, size_t floats);
  * ksplit = 0 picks the split from the shapes and the arena size (small grids with a long K: ~512 workgroups). */
 int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
                  int accumulate, int ksplit, void* stream);
+/* Deferred second stages.  With enable = 1 the fixed-order folds whose results only the optimizer (or a gradient all-reduce) reads -- the
+ * split reduction of a weight-gradient GEMM (transA = 1), the bias gradient of mkws_op_bias_act_bwd, the weight gradients of
+ * mkws_op_dwconv_bwd / mkws_op_stem_bwd_weight -- are QUEUED (their partial sums stay in the scratch arena, handed out from a bump pointer)
+ * and run as ONE launch at mkws_op_fold_flush, at enable = 0, or when the queue (24 entries) or the arena is full.  Same sums in the same
+ * order: bit-identical results, ~90 launches fewer per training step.  Until the flush those outputs are not final.  Per host thread, like
+ * the scratch arena; capturable. */
+int mkws_op_fold_defer(int enable, void* stream);
+int mkws_op_fold_flush(void* stream);
 /* Dense / SE layer forward in one call: Z = X[M,K] . W[K,N] (kept: the backward pass differentiates the activation at Z + bias) and
  * A = act(Z + bias), the epilogue fused into the GEMM (or into its split-reduction fold). */
 int mkws_op_dense_fwd(const float* d_X, const float* d_W, const float* d_bias, int act, float* d_Z, float* d_A, int M, int N, int K, void* stream);

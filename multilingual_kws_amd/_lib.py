@@ -73,6 +73,8 @@ SYMBOLS = [
     ("mkws_head_adam_step_dev", _I, [_P, _F, _F, _F, _F, _P, _F, _P]),
     # training operators (backprop_into_embedding)
     ("mkws_op_set_scratch", _I, [_P, _SZ]),
+    ("mkws_op_fold_defer", _I, [_I, _P]),
+    ("mkws_op_fold_flush", _I, [_P]),
     ("mkws_op_bn_train_fwd", _I, [_P, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P]),
     ("mkws_op_bn_train_fwd_res", _I, [_P, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     ("mkws_op_step_inc", _I, [_P, _P]),

@@ -162,6 +162,26 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   out[i] = accumulate ? out[i] + v : v;
 }
 
+// Several deferred second stages in ONE launch (mkws_op_fold_defer): block b serves the descriptor whose block range holds b.  Each
+// output element is the same fixed-order sum the single-descriptor kernels (fold_partials_kernel, gemm_reduce_kernel without an epilogue)
+// compute: bit-identical results, one launch instead of up to kMaxFolds.
+constexpr int kMaxFolds = 24;
+struct FoldDesc { const float* part; float* out; int chunks, n, N, ldc; float scale; int accumulate; int block0; };
+struct FoldBatch { FoldDesc d[kMaxFolds]; int n; };
+__global__ __launch_bounds__(256) void fold_batch_kernel(FoldBatch fb) {
+  int k = 0;
+  for (int j = 1; j < fb.n; ++j)
+    if ((int)blockIdx.x >= fb.d[j].block0) k = j;
+  const FoldDesc& d = fb.d[k];
+  const int i = ((int)blockIdx.x - d.block0) * 256 + (int)threadIdx.x;
+  if (i >= d.n) return;
+  float v = d.part[i];
+  for (int z = 1; z < d.chunks; ++z) v += d.part[(size_t)z * d.n + i];
+  v *= d.scale;
+  const size_t o = (size_t)(i / d.N) * d.ldc + (i % d.N);
+  d.out[o] = d.accumulate ? d.out[o] + v : v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batch statistics of Z [M, C] per channel, two levels, fixed order.
 // Level 1 (grid: 64-channel slabs x row chunks, block = 64 channel lanes x 4 row lanes): every workgroup computes the mean of ITS
@@ -796,15 +816,56 @@ namespace {
 // Scratch arena for the partial sums of the fixed-order reductions: caller-owned device memory, set per host thread.
 thread_local float* g_scratch = nullptr;
 thread_local size_t g_scratch_floats = 0;
-inline float* scratch(size_t floats) { return (g_scratch && floats <= g_scratch_floats) ? g_scratch : nullptr; }
+inline float* scratch(size_t floats) { return (g_scratch && floats <= g_scratch_floats) ? g_scratch : nullptr; }   // capacity check (base of the arena)
+// Deferred second stages (mkws_op_fold_defer): their partial sums stay in the arena until the flush, so the arena is handed out from a
+// bump pointer while folds are queued; every operator takes its scratch through scratch_at(), which flushes when the arena is full.
+thread_local size_t g_bump = 0;                       // floats held by queued folds
+thread_local int g_defer = 0;
+thread_local FoldBatch g_fb;                          // g_fb.n descriptors queued
+thread_local int g_fold_blocks = 0;
+inline int fold_flush(hipStream_t s) {
+  if (g_fb.n > 0) hipLaunchKernelGGL(fold_batch_kernel, dim3(g_fold_blocks), dim3(256), 0, s, g_fb);
+  g_fb.n = 0; g_fold_blocks = 0; g_bump = 0;
+  return MKWS_OK;
+}
+inline float* scratch_at(size_t floats, hipStream_t s) {
+  if (!g_scratch || floats > g_scratch_floats) return nullptr;
+  if (g_bump + floats > g_scratch_floats) fold_flush(s);
+  return g_scratch + g_bump;
+}
+// second stage out[(i / N) * ldc + i % N] (+)= scale * sum_z part[z][i], i < n: queued when deferral is on, launched otherwise (returns false)
+inline bool fold_defer(const float* part, float* out, int chunks, int n, int N, int ldc, float scale, int accumulate, hipStream_t s) {
+  if (!g_defer) return false;
+  if (g_fb.n == kMaxFolds) { fold_flush(s); return false; }          // (the caller's partials sit at the old bump position: fold them now)
+  FoldDesc& d = g_fb.d[g_fb.n++];
+  d.part = part; d.out = out; d.chunks = chunks; d.n = n; d.N = N; d.ldc = ldc; d.scale = scale; d.accumulate = accumulate; d.block0 = g_fold_blocks;
+  g_fold_blocks += (n + 255) / 256;
+  g_bump += ((size_t)chunks * n + 63) & ~(size_t)63;
+  return true;
+}
 inline int row_chunks(int M, int cap) { int c = (M + 127) / 128; if (c > cap) c = cap; if (c < 1) c = 1; return c; }
 }  // namespace
 
 extern "C" {
 
 int mkws_op_set_scratch(float* d_scratch, size_t floats) {
+  if (d_scratch != g_scratch || floats != g_scratch_floats) { g_fb.n = 0; g_fold_blocks = 0; g_bump = 0; }      // a new arena: nothing is queued in it
   g_scratch = d_scratch;
   g_scratch_floats = d_scratch ? floats : 0;
+  return MKWS_OK;
+}
+
+int mkws_op_fold_defer(int enable, void* stream) {
+  if (enable) { g_fb.n = 0; g_fold_blocks = 0; g_bump = 0; }      // a new pass: whatever an aborted one left queued is dropped, not folded
+  else fold_flush(static_cast<hipStream_t>(stream));
+  g_defer = enable ? 1 : 0;
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_fold_flush(void* stream) {
+  fold_flush(static_cast<hipStream_t>(stream));
+  MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
 
@@ -826,7 +887,7 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
   }
   float* part = nullptr;
   if (ksplit > 1) {
-    part = scratch((size_t)ksplit * M * N);
+    part = scratch_at((size_t)ksplit * M * N, s);
     MKWS_REQ(part, "gemm: ksplit = %d needs %zu floats of scratch (mkws_op_set_scratch)", ksplit, (size_t)ksplit * M * N);
   }
   const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
@@ -837,7 +898,9 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
   else if (!transB) MKWS_TG(true, false);
   else MKWS_TG(true, true);
 #undef MKWS_TG
-  if (ksplit > 1) hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, s, part, ksplit, C, M, N, ldc, accumulate, bias, act, Act);
+  // the fold of a weight-gradient GEMM (transA, no epilogue) may wait for the batch launch: nobody reads dW before the optimizer / all-reduce
+  if (ksplit > 1 && !(transA && !Act && fold_defer(part, C, ksplit, M * N, N, ldc, 1.0f, accumulate, s)))
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, s, part, ksplit, C, M, N, ldc, accumulate, bias, act, Act);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -855,7 +918,7 @@ int mkws_op_dense_fwd(const float* X, const float* W, const float* bias, int act
 static int bn_stats_impl(const float* Z, int M, int C, float* mean, float* var, float* mmean, float* mvar, float momentum, hipStream_t s) {
   MKWS_REQ(C % 4 == 0, "bn_stats: C must be a multiple of 4");
   const int chunks = row_chunks(M, 128);
-  float* part = scratch((size_t)chunks * 2 * C);
+  float* part = scratch_at((size_t)chunks * 2 * C, s);
   MKWS_REQ(part, "bn_stats: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, part, M, C);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, chunks, M, C, mean, var, mmean, mvar, momentum);
@@ -880,7 +943,7 @@ int mkws_op_bn_train_fwd_res(const float* Z, int M, int C, const float* gamma, c
   MKWS_REQ(C % 4 == 0, "bn_train_fwd: C must be a multiple of 4");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int chunks = row_chunks(M, 128);
-  float* part = scratch((size_t)chunks * 2 * C);
+  float* part = scratch_at((size_t)chunks * 2 * C, s);
   MKWS_REQ(part, "bn_train_fwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, part, M, C);
   hipLaunchKernelGGL(bn_train_fwd_kernel, dim3((C + 63) / 64, row_chunks(M, 256)), dim3(256), 0, s, Z, part, chunks, gamma, beta, eps, act, momentum, moving_mean,
@@ -913,7 +976,7 @@ int mkws_op_bn_act_bwd_ex(const float* Z, const float* mean, const float* var, c
   hipStream_t s = static_cast<hipStream_t>(stream);
   MKWS_REQ(C % 4 == 0, "bn_act_bwd: C must be a multiple of 4");
   const int chunks = row_chunks(M, 128);
-  float* part = ::scratch((size_t)chunks * 2 * C);
+  float* part = scratch_at((size_t)chunks * 2 * C, s);
   MKWS_REQ(part, "bn_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
   (void)scratch;                                       // (the 2*C-float argument of round 2's atomics path; kept in the signature)
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, part, M, C, src, row_scale, bcast,
@@ -944,12 +1007,13 @@ int mkws_op_dwconv_bwd(const float* X, const float* W, const float* dZ, float* d
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dX) hipLaunchKernelGGL(dw_bwd_input_kernel, dim3(grid_for((size_t)B * H * Wd * (C / 4))), dim3(256), 0, st, dZ, W, dX, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
   int chunks = (B * Ho * Wo + 127) / 128; if (chunks > 128) chunks = 128; if (chunks < 1) chunks = 1;
-  float* part = scratch((size_t)chunks * k * k * C);
+  float* part = scratch_at((size_t)chunks * k * k * C, st);
   MKWS_REQ(part, "dwconv_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * k * k * C);
   const dim3 grid((C / 4 + 15) / 16, chunks);
   if (k == 3) hipLaunchKernelGGL((dw_bwd_weight_kernel<3>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   else hipLaunchKernelGGL((dw_bwd_weight_kernel<5>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((k * k * C + 255) / 256), dim3(256), 0, st, part, chunks, k * k * C, dW, 1.0f, 0);
+  if (!fold_defer(part, dW, chunks, k * k * C, k * k * C, k * k * C, 1.0f, 0, st))
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((k * k * C + 255) / 256), dim3(256), 0, st, part, chunks, k * k * C, dW, 1.0f, 0);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -965,10 +1029,10 @@ int mkws_op_stem_bwd_weight(const float* spec, const float* dZ, float norm_mean,
   MKWS_REQ(spec && dZ && dW && B > 0, "stem_bwd_weight: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
   int blocks = (B * 500 + 255) / 256; if (blocks > 256) blocks = 256;
-  float* part = scratch((size_t)blocks * 288);
+  float* part = scratch_at((size_t)blocks * 288, s);
   MKWS_REQ(part, "stem_bwd_weight: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)blocks * 288);
   hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, dZ, norm_mean, norm_std, part, B);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(2), dim3(256), 0, s, part, blocks, 288, dW, 1.0f, 0);
+  if (!fold_defer(part, dW, blocks, 288, 288, 288, 1.0f, 0, s)) hipLaunchKernelGGL(fold_partials_kernel, dim3(2), dim3(256), 0, s, part, blocks, 288, dW, 1.0f, 0);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -1013,11 +1077,11 @@ int mkws_op_bias_act_bwd(const float* Z, const float* bias, int act, float* dA, 
   MKWS_REQ(Z && bias && dA && dbias && M > 0 && N > 0, "bias_act_bwd: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
   int chunks = (M + 63) / 64; if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
-  float* part = scratch((size_t)chunks * N);
+  float* part = scratch_at((size_t)chunks * N, s);
   MKWS_REQ(part, "bias_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * N);
   // one pass: dA <- dA * act'(Z + bias) in place and this chunk's column sums; then the chunks fold in order into dbias
   hipLaunchKernelGGL((col_sum_partial_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, dA, Z, bias, act, part, M, N);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, chunks, N, dbias, 1.0f, 0);
+  if (!fold_defer(part, dbias, chunks, N, N, N, 1.0f, 0, s)) hipLaunchKernelGGL(fold_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, chunks, N, dbias, 1.0f, 0);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

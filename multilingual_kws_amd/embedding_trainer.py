@@ -250,6 +250,9 @@ class EmbeddingTrainer:
             raise RuntimeError("backward() needs a forward_train() first")
         B = tape["B"]
         self._bind_stream()
+        # second stages of the gradient reductions wait in a queue and run a batch at a time (mkws_op_fold_defer): nobody reads a weight
+        # gradient before the all-reduce / the optimizer
+        _lib.check(self.L.mkws_op_fold_defer(1, self._s()))
         # (no memset of the 52 MB gradient blob: every trainable tensor's gradient is WRITTEN by exactly one operator per step, and the slots
         #  of the non-trainable tensors -- moving statistics, normalisation constants -- are never touched after the zero-initialisation)
         self._pending = []
@@ -294,6 +297,7 @@ class EmbeddingTrainer:
             d = d_in
         dZ0 = self._bn_bwd(tape["stem_bn"], d)
         _lib.check(self.L.mkws_op_stem_bwd_weight(self._p(tape["spec"]), self._p(dZ0), self.norm_mean, self.norm_std, self._p(self.G("stem_conv/kernel")), B, self._s()))
+        _lib.check(self.L.mkws_op_fold_defer(0, self._s()))           # flush: every gradient is final from here on
         if allreduce:
             self._allreduce_range(0, self.tensors["top_conv/kernel"]["offset"])
             for h in self._pending:
@@ -303,6 +307,7 @@ class EmbeddingTrainer:
 
     def _allreduce_range(self, lo, hi):
         import torch.distributed as dist
+        _lib.check(self.L.mkws_op_fold_flush(self._s()))               # the range's gradients must be final before the collective reads them
         if dist.is_available() and dist.is_initialized():
             self._pending.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
