@@ -963,22 +963,20 @@ int mkws_op_bn_act_fwd(const float* Z, const float* mean, const float* var, cons
 
 int mkws_op_bn_act_bwd(const float* Z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, float* dA, float* dgamma,
                        float* dbeta, float* scratch, int M, int C, void* stream) {
-  MKWS_REQ(scratch, "bn_act_bwd: bad arguments");
+  MKWS_REQ(scratch, "bn_act_bwd: bad arguments");       // (the 2*C-float argument of round 2's atomics path; kept in the signature, unused)
   return mkws_op_bn_act_bwd_ex(Z, mean, var, gamma, beta, eps, act, dA, dA, nullptr, nullptr, 0.0f, 1, dgamma, dbeta, M, C, stream);
 }
 
 int mkws_op_bn_act_bwd_ex(const float* Z, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, float* dA,
                           const float* src, const float* row_scale, const float* bcast, float bscale, int group, float* dgamma, float* dbeta, int M, int C,
                           void* stream) {
-  float* scratch = dA;                                 // (placeholder for the check below; the partial sums live in the scratch arena)
   MKWS_REQ(group > 0 && (src || bcast), "bn_act_bwd_ex: needs an incoming gradient (src and / or bcast) and a positive group");
-  MKWS_REQ(Z && mean && var && gamma && beta && dA && dgamma && dbeta && scratch && M > 0 && C > 0, "bn_act_bwd: bad arguments");
+  MKWS_REQ(Z && mean && var && gamma && beta && dA && dgamma && dbeta && M > 0 && C > 0, "bn_act_bwd: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
   MKWS_REQ(C % 4 == 0, "bn_act_bwd: C must be a multiple of 4");
   const int chunks = row_chunks(M, 128);
   float* part = scratch_at((size_t)chunks * 2 * C, s);
   MKWS_REQ(part, "bn_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
-  (void)scratch;                                       // (the 2*C-float argument of round 2's atomics path; kept in the signature)
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, part, M, C, src, row_scale, bcast,
                      bscale, group);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((C + 63) / 64, row_chunks(M, 256)), dim3(256), 0, s, Z, mean, var, gamma, eps, dA, part, chunks, dgamma, dbeta, M, C);
