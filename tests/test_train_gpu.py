@@ -60,6 +60,82 @@ def test_gemm_all_transposes(ops, M, N, K, ta, tb, ks):
         assert _rel(C.cpu().numpy(), 2 * ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,HW,C,act", [(6, 35, 40, 0), (5, 130, 24, 1)])
+def test_batchnorm_fused_residual_and_gradient_assembly(ops, B, HW, C, act):
+    """mkws_op_bn_train_fwd_res / mkws_op_bn_act_bwd_ex = the unfused operator sequences (row_scale_add, add_bcast + bn_act_bwd)."""
+    ops.check(ops.L.mkws_op_set_scratch(ops.p(ops.scratch), ops.scratch.numel()))
+    rng = np.random.default_rng(B * HW + C)
+    M = B * HW
+    Z, X = ops.t(rng.standard_normal((M, C))), ops.t(rng.standard_normal((M, C)))
+    g, b = ops.t(rng.uniform(0.5, 1.5, C)), ops.t(0.1 * rng.standard_normal(C))
+    keep = ops.t((rng.random(B) > 0.3) / 0.7)
+    new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=ops.dev)
+
+    def stats():
+        return ops.t(np.zeros(C)), ops.t(np.ones(C)), new(C), new(C)
+    mm, mv, mean, var = stats()
+    A = new(M, C)
+    ops.check(ops.L.mkws_op_bn_train_fwd(ops.p(Z), M, C, ops.p(g), ops.p(b), 1e-3, act, 0.99, ops.p(mm), ops.p(mv), ops.p(mean), ops.p(var), ops.p(A), ops.s()))
+    ref = new(M, C)
+    ops.check(ops.L.mkws_op_row_scale_add(ops.p(A), ops.p(keep), ops.p(X), ops.p(ref), B, HW * C, ops.s()))
+    mm2, mv2, mean2, var2 = stats()
+    out = new(M, C)
+    ops.check(ops.L.mkws_op_bn_train_fwd_res(ops.p(Z), M, C, ops.p(g), ops.p(b), 1e-3, act, 0.99, ops.p(mm2), ops.p(mv2), ops.p(mean2), ops.p(var2), ops.p(out),
+                                             ops.p(X), ops.p(keep), HW, ops.s()))
+    assert torch.equal(mean2, mean) and torch.equal(var2, var) and torch.equal(mm2, mm) and torch.equal(mv2, mv)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    # backward: incoming gradient = src * keep[row // HW] + bcast[row // HW] / HW, assembled inside the first launch
+    src, bc = ops.t(rng.standard_normal((M, C))), ops.t(rng.standard_normal((B, C)))
+    dA = new(M, C)
+    ops.check(ops.L.mkws_op_row_scale_add(ops.p(src), ops.p(keep), None, ops.p(dA), B, HW * C, ops.s()))
+    ops.check(ops.L.mkws_op_add_bcast(ops.p(dA), ops.p(bc), 1.0 / HW, B, HW, C, ops.s()))
+    gg, gb, scr = new(C), new(C), new(2 * C)
+    ops.check(ops.L.mkws_op_bn_act_bwd(ops.p(Z), ops.p(mean), ops.p(var), ops.p(g), ops.p(b), 1e-3, act, ops.p(dA), ops.p(gg), ops.p(gb), ops.p(scr), M, C, ops.s()))
+    keep_src = src.clone()
+    d2, gg2, gb2 = new(M, C), new(C), new(C)
+    ops.check(ops.L.mkws_op_bn_act_bwd_ex(ops.p(Z), ops.p(mean), ops.p(var), ops.p(g), ops.p(b), 1e-3, act, ops.p(d2), ops.p(src), ops.p(keep), ops.p(bc), 1.0 / HW, HW,
+                                          ops.p(gg2), ops.p(gb2), M, C, ops.s()))
+    assert torch.equal(src, keep_src)                                   # the source gradient stays intact (the shortcut still needs it)
+    for got, want in ((d2, dA), (gg2, gg), (gb2, gb)):
+        assert _rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    # neither a source nor a broadcast term: refused
+    assert ops.L.mkws_op_bn_act_bwd_ex(ops.p(Z), ops.p(mean), ops.p(var), ops.p(g), ops.p(b), 1e-3, act, ops.p(d2), None, None, None, 0.0, HW, ops.p(gg2), ops.p(gb2), M, C,
+                                       ops.s()) < 0
+
+
+def test_deferred_folds_are_bit_identical(ops):
+    """mkws_op_fold_defer: queued second stages (weight-gradient GEMM, bias / depthwise / stem gradient folds) = the immediate ones, bit for bit,
+    also when the queue overflows (more than 24 entries) and when a flush comes in between."""
+    ops.check(ops.L.mkws_op_set_scratch(ops.p(ops.scratch), ops.scratch.numel()))
+    rng = np.random.default_rng(11)
+    new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=ops.dev)
+    M, K, N = 4000, 24, 96
+    X, dZ = ops.t(rng.standard_normal((M, K))), ops.t(rng.standard_normal((M, N)))
+    Zb, bias = ops.t(rng.standard_normal((M, N))), ops.t(rng.standard_normal(N))
+    B, H, W, C, k = 8, 13, 10, 48, 3
+    Xd, Wd, dZd = ops.t(rng.standard_normal((B * H * W, C))), ops.t(rng.standard_normal((k * k, C))), ops.t(rng.standard_normal((B * H * W, C)))
+
+    def run(defer, rounds):
+        outs = []
+        ops.check(ops.L.mkws_op_fold_defer(1 if defer else 0, ops.s()))
+        for r in range(rounds):
+            dW, db, dWd = new(K, N), new(N), new(k * k, C)
+            dA = dZ.clone()
+            ops.check(ops.L.mkws_op_gemm(ops.p(X), ops.p(dZ), ops.p(dW), K, N, M, K, N, N, 1, 0, 0, 0, ops.s()))
+            ops.check(ops.L.mkws_op_bias_act_bwd(ops.p(Zb), ops.p(bias), 1, ops.p(dA), ops.p(db), M, N, ops.s()))
+            ops.check(ops.L.mkws_op_dwconv_bwd(ops.p(Xd), ops.p(Wd), ops.p(dZd), None, ops.p(dWd), B, H, W, C, k, 1, 1, 1, H, W, ops.s()))
+            if defer and r == 3:
+                ops.check(ops.L.mkws_op_fold_flush(ops.s()))
+            outs += [dW, db, dWd]
+        ops.check(ops.L.mkws_op_fold_defer(0, ops.s()))
+        torch.cuda.synchronize()
+        return outs
+    ref = run(False, 12)
+    got = run(True, 12)                                                # 36 folds: the 24-entry queue overflows once, plus one explicit flush
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    assert all(torch.isfinite(t).all() for t in got)
+
+
 @pytest.mark.parametrize("M,C,act", [(1000, 32, 1), (48, 240, 1), (96, 24, 0), (4000, 96, 1)])
 def test_batchnorm_train_forward_backward(ops, M, C, act):
     rng = np.random.default_rng(C)
