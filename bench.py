@@ -217,6 +217,19 @@ def embed_roofline(em, spec, B, reps, arch, extra=None):
             cost = costs["stem_block1a"]
         elif kernel.startswith("mbconv_front"):
             cost = costs[stage.replace("_dw", "_front")]
+        elif stage.startswith("chain:"):
+            # depth-fused launch: the algorithmic work of its blocks; bytes = chain input + output + every weight once (inner activations stay in LDS)
+            names = stage[len("chain:"):].split(",")
+            fl = sum(costs["block" + n + "_block"][0] for n in names)
+            act = {n: (ci, co, s_) for n, ci, co, _, s_, _ in arch.BLOCKS}
+            by = sum(costs["block" + n + "_block"][1] for n in names)
+            for a_, b_ in zip(names[:-1], names[1:]):
+                m = B * 12
+                co = act[a_][1]
+                by -= 4 * m * co * 2                                    # a_'s output store + b_'s input load
+                if act[b_][2] == 1 and act[b_][0] == act[b_][1]:
+                    by -= 4 * m * co                                    # b_'s residual re-read
+            cost = (fl, by)
         elif kernel.startswith("mbconv_block") or kernel.startswith("mbconv_mid") or kernel.startswith("mbconv_pair"):
             cost = costs[stage + "_block"]
         else:

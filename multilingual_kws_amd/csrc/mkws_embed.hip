@@ -2175,6 +2175,369 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depth-fused chain of whole-block kernels for the 4x3-image blocks (4b -> 4c -> 5a -> 5b -> 5c -> 6a): ONE launch.
+// In mbconv_block_kernel a workgroup owns the same G clips in every one of these blocks and nothing crosses workgroups, so
+// the launch boundaries between them were pure overhead: 2-3 us of start / end skew each, the input tile's HBM round trip
+// and staging pass (~2 us), and a phase A that starts on an empty weight ring.  Here the workgroup walks the blocks itself:
+//   * block k's projection epilogue writes its output tile straight into the U region as block k + 1's MFMA B-operand
+//     fragments (the lane that holds output channels 16t + 4g .. +3 of row 16m + c IS lane (g, c) of fragment (j = t, m):
+//     a lane-linear ds_write_b128, no transpose) -- the activations of the chain never leave the CU;
+//   * the same lane finishes the same (tile, row tile) in the next block (Cin == Cout whenever a block has a residual), so
+//     the residual rides in registers (carry) instead of being re-read;
+//   * block k + 1's expand ring and BN constants are requested while block k's gate / projection phases run.
+// Only the chain's input and its last block's output touch HBM (the launcher stops the chain at a tapped block, so the
+// parity taps see the chain's own arithmetic).  Same operations in the same order as mbconv_block_kernel: bit-identical.
+constexpr int kChainMax = 6;
+// The per-block constants (weight pointers, sizes) live in a device table built once per handle (a by-value array indexed with the
+// loop counter would be copied to scratch); the uniform loads below are scalar loads.
+struct ChainArgs {
+  const BlockArgs* tab;       // [kNumBlocks] in device memory: X / Y / dbg pointers null, B unused
+  int i0, n;                  // blocks i0 .. i0 + n - 1 of the plan
+  unsigned kinds;             // 2 bits per chain position: 0 = 3x3 stride 1, 1 = 5x5 stride 1, 2 = 5x5 stride 2 (last block only: the image shrinks to 2x2)
+  const float* X; float* Y;   // the chain's input and its last block's output
+  int B;
+  int ldsU, ldsE;             // LDS carve in floats, the maximum over the chain's blocks (Z follows E)
+};
+
+template <int KS, int S, int MT, int NWAVES>
+__device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs* nx, float* s_blk, int ldsU, int ldsE, bool first,
+                                            f32x4 (&wqa)[4][(MT >= 3) ? 1 : 2], f32x4 (&carry)[MT]) {
+  constexpr int NTHR = NWAVES * 64;
+  constexpr int HT = 4, WT = 3, HW = HT * WT;
+  constexpr int G = MT * 16 / HW;
+  constexpr int HoT = (S == 1) ? HT : 2, WoT = (S == 1) ? WT : 2;
+  constexpr int HoWo = HoT * WoT;
+  constexpr int MTO = (G * HoWo + 15) / 16;
+  constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+  constexpr int LDR = 52;
+  constexpr int NTWA = (MT >= 3) ? 1 : 2;
+  const int Cexp = a.Cexp, LDE = Cexp + 4;
+  const int KCx = Cexp / 16;
+  float* s_X = s_blk;
+  float* s_S = s_blk;
+  float* s_G = s_S + G * Cexp;
+  float* s_P = s_G;
+  float* s_E = s_blk + ldsU;
+  float* s_scE = s_E + ldsE;
+  float* s_shE = s_scE + Cexp;
+  float* s_R = s_scE;
+  float* s_be = s_R + 16 * LDR;
+  // opaque: per-thread index arithmetic must be recomputed in every block (hoisted out of the block loop it is spilled, and a scratch
+  // reload inside a ring epilogue drains the in-order weight ring)
+  const int tid = opaque_((int)threadIdx.x), lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const unsigned loff = (unsigned)(g * 64 + c * 4);
+  const int b0 = blockIdx.x * G;
+  const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
+  const int rows_in = gvalid * HW, rows_out = gvalid * HoWo;
+  const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
+
+  // ---- phase A: expand.  The input fragments are in s_X and the first ring slots in flight (kernel prologue / previous block) ----
+  const int a_groups = (a.NTe + NTWA - 1) / NTWA;
+  const int a_runs = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
+  {
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
+    auto xmake = [](const f32x4& v) { return v; };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTWA][MT]) {
+#pragma unroll
+      for (int q = 0; q < NTWA; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < a.NTe) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(s_scE + n), sh = *reinterpret_cast<const f32x4*>(s_shE + n);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 y = acc[q][m] * sc + sh;
+            y = swish4_(y);
+            if (m * 16 + c >= rows_in) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(s_E + (size_t)(m * 16 + c) * LDE + n) = y;
+          }
+        }
+      }
+    };
+    stream_mfma_runs<NTWA, 4, MT, true>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, a_runs, a.KCe, a_tile_of, xload, xmake, epi);
+  }
+  __syncthreads();
+
+  // ---- phase B: depthwise (+BN+swish) in place + SE means (see mbconv_block_kernel) ----
+  for (int i = tid; i < Cexp; i += NTHR) s_be[i] = a.be[i];
+  const int c1_per = (KCx + NWAVES - 1) / NWAVES;
+  const int c1_j0 = wave * c1_per;
+  const int c1_kc = (c1_j0 + c1_per <= KCx) ? c1_per : (KCx > c1_j0 ? KCx - c1_j0 : 0);
+  const WBuf c1_w(a.WrP + (size_t)c1_j0 * a.NTR * 256, loff);
+  f32x4 wq1[3][3];
+  // (the 5x5 depthwise holds 12 inputs + 12 outputs + its taps per thread: C1's ring is requested behind it, not in front)
+  if (KS == 3) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  {
+    const int Q = Cexp / 4;
+    for (int task = tid; task < G * Q; task += NTHR) {
+      const int gi = task / Q, q4 = (task - gi * Q) * 4;
+      float* Eg = s_E + (size_t)gi * HW * LDE + q4;
+      f32x4 ein[HW];
+#pragma unroll
+      for (int pix = 0; pix < HW; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(Eg + (size_t)pix * LDE);
+      f32x4 acc[HoWo];
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) {
+          bool used = false;
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+            }
+          if (!used) continue;
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + q4);
+#pragma unroll
+          for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WoT; ++ow) {
+              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv;
+            }
+        }
+      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + q4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + q4);
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) {
+        f32x4 y = acc[o] * sc + sh;
+        y = swish4_(y);
+        if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Eg + (size_t)o * LDE) = y;
+        ssum += y;
+      }
+      *reinterpret_cast<f32x4*>(s_S + (size_t)gi * Cexp + q4) = ssum * (1.0f / (float)HoWo);
+    }
+  }
+  if (KS != 3) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  __syncthreads();
+
+  // ---- phase C1: r^T[se, clips] = Wr^T . mean^T, K = Cexp split over the waves ----
+  constexpr int NTW2 = 3;
+  const int c2_groups = (KCx + NTW2 - 1) / NTW2;
+  const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto c2_tile_of = [&](int r) { return (wave + NWAVES * r) * NTW2; };
+  f32x4 wq2[3][NTW2];
+  {
+    f32x4 acc[3][1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* srow = s_S + (size_t)(c < G ? c : 0) * Cexp + 16 * c1_j0 + 4 * g;
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
+    stream_mfma_runs_prefetch<NTW2, 3>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);
+    if (c < G) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+    }
+  }
+  const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
+  __syncthreads();
+  for (int t = tid; t < 48 * G; t += NTHR) {
+    const int n = t / G, clip = t - n * G;
+    float v = 0.0f;
+    if (n < a.se) {
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * G + clip];
+      v = swishf_(v + br_pre);
+    }
+    s_R[clip * LDR + n] = v;
+  }
+  __syncthreads();
+
+  // ---- phase C2: gate; phase D's weight stream is requested first (see mbconv_block_kernel for the row split) ----
+  const bool d_rowsplit = (a.NTp == NWAVES / 2 + 1) && (MTO > 1) && (MTO <= NWAVES / 2 - 1);
+  const int d_ntw = d_rowsplit ? ((wave < NWAVES / 2) ? 1 : 0) : ((a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0);
+  const int d_row = (d_rowsplit && wave >= NWAVES / 2 && wave < NWAVES / 2 + MTO) ? wave - NWAVES / 2 : -1;
+  const WBuf d_w(a.WpP, loff);
+  f32x4 wqd[4][3];
+  if (d_ntw > 0 || d_row >= 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);
+  {
+    const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
+#pragma unroll
+      for (int q = 0; q < NTW2; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < KCx && c < G) {
+          f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
+          y = sigmoid4_(y);
+          *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
+        }
+      }
+    };
+    stream_mfma_runs<NTW2, 3, 1, true>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
+  }
+  __syncthreads();
+
+  // ---- gate the depthwise output in place; the NEXT block's expand BN constants travel under it (Z is free from here on) ----
+  constexpr int NCST = 3;                                       // Cexp <= NCST * NTHR (host-checked)
+  float nsc[NCST], nsh[NCST];
+  const int nxCexp = nx ? nx->Cexp : 0;
+  if (nx) {
+    const float* nscE = nx->scE; const float* nshE = nx->shE;
+#pragma unroll
+    for (int k = 0; k < NCST; ++k) {
+      const int i = tid + k * NTHR;
+      if (i < nxCexp) { nsc[k] = nscE[i]; nsh[k] = nshE[i]; }
+    }
+  }
+  {
+    const int Q = Cexp / 4;
+    for (int i = tid; i < G * HoWo * Q; i += NTHR) {
+      const int ro = i / Q, q4 = (i - ro * Q) * 4;
+      const int clip = ro / HoWo;
+      float* e = s_E + (size_t)(clip * HW + (ro - clip * HoWo)) * LDE + q4;
+      *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)clip * Cexp + q4);
+    }
+  }
+  if (nx) {
+#pragma unroll
+    for (int k = 0; k < NCST; ++k) {
+      const int i = tid + k * NTHR;
+      if (i < nxCexp) { s_scE[i] = nsc[k]; s_scE[nxCexp + i] = nsh[k]; }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase D: gated project (+ residual).  The next block's expand ring is requested first; the output tile becomes the
+  //      next block's input fragments in U (free since the gate was applied) and this lane's residual (carry) ----
+  if (nx) {
+    const int nNTe = nx->NTe, nKCe = nx->KCe;
+    const int n_groups = (nNTe + NTWA - 1) / NTWA;
+    const int n_runs = (n_groups > wave) ? (n_groups - wave + NWAVES - 1) / NWAVES : 0;
+    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(nx->WpE, loff), (size_t)nNTe * 256, nNTe, n_runs, nKCe, a_tile_of);
+  }
+  {
+    const size_t cstride = (size_t)a.NTp * 256;
+    const float* erow[MTO];
+#pragma unroll
+    for (int m = 0; m < MTO; ++m) {
+      int r = m * 16 + c;
+      if (r >= G * HoWo) r = G * HoWo - 1;
+      const int clip = r / HoWo;
+      erow[m] = s_E + (size_t)(clip * HW + (r - clip * HoWo)) * LDE + 4 * g;
+    }
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(erow[m] + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    // one finished output fragment: tile t, row tile m (slot = its index in carry)
+    auto finish = [&](f32x4 y, int t, int m, int slot, const f32x4& sc, const f32x4& sh) {
+      const int n = t * 16 + 4 * g, r = m * 16 + c;
+      y = y * sc + sh;
+      if (a.residual) {
+        if (first) { if (r < rows_out) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + n); }
+        else y += carry[slot];
+      }
+      if (nx) {
+        if constexpr (S == 1) {
+          if (r >= rows_out) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+          carry[slot] = y;
+          *reinterpret_cast<f32x4*>(s_X + ((size_t)(t * MT + m) * 64 + lane) * 4) = y;
+        }
+      } else if (r < rows_out) {
+        *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+      }
+    };
+    auto run = [&](auto ntw_tag) {
+      constexpr int NTW = decltype(ntw_tag)::value;
+      f32x4 acc[NTW][MTO];
+#pragma unroll
+      for (int q = 0; q < NTW; ++q)
+#pragma unroll
+        for (int m = 0; m < MTO; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      stream_mfma<NTW, 4, MTO, true>(acc, wqd, d_w, cstride, wave, NWAVES, a.NTp, KCx, xload, xmake);
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        const int t = wave + NWAVES * q;
+        if (t < a.NTp) {
+          const int n = t * 16 + 4 * g;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scP + n), sh = *reinterpret_cast<const f32x4*>(a.shP + n);
+#pragma unroll
+          for (int m = 0; m < MTO; ++m) finish(acc[q][m], t, m, (NTW == 1) ? m : 0, sc, sh);
+        }
+      }
+    };
+    if (d_row >= 0) {
+      const float* er = erow[0];
+#pragma unroll
+      for (int m = 1; m < MTO; ++m) er = (d_row == m) ? erow[m] : er;
+      auto xload1 = [&](int j, int) { return *reinterpret_cast<const f32x4*>(er + 16 * j); };
+      f32x4 acc1[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
+      stream_mfma<1, 4, 1, true>(acc1, wqd, d_w, cstride, a.NTp - 1, NWAVES, a.NTp, KCx, xload1, xmake);
+      const int n = (a.NTp - 1) * 16 + 4 * g;
+      finish(acc1[0][0], a.NTp - 1, d_row, 0, *reinterpret_cast<const f32x4*>(a.scP + n), *reinterpret_cast<const f32x4*>(a.shP + n));
+    } else if (d_ntw == 1) run(std::integral_constant<int, 1>{});
+    else if (d_ntw == 2) run(std::integral_constant<int, 2>{});
+    else if (d_ntw >= 3) run(std::integral_constant<int, 3>{});
+  }
+  if (nx) __syncthreads();
+}
+
+template <int MT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca) {
+  extern __shared__ __attribute__((aligned(16))) float s_blk[];
+  constexpr int NTHR = NWAVES * 64;
+  constexpr int HW = 12, G = MT * 16 / HW;
+  constexpr int NTWA = (MT >= 3) ? 1 : 2;
+  const BlockArgs* __restrict__ tab = ca.tab + ca.i0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const unsigned loff = (unsigned)(g * 64 + c * 4);
+  f32x4 wqa[4][NTWA];
+  f32x4 carry[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) carry[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    // prologue = the head of mbconv_block_kernel: first block's expand ring, then its input tile and BN constants
+    const int Cin = tab[0].Cin, KCe = tab[0].KCe, NTe = tab[0].NTe, Cexp = tab[0].Cexp;
+    const int b0 = blockIdx.x * G;
+    const int gvalid = (ca.B - b0 < G) ? (ca.B - b0) : G;
+    const int rows_in = gvalid * HW;
+    const size_t row0_in = (size_t)b0 * HW;
+    const int a_groups = (NTe + NTWA - 1) / NTWA;
+    const int a_runs = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
+    auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
+    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(tab[0].WpE, loff), (size_t)NTe * 256, NTe, a_runs, KCe, a_tile_of);
+    float* s_X = s_blk;
+    float* s_scE = s_blk + ca.ldsU + ca.ldsE;
+    for (int jm = wave; jm < KCe * MT; jm += NWAVES) {
+      const int j = jm / MT, m = jm - j * MT;
+      const int r = m * 16 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows_in && 16 * j + 4 * g < Cin) v = *reinterpret_cast<const f32x4*>(ca.X + (row0_in + r) * Cin + 16 * j + 4 * g);
+      *reinterpret_cast<f32x4*>(s_X + ((size_t)jm * 64 + lane) * 4) = v;
+    }
+    const float* scE = tab[0].scE; const float* shE = tab[0].shE;
+    for (int i = tid; i < Cexp; i += NTHR) { s_scE[i] = scE[i]; s_scE[Cexp + i] = shE[i]; }
+    __syncthreads();
+  }
+  for (int i = 0; i < ca.n; ++i) {
+    BlockArgs a = tab[i];
+    const bool last = (i + 1 == ca.n);
+    a.X = ca.X; a.Y = ca.Y; a.B = ca.B;                       // X is read by the first block only (residual), Y written by the last
+    a.dbg_dw = nullptr; a.dbg_gate = nullptr;                // ("_dw" / "_gate" taps of a block run mbconv_block_kernel: the launcher ends the chain in front of it)
+    const BlockArgs* nx = last ? nullptr : tab + i + 1;
+    const unsigned kind = (ca.kinds >> (2 * i)) & 3u;
+    if (kind == 0) chain_block<3, 1, MT, NWAVES>(a, nx, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry);
+    else if (kind == 1) chain_block<5, 1, MT, NWAVES>(a, nx, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry);
+    else chain_block<5, 2, MT, NWAVES>(a, nx, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Paired whole-block kernel for the 2x2-image blocks (6b..7a).  mbconv_block_kernel gives every CU one 16-row tile and
 // makes it pull the whole block's weights (2.2 MB) from L2, and a CU's L2 stream tops out at ~41 GB/s whatever is kept in
 // flight (profiles/r02_notes.md): 54 us of the 59.  Here TWO workgroups on two CUs of one XCD share 8 clips (two row
@@ -3120,6 +3483,8 @@ struct mkws_embed {
   int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 3a and 4a (where it measured faster), 2 = 2a..4a, 0 = never
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
+  int fuse_chain = 1;              // consecutive 4x3-image blocks (4b..6a) in ONE launch (mbconv_chain_kernel): activations stay in LDS from block to block
+  mkws::BlockArgs* d_chain_tab = nullptr;   // device copy of every block's constants (BlockArgs without X / Y / dbg) for the chain kernels
   int fuse_pair = 1;               // stride-1 2x2 blocks on mbconv_pair_kernel: two workgroups share 8 clips and split the channels
   float* pair_xc1 = nullptr; float* pair_xd = nullptr; int* pair_flags = nullptr;   // exchange buffers of the paired kernel
   int* pair_err_dev = nullptr;     // sticky failure word of the paired kernel (device memory)
@@ -3568,6 +3933,67 @@ int launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43,
   return MKWS_OK;
 }
 
+// Depth-fused chain (mbconv_chain_kernel): consecutive 4x3-image blocks [i0, i1] of the plan in one launch.
+static void fill_block_args(BlockArgs& a, const BlockPlan& b, int B) {
+  a.X = nullptr; a.Cin = b.spec.in_ch;
+  a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KCe = b.expand.KC; a.NTe = b.expand.NTtot;
+  a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift;
+  a.WrP = b.se.WrP; a.br = b.se.br; a.NTR = b.se.NTR; a.We2P = b.se.WeP; a.be = b.se.be;
+  a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift; a.NTp = b.project.NTtot;
+  a.Y = nullptr; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
+  a.dbg_dw = nullptr; a.dbg_gate = nullptr;
+  a.B = B; a.Cexp = b.ce; a.se = b.se.se;
+#ifdef MKWS_FRONT_TIMING
+  a.dbg_t = nullptr;
+#endif
+}
+// May block i+1 follow block i inside one chain launch?  (The chain keeps activations in LDS and the residual in registers.)
+static bool chain_link_ok(const BlockPlan& b, const BlockPlan& next) {
+  if (b.spec.stride != 1) return false;                                  // a stride-2 block ends the chain (the image shrinks)
+  if (b.project.NTtot > kBlockWaves) return false;                       // one output tile per wave: the residual carry is one fragment per row tile
+  if (next.spec.in_ch != b.spec.out_ch || next.expand.KC != b.project.NTtot) return false;
+  return next.ce <= 3 * kBlockWaves * 64;
+}
+bool cluster_supported(const BlockPlan& b);
+static bool chain_member(const mkws_embed* em, const BlockPlan& b) {
+  if (!em->fuse_chain || !em->fuse_block || !block_supported(b, em->fuse_block)) return false;
+  if (!(b.H == 4 && b.W == 3)) return false;
+  if (em->fuse_cluster && cluster_supported(b) && em->cl_flags) return false;
+  return true;
+}
+int launch_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const float* X, float* Y, int B) {
+  ChainArgs ca;
+  const int n = i1 - i0 + 1, mt43 = em->block_mt43;
+  if (!em->d_chain_tab) return fail(MKWS_ERR_UNSUPPORTED, "chain: no block table");
+  ca.tab = em->d_chain_tab; ca.i0 = i0; ca.n = n; ca.kinds = 0; ca.ldsU = ca.ldsE = 0;
+  ca.X = X; ca.Y = Y; ca.B = B;
+  int ldsZ = 0;
+  std::string names;
+  for (int k = 0; k < n; ++k) {
+    const BlockPlan& b = em->blocks[i0 + k];
+    const int ks = b.spec.kernel, st = b.spec.stride;
+    if (ks == 3 && st != 1) return fail(MKWS_ERR_UNSUPPORTED, "chain: 3x3 stride-2 block");
+    ca.kinds |= (unsigned)((ks == 3 && st == 1) ? 0 : (ks == 5 && st == 1) ? 1 : 2) << (2 * k);
+    const int MT = block_row_tiles(b, mt43), G = MT * 16 / (b.H * b.W);
+    const BlockLds L = block_lds(b.expand.KC, b.ce, MT, G, kBlockWaves);
+    ca.ldsU = std::max(ca.ldsU, L.U); ca.ldsE = std::max(ca.ldsE, L.E); ldsZ = std::max(ldsZ, L.Z);
+    names += (k ? "," : "") + std::string(b.spec.name);
+  }
+  const size_t lds = ((size_t)ca.ldsU + ca.ldsE + ldsZ) * sizeof(float);
+  if (lds > 160 * 1024) return fail(MKWS_ERR_UNSUPPORTED, "chain: LDS carve %zu bytes", lds);
+  const int G = mt43 * 16 / 12;
+  const dim3 grid((B + G - 1) / G);
+  ProfScope ps("chain:" + names, std::string("mbconv_chain_kernel<") + std::to_string(mt43) + "," + std::to_string(kBlockWaves) + ">");
+  if (mt43 == 3) {
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_chain_kernel<3, kBlockWaves>), 160 * 1024)) return rc_;
+    hipLaunchKernelGGL((mbconv_chain_kernel<3, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, ca);
+  } else {
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_chain_kernel<2, kBlockWaves>), 160 * 1024)) return rc_;
+    hipLaunchKernelGGL((mbconv_chain_kernel<2, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, ca);
+  }
+  return MKWS_OK;
+}
+
 // Paired whole-block kernel (mbconv_pair_kernel): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a).
 struct PairWs { float* xc1 = nullptr; float* xd = nullptr; int* flags = nullptr; int* err_dev = nullptr; int* err_host = nullptr; int fault = 0; int mt = 2; };
 static int pair_count(int B, int mt) { const int G = 4 * mt; return ((B + G - 1) / G + 7) / 8 * 8; }   // padded to whole groups of 8 pairs (16 workgroups)
@@ -3932,6 +4358,26 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       float* t = cur; cur = nxt; nxt = t;
       continue;
     }
+    {
+      // depth-fused chain: blocks i .. e in one launch.  A block whose output is tapped ends the chain; a block whose inner taps
+      // ("_expand" / "_dw" / "_gate") are wanted is left to the single-block paths below (the chain stops in front of it)
+      auto inner_tap = [&](int j) {
+        if (!stop) return false;
+        const std::string q = std::string("block") + em->blocks[j].spec.name;
+        return (q + "_expand") == stop || (q + "_dw") == stop || (q + "_gate") == stop;
+      };
+      if (chain_member(em, b) && !inner_tap(i)) {
+        int e = i;
+        while (e + 1 < kNumBlocks && e + 1 - i < kChainMax && !(stop && (std::string("block") + em->blocks[e].spec.name) == stop) &&
+               chain_member(em, em->blocks[e + 1]) && chain_link_ok(em->blocks[e], em->blocks[e + 1]) && !inner_tap(e + 1)) ++e;
+        const BlockPlan& bl = em->blocks[e];
+        if (int rc = launch_chain(s, em, i, e, cur, nxt, B)) return rc;
+        if (hit(std::string("block") + bl.spec.name, nxt, (size_t)B * bl.Ho * bl.Wo * bl.spec.out_ch)) return MKWS_OK;
+        float* t = cur; cur = nxt; nxt = t;
+        i = e;
+        continue;
+      }
+    }
     if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
@@ -4157,6 +4603,17 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     // the expand FC's K (= se) is padded to NTR*16 by pack_gemm: KC of se_e == NTR by construction
   }
   em->top = G(o_top); em->dense0 = G(o_d0); em->dense1 = G(o_d1); em->dense2 = G(o_d2);
+  {
+    // constants of every block for the chain kernels (blocks without an expand conv are never chained: their entries stay zero)
+    std::vector<BlockArgs> tab(kNumBlocks);
+    memset(static_cast<void*>(tab.data()), 0, sizeof(BlockArgs) * kNumBlocks);
+    for (int i = 0; i < kNumBlocks; ++i)
+      if (em->blocks[i].has_expand) fill_block_args(tab[i], em->blocks[i], 0);
+    if (hipMalloc(reinterpret_cast<void**>(&em->d_chain_tab), sizeof(BlockArgs) * kNumBlocks) != hipSuccess ||
+        hipMemcpy(em->d_chain_tab, tab.data(), sizeof(BlockArgs) * kNumBlocks, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(em->d_weights); if (em->d_chain_tab) (void)hipFree(em->d_chain_tab); delete em; return fail(MKWS_ERR_ALLOC, "block table upload failed");
+    }
+  }
 
   // workspace
   const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 20480 + 9 * 48;
@@ -4166,7 +4623,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   const size_t cluster_floats = ncl * ((size_t)kClusterPMax * kClXc1 + (size_t)kClusterPMax * kClMaxTiles * 256 + (size_t)kNumBlocks * 2 * kClFlagRow);
   const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4 + cluster_floats;
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
-    (void)hipFree(em->d_weights); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
+    (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
   }
   float* w = em->d_ws;
   const size_t mb = (size_t)max_batch;
@@ -4183,7 +4640,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     em->pair_flag_count = np * 4;
     if (hipMemset(em->pair_flags, 0, (np * 4 + 4) * sizeof(int)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&em->pair_err_host), 64, hipHostMallocMapped) != hipSuccess) {
-      (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "setting up the pair flags failed");
+      (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "setting up the pair flags failed");
     }
     *em->pair_err_host = 0;
     if (ncl > 0) {
@@ -4192,7 +4649,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
       em->cl_flags = reinterpret_cast<int*>(w); w += ncl * 2 * kClFlagRow * kNumBlocks;
       em->cl_flag_count = ncl * 2 * kClFlagRow * kNumBlocks;
       if (hipMemset(em->cl_flags, 0, em->cl_flag_count * sizeof(int)) != hipSuccess) {
-        (void)hipFree(em->d_weights); (void)hipFree(em->d_ws); (void)hipHostFree(em->pair_err_host); delete em; return fail(MKWS_ERR_HIP, "clearing the cluster flags failed");
+        (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); (void)hipFree(em->d_ws); (void)hipHostFree(em->pair_err_host); delete em; return fail(MKWS_ERR_HIP, "clearing the cluster flags failed");
       }
     }
   }
@@ -4204,6 +4661,7 @@ void mkws_embed_destroy(mkws_embed* em) {
   if (!em) return;
   if (em->d_weights) (void)hipFree(em->d_weights);
   if (em->d_ws) (void)hipFree(em->d_ws);
+  if (em->d_chain_tab) (void)hipFree(em->d_chain_tab);
   if (em->pair_err_host) (void)hipHostFree(em->pair_err_host);
   delete em;
 }
@@ -4229,6 +4687,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
   if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
   if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_chain") == 0) { em->fuse_chain = value; return MKWS_OK; }
   if (strcmp(name, "fuse_cluster") == 0) {
     if (value && !em->cl_flags) return fail(MKWS_ERR_UNSUPPORTED, "fuse_cluster needs a handle of at most 64 clips (max_batch = %d)", em->max_batch);
     em->fuse_cluster = value; return MKWS_OK;
@@ -4250,6 +4709,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_mid") == 0) return em->fuse_mid;
   if (strcmp(name, "fuse_back") == 0) return em->fuse_back;
   if (strcmp(name, "fuse_pair") == 0) return em->fuse_pair;
+  if (strcmp(name, "fuse_chain") == 0) return em->fuse_chain;
   if (strcmp(name, "fuse_cluster") == 0) return em->fuse_cluster;
   if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
   if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;

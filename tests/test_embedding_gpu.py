@@ -53,7 +53,8 @@ def test_execution_options_agree(ctx):
     x = torch.from_numpy(spec).to(ctx["dev"])
     ref = ctx["oracle"].forward(spec).numpy()
     try:
-        for front, block, mid, pair in ((0, 0, 0, 0), (1, 0, 0, 1), (1, 2, 1, 1), (0, 2, 0, 0), (1, 1, 2, 1), (0, 0, 1, 0), (1, 2, 1, 0)):
+        for combo, (front, block, mid, pair) in enumerate(((0, 0, 0, 0), (1, 0, 0, 1), (1, 2, 1, 1), (0, 2, 0, 0), (1, 1, 2, 1), (0, 0, 1, 0), (1, 2, 1, 0))):
+            ctx["em"].set_option("fuse_chain", combo & 1)          # the depth-fused chain only exists on top of fuse_block = 2
             ctx["em"].set_option("fuse_pair", pair)
             ctx["em"].set_option("fuse_front", front)
             ctx["em"].set_option("fuse_block", block)
@@ -69,6 +70,7 @@ def test_execution_options_agree(ctx):
                 got = ctx["em"].tap(x[:3], name).cpu().numpy().reshape(taps[name].shape)
                 assert _rel(got, taps[name]) < REL_TOL, (front, block, mid, pair, name)
     finally:
+        ctx["em"].set_option("fuse_chain", 1)
         ctx["em"].set_option("fuse_pair", 1)
         ctx["em"].set_option("fuse_front", 1)
         ctx["em"].set_option("fuse_block", 2)
@@ -76,6 +78,29 @@ def test_execution_options_agree(ctx):
         ctx["em"].set_option("fuse_back", 1)
         ctx["em"].set_option("fuse_stem", 1)
         ctx["em"].set_option("fuse_gap", 1)
+
+
+def test_depth_fused_chain_is_bit_identical_to_the_single_block_kernels(ctx):
+    """mbconv_chain_kernel (blocks 4b..6a in one launch, activations in LDS, residual in registers) performs the same operations in the
+    same order as one mbconv_block_kernel launch per block: embeddings and every block output inside the chain are bit-identical,
+    for full, ragged and multi-round batches."""
+    rng = np.random.default_rng(21)
+    spec = _spec(rng, 1024)
+    x = torch.from_numpy(spec).to(ctx["dev"])
+    em = ctx["em"]
+    assert em.get_option("fuse_chain") == 1
+    try:
+        got = {b: em.forward(x[:b]).clone() for b in (1024, 1023, 37, 6, 5, 4, 3, 1)}
+        taps = {n: em.tap(x[:9], n).clone() for n in ("block4b", "block4c", "block5a", "block5b", "block5c", "block6a", "block5b_dw", "block5c_gate", "block6a_dw")}
+        em.set_option("fuse_chain", 0)
+        for b, e in got.items():
+            assert torch.equal(em.forward(x[:b]), e), b
+        for n, t in taps.items():
+            assert torch.equal(em.tap(x[:9], n), t), n
+    finally:
+        em.set_option("fuse_chain", 1)
+    ref = ctx["oracle"].forward(spec[:16]).numpy()
+    assert _rel(got[1024][:16].cpu().numpy(), ref) < REL_TOL
 
 
 def test_golden_embedding_on_device(ctx, golden_dir):
