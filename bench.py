@@ -120,22 +120,59 @@ def _cpu_worker(kind, idx, threads, n_clips, first_clip, budget_s, q, go):
         q.put(("done", idx, done, time.perf_counter() - t0))
 
 
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota_us).
+    os.cpu_count() is the HOST's count -- on the GPU boxes it says 256 while the container gets a fraction of that, and sizing
+    the worker pool from it oversubscribed the quota 10-20x (round 3: "256 cores" ran 1.4x faster than one thread)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                                                  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def cpu_baseline(kind, budget_s):
-    """BASELINE.md section 3.3 asks for both: one thread, and all host cores.  The contract's fields describe the all-cores run;
-    "single_thread" holds the 1-core one (a third of the time budget)."""
+    """BASELINE.md section 3.3 asks for both: one thread, and all host cores.  The contract's fields describe the all-cores run
+    ("cores" = the usable cores the workers were sized for, "host_cores" = os.cpu_count()); "single_thread" holds the 1-core one
+    (a third of the time budget).  An all-cores figure below 2x the single thread on >= 4 cores is flagged, not hidden."""
     one = _cpu_run(kind, budget_s / 3.0, procs=1, threads=1)
     allc = _cpu_run(kind, budget_s * 2.0 / 3.0)
     allc["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample")}
+    allc["speedup_over_single_thread"] = round(allc["value"] / one["value"], 2) if one["value"] > 0 else None
+    if allc["cores"] >= 4 and allc["value"] < 2.0 * one["value"]:
+        allc["note"] = (f"all-cores run is only {allc['value'] / max(one['value'], 1e-9):.2f}x one thread on {allc['cores']} usable cores: "
+                        "the host cores are shared or throttled; treat the single-thread figure as the reliable one")
     return allc
 
 
 def _cpu_run(kind, budget_s, procs=None, threads=None):
     import multiprocessing as mp
     ncpu = os.cpu_count() or 1
-    if threads is None:
-        threads = 1 if kind == "frontend" else min(8, ncpu)       # PyTorch-CPU convs on 49x40 images stop scaling near 8 threads
-    if procs is None:
-        procs = max(1, min(ncpu // threads, 64))
+    usable = usable_cores()
+    if procs is None and threads is None:
+        # one single-threaded worker per usable core (the PyTorch-CPU convolutions on 49x40 images scale better across processes
+        # than across intra-op threads); above 64 cores the workers get the remaining cores as threads
+        procs = max(1, min(usable, 64))
+        threads = max(1, usable // procs)
+    elif threads is None:
+        threads = 1
+    elif procs is None:
+        procs = max(1, min(usable // threads, 64))
     ctx = mp.get_context("spawn")
     q, go = ctx.Queue(), ctx.Event()
     ps = [ctx.Process(target=_cpu_worker, args=(kind, i, threads, 128, 1024 + 128 * i, budget_s, q, go)) for i in range(procs)]
@@ -169,7 +206,7 @@ def _cpu_run(kind, budget_s, procs=None, threads=None):
             "finetune": "oracle C micro-frontend + PyTorch-CPU fp32 embedding + numpy head loss/gradient/update (augmentation not included)",
             "stream": "oracle C micro-frontend per 1 s window (no frame sharing, as the reference) + PyTorch-CPU fp32 embedding + 50 numpy heads"}[kind]
     unit = "windows/s" if kind == "stream" else "clips/s"
-    return {"value": round(total / wall, 2), "unit": unit, "cores": procs * threads, "host_cores": ncpu, "procs": procs,
+    return {"value": round(total / wall, 2), "unit": unit, "cores": procs * threads, "usable_cores": usable, "host_cores": ncpu, "procs": procs,
             "threads_per_proc": threads, "kind": "port",
             "sample": f"{total} synthetic clips in {wall:.1f} s: {what}; {procs} processes x {threads} threads; TensorFlow not installable here"}
 

@@ -154,7 +154,12 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  * handle notices (a host-mapped word, no synchronisation), switches the handle to the one-workgroup-per-4-clips kernel for
  * good ("fuse_pair" = 0, mkws_embed_get_option("pair_degraded") counts it) and returns MKWS_ERR_EXCHANGE: the earlier result is
  * invalid, the repeated call is correct.  A captured hipGraph keeps replaying the paired launch: graph users poll
- * mkws_embed_get_option(em, "pair_degraded") / check for NaN, or capture with "fuse_pair" = 0.
+ * mkws_embed_get_option(em, "exchange_error") (nonzero = a launch that already executed recorded a failure; host-mapped word, no
+ * synchronisation) before a replay, and on a hit make one eager mkws_embed_forward (which heals the handle and returns
+ * MKWS_ERR_EXCHANGE), repeat it, and re-capture -- multilingual_kws_amd/embedding/batch_streaming_analysis.py does exactly that --
+ * or capture with "fuse_pair" = 0.  The exchange kernels assume that no OTHER kernel competes for the XCD's CUs while they spin:
+ * the paired kernel tolerates concurrent launches (at most one unmatched half per launch and XCD), the cluster kernel (10-14 members)
+ * does not, so handles that run concurrently (serving lanes) must not use "fuse_cluster".
  *
  * Execution options (A/B switches for measurement; results are equal up to fp32 rounding):
  *   "fuse_front" (default 1): expand 1x1 conv + depthwise conv in one kernel (expanded tensor stays in LDS);
@@ -187,9 +192,11 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (persistent workgroups, one per CU, each walking
  *                 clips blockIdx, blockIdx + grid, ... with the next clip's spectrogram prefetched; both 25x20x32 activations stay
  *                 in LDS); 0 = separate kernels.
+ *   "pair_fault" / "inject_exchange_error" (test hooks): force the exchange kernels' failure paths / leave the error words as a failed
+ *                 exchange of an earlier launch would (tests/test_embedding_gpu.py, tests/test_streaming.py).
  *   "big_tiles" (A/B aid, default 0): 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (what handles above 512 clips use). */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
-/* Current value of an option above, or of "pair_degraded" (times the handle left the paired kernel after a failed exchange) /
+/* Current value of an option above, of "exchange_error" (see the failure contract), or of "pair_degraded" (times the handle left the paired kernel after a failed exchange) /
  * "max_batch"; negative mkws_status for an unknown name.  ("pair_fault" is a write-only test hook that forces those failures.) */
 int mkws_embed_get_option(const mkws_embed* em, const char* name);
 

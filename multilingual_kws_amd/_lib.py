@@ -1,5 +1,6 @@
 """ctypes loader for lib/libmkws_hip.so (C-ABI: include/mkws.h).  Fails loudly; no fallback."""
 import ctypes
+import itertools
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -125,8 +126,28 @@ def lib():
             fn = getattr(L, name)       # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
+        got = L.mkws_abi_version()
+        if got != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: rebuild it (make -C multilingual_kws_amd/csrc)")
         _lib = L
     return _lib
+
+
+_generation = itertools.count(1)
+
+
+def next_generation():
+    """Process-unique serial for every handle wrapper: caches keyed on raw handle addresses add it, so that a handle destroyed and
+    re-created at the same address is not mistaken for the old one."""
+    return next(_generation)
+
+
+def forget_graphs(obj):
+    """Called by the wrappers' close(): drops captured graphs that point into the handle being destroyed."""
+    import sys
+    m = sys.modules.get("multilingual_kws_amd.embedding.batch_streaming_analysis")
+    if m is not None:
+        m._BatchGraph.forget(obj)
 
 
 def check(code):

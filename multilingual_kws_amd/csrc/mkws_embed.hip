@@ -2197,12 +2197,45 @@ struct ChainArgs {
   const float* X; float* Y;   // the chain's input and its last block's output
   int B;
   int ldsU, ldsE;             // LDS carve in floats, the maximum over the chain's blocks (Z follows E)
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbg_t;  // [workgroups][kChainMax][8] wall_clock64 stamps
+#endif
 };
 
+// Values loaded from the block table arrive in VGPRs (a global load is a vector load unless the compiler can prove the memory is never
+// written); used as a buffer descriptor or a scalar offset they would make hipcc wrap EVERY buffer_load of the weight rings in a
+// waterfall loop (4 v_readfirstlane + compares + a branch per load).  The table entries are uniform by construction: pin them to SGPRs.
+__device__ __forceinline__ int sgpr_(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* sgpr_(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  // rebuilt as a GLOBAL pointer: an integer cast to a generic pointer would turn every load through it into a flat_load, which hipcc
+  // fences with s_waitcnt vmcnt(0) lgkmcnt(0) (it may alias LDS) -- the depthwise tap loads then ran one latency at a time
+  typedef __attribute__((address_space(1))) T* gptr_t;
+  return (T*)reinterpret_cast<gptr_t>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ BlockArgs sgpr_block_args(const BlockArgs& t) {
+  BlockArgs a;
+  a.X = nullptr; a.Cin = sgpr_(t.Cin);
+  a.WpE = sgpr_(t.WpE); a.scE = sgpr_(t.scE); a.shE = sgpr_(t.shE); a.KCe = sgpr_(t.KCe); a.NTe = sgpr_(t.NTe);
+  a.Wd = sgpr_(t.Wd); a.scD = sgpr_(t.scD); a.shD = sgpr_(t.shD);
+  a.WrP = sgpr_(t.WrP); a.br = sgpr_(t.br); a.NTR = sgpr_(t.NTR); a.We2P = sgpr_(t.We2P); a.be = sgpr_(t.be);
+  a.WpP = sgpr_(t.WpP); a.scP = sgpr_(t.scP); a.shP = sgpr_(t.shP); a.NTp = sgpr_(t.NTp);
+  a.Y = nullptr; a.Cout = sgpr_(t.Cout); a.residual = sgpr_(t.residual);
+  a.dbg_dw = nullptr; a.dbg_gate = nullptr;
+  a.B = 0; a.Cexp = sgpr_(t.Cexp); a.se = sgpr_(t.se);
+#ifdef MKWS_FRONT_TIMING
+  a.dbg_t = nullptr;
+#endif
+  return a;
+}
+
 template <int KS, int S, int MT, int NWAVES>
-__device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs* nx, float* s_blk, int ldsU, int ldsE, bool first,
-                                            f32x4 (&wqa)[4][(MT >= 3) ? 1 : 2], f32x4 (&carry)[MT]) {
+__device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs* nxp, bool has_next, float* s_blk, int ldsU, int ldsE, bool first,
+                                            f32x4 (&wqa)[4][(MT >= 3) ? 1 : 2], f32x4 (&carry)[MT], unsigned long long* dbg_t) {
   constexpr int NTHR = NWAVES * 64;
+  const BlockArgs* nx = has_next ? nxp : nullptr;      // nxp is always a valid table entry (the block itself when there is no next one)
   constexpr int HT = 4, WT = 3, HW = HT * WT;
   constexpr int G = MT * 16 / HW;
   constexpr int HoT = (S == 1) ? HT : 2, WoT = (S == 1) ? WT : 2;
@@ -2233,6 +2266,9 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   const int rows_in = gvalid * HW, rows_out = gvalid * HoWo;
   const size_t row0_in = (size_t)b0 * HW, row0_out = (size_t)b0 * HoWo;
 
+#ifdef MKWS_FRONT_TIMING
+  if (dbg_t && threadIdx.x == 0) dbg_t[0] = wall_clock64();
+#endif
   // ---- phase A: expand.  The input fragments are in s_X and the first ring slots in flight (kernel prologue / previous block) ----
   const int a_groups = (a.NTe + NTWA - 1) / NTWA;
   const int a_runs = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
@@ -2260,6 +2296,9 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   }
   __syncthreads();
 
+#ifdef MKWS_FRONT_TIMING
+  if (dbg_t && threadIdx.x == 0) dbg_t[1] = wall_clock64();
+#endif
   // ---- phase B: depthwise (+BN+swish) in place + SE means (see mbconv_block_kernel) ----
   for (int i = tid; i < Cexp; i += NTHR) s_be[i] = a.be[i];
   const int c1_per = (KCx + NWAVES - 1) / NWAVES;
@@ -2267,21 +2306,19 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   const int c1_kc = (c1_j0 + c1_per <= KCx) ? c1_per : (KCx > c1_j0 ? KCx - c1_j0 : 0);
   const WBuf c1_w(a.WrP + (size_t)c1_j0 * a.NTR * 256, loff);
   f32x4 wq1[3][3];
-  // (the 5x5 depthwise holds 12 inputs + 12 outputs + its taps per thread: C1's ring is requested behind it, not in front)
+  // (5x5: a thread holds 12 inputs + 12 outputs + 25 taps -- 196 registers; C1's ring is requested behind the depthwise loop there,
+  // where waves that own one round of tasks wait for those that own two)
   if (KS == 3) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   {
     const int Q = Cexp / 4;
     for (int task = tid; task < G * Q; task += NTHR) {
       const int gi = task / Q, q4 = (task - gi * Q) * 4;
       float* Eg = s_E + (size_t)gi * HW * LDE + q4;
-      f32x4 ein[HW];
+      // every tap this image uses and the BN constants are requested FIRST, in source order: hipcc leaves this region in source order
+      // (in mbconv_block_kernel its scheduler hoists the loads by itself; here, "load a tap, use it" ran one L2 latency per tap)
+      f32x4 wv[KS * KS];
 #pragma unroll
-      for (int pix = 0; pix < HW; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(Eg + (size_t)pix * LDE);
-      f32x4 acc[HoWo];
-#pragma unroll
-      for (int o = 0; o < HoWo; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < KS; ++i) {
+      for (int i = 0; i < KS; ++i)
 #pragma unroll
         for (int jx = 0; jx < KS; ++jx) {
           bool used = false;
@@ -2292,19 +2329,30 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
               const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
               used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
             }
-          if (!used) continue;
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + q4);
+          if (used) wv[i * KS + jx] = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + q4);
+        }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + q4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + q4);
+      f32x4 ein[HW];
+#pragma unroll
+      for (int pix = 0; pix < HW; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(Eg + (size_t)pix * LDE);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[HoWo];
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) {
 #pragma unroll
           for (int oh = 0; oh < HoT; ++oh)
 #pragma unroll
             for (int ow = 0; ow < WoT; ++ow) {
               const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
-              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv;
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv[i * KS + jx];
             }
         }
       }
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + q4);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + q4);
       f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < HoWo; ++o) {
@@ -2320,7 +2368,22 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   if (KS != 3) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   __syncthreads();
 
+#ifdef MKWS_FRONT_TIMING
+  if (dbg_t && threadIdx.x == 0) dbg_t[2] = wall_clock64();
+#endif
   // ---- phase C1: r^T[se, clips] = Wr^T . mean^T, K = Cexp split over the waves ----
+  // the NEXT block's expand BN constants are requested here (they go to Z under the gate pass, two phases later: nothing waits for them)
+  constexpr int NCST = 3;                                       // Cexp <= NCST * NTHR (host-checked)
+  float nsc[NCST], nsh[NCST];
+  const int nxCexp = nx ? sgpr_(nx->Cexp) : 0;
+  if (nx) {
+    const float* nscE = sgpr_(nx->scE); const float* nshE = sgpr_(nx->shE);
+#pragma unroll
+    for (int k = 0; k < NCST; ++k) {
+      const int i = tid + k * NTHR;
+      if (i < nxCexp) { nsc[k] = nscE[i]; nsh[k] = nshE[i]; }
+    }
+  }
   constexpr int NTW2 = 3;
   const int c2_groups = (KCx + NTW2 - 1) / NTW2;
   const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
@@ -2356,6 +2419,9 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   }
   __syncthreads();
 
+#ifdef MKWS_FRONT_TIMING
+  if (dbg_t && threadIdx.x == 0) dbg_t[3] = wall_clock64();
+#endif
   // ---- phase C2: gate; phase D's weight stream is requested first (see mbconv_block_kernel for the row split) ----
   const bool d_rowsplit = (a.NTp == NWAVES / 2 + 1) && (MTO > 1) && (MTO <= NWAVES / 2 - 1);
   const int d_ntw = d_rowsplit ? ((wave < NWAVES / 2) ? 1 : 0) : ((a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0);
@@ -2382,18 +2448,10 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   }
   __syncthreads();
 
-  // ---- gate the depthwise output in place; the NEXT block's expand BN constants travel under it (Z is free from here on) ----
-  constexpr int NCST = 3;                                       // Cexp <= NCST * NTHR (host-checked)
-  float nsc[NCST], nsh[NCST];
-  const int nxCexp = nx ? nx->Cexp : 0;
-  if (nx) {
-    const float* nscE = nx->scE; const float* nshE = nx->shE;
-#pragma unroll
-    for (int k = 0; k < NCST; ++k) {
-      const int i = tid + k * NTHR;
-      if (i < nxCexp) { nsc[k] = nscE[i]; nsh[k] = nshE[i]; }
-    }
-  }
+#ifdef MKWS_FRONT_TIMING
+  if (dbg_t && threadIdx.x == 0) dbg_t[4] = wall_clock64();
+#endif
+  // ---- gate the depthwise output in place; the NEXT block's expand BN constants (requested in C1) go to Z, free from here on ----
   {
     const int Q = Cexp / 4;
     for (int i = tid; i < G * HoWo * Q; i += NTHR) {
@@ -2412,13 +2470,19 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   }
   __syncthreads();
 
+#ifdef MKWS_FRONT_TIMING
+  if (dbg_t && threadIdx.x == 0) dbg_t[5] = wall_clock64();
+#endif
   // ---- phase D: gated project (+ residual).  The next block's expand ring is requested first; the output tile becomes the
   //      next block's input fragments in U (free since the gate was applied) and this lane's residual (carry) ----
-  if (nx) {
-    const int nNTe = nx->NTe, nKCe = nx->KCe;
+  {
+    // UNCONDITIONAL (the last block of a chain re-requests its own first fragments, four wasted loads per wave): a ring that is
+    // refilled only "if there is a next block" stays live across the block loop, and its 16-32 registers push the depthwise phase
+    // into spills
+    const int nNTe = sgpr_(nxp->NTe), nKCe = sgpr_(nxp->KCe);
     const int n_groups = (nNTe + NTWA - 1) / NTWA;
     const int n_runs = (n_groups > wave) ? (n_groups - wave + NWAVES - 1) / NWAVES : 0;
-    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(nx->WpE, loff), (size_t)nNTe * 256, nNTe, n_runs, nKCe, a_tile_of);
+    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(sgpr_(nxp->WpE), loff), (size_t)nNTe * 256, nNTe, n_runs, nKCe, a_tile_of);
   }
   {
     const size_t cstride = (size_t)a.NTp * 256;
@@ -2440,14 +2504,11 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
         if (first) { if (r < rows_out) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + r) * a.Cin + n); }
         else y += carry[slot];
       }
-      if (nx) {
-        if constexpr (S == 1) {
-          if (r >= rows_out) y = (f32x4){0.f, 0.f, 0.f, 0.f};
-          carry[slot] = y;
-          *reinterpret_cast<f32x4*>(s_X + ((size_t)(t * MT + m) * 64 + lane) * 4) = y;
-        }
-      } else if (r < rows_out) {
-        *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+      if (!nx && r < rows_out) *reinterpret_cast<f32x4*>(a.Y + (row0_out + r) * a.Cout + n) = y;
+      if constexpr (S == 1) {
+        if (r >= rows_out) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+        carry[slot] = y;                                           // (unconditional, like the ring above)
+        if (nx) *reinterpret_cast<f32x4*>(s_X + ((size_t)(t * MT + m) * 64 + lane) * 4) = y;
       }
     };
     auto run = [&](auto ntw_tag) {
@@ -2482,7 +2543,12 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
     else if (d_ntw == 2) run(std::integral_constant<int, 2>{});
     else if (d_ntw >= 3) run(std::integral_constant<int, 3>{});
   }
+#ifdef MKWS_FRONT_TIMING
+  __syncthreads();
+  if (dbg_t && threadIdx.x == 0) dbg_t[6] = wall_clock64();
+#else
   if (nx) __syncthreads();
+#endif
 }
 
 template <int MT, int NWAVES>
@@ -2496,13 +2562,16 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const unsigned loff = (unsigned)(g * 64 + c * 4);
+#ifdef MKWS_FRONT_TIMING
+  if (ca.dbg_t && threadIdx.x == 0) ca.dbg_t[(size_t)gridDim.x * kChainMax * 8 + blockIdx.x] = wall_clock64();
+#endif
   f32x4 wqa[4][NTWA];
   f32x4 carry[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) carry[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     // prologue = the head of mbconv_block_kernel: first block's expand ring, then its input tile and BN constants
-    const int Cin = tab[0].Cin, KCe = tab[0].KCe, NTe = tab[0].NTe, Cexp = tab[0].Cexp;
+    const int Cin = sgpr_(tab[0].Cin), KCe = sgpr_(tab[0].KCe), NTe = sgpr_(tab[0].NTe), Cexp = sgpr_(tab[0].Cexp);
     const int b0 = blockIdx.x * G;
     const int gvalid = (ca.B - b0 < G) ? (ca.B - b0) : G;
     const int rows_in = gvalid * HW;
@@ -2510,7 +2579,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca)
     const int a_groups = (NTe + NTWA - 1) / NTWA;
     const int a_runs = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
     auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
-    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(tab[0].WpE, loff), (size_t)NTe * 256, NTe, a_runs, KCe, a_tile_of);
+    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(sgpr_(tab[0].WpE), loff), (size_t)NTe * 256, NTe, a_runs, KCe, a_tile_of);
     float* s_X = s_blk;
     float* s_scE = s_blk + ca.ldsU + ca.ldsE;
     for (int jm = wave; jm < KCe * MT; jm += NWAVES) {
@@ -2520,20 +2589,25 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca)
       if (r < rows_in && 16 * j + 4 * g < Cin) v = *reinterpret_cast<const f32x4*>(ca.X + (row0_in + r) * Cin + 16 * j + 4 * g);
       *reinterpret_cast<f32x4*>(s_X + ((size_t)jm * 64 + lane) * 4) = v;
     }
-    const float* scE = tab[0].scE; const float* shE = tab[0].shE;
+    const float* scE = sgpr_(tab[0].scE); const float* shE = sgpr_(tab[0].shE);
     for (int i = tid; i < Cexp; i += NTHR) { s_scE[i] = scE[i]; s_scE[Cexp + i] = shE[i]; }
     __syncthreads();
   }
   for (int i = 0; i < ca.n; ++i) {
-    BlockArgs a = tab[i];
+    BlockArgs a = sgpr_block_args(tab[i]);
     const bool last = (i + 1 == ca.n);
-    a.X = ca.X; a.Y = ca.Y; a.B = ca.B;                       // X is read by the first block only (residual), Y written by the last
-    a.dbg_dw = nullptr; a.dbg_gate = nullptr;                // ("_dw" / "_gate" taps of a block run mbconv_block_kernel: the launcher ends the chain in front of it)
-    const BlockArgs* nx = last ? nullptr : tab + i + 1;
+    a.X = ca.X; a.Y = ca.Y; a.B = ca.B;                       // X is read by the first block only (residual), Y written by the last                // ("_dw" / "_gate" taps of a block run mbconv_block_kernel: the launcher ends the chain in front of it)
+    const BlockArgs* nxp = last ? tab + i : tab + i + 1;
     const unsigned kind = (ca.kinds >> (2 * i)) & 3u;
-    if (kind == 0) chain_block<3, 1, MT, NWAVES>(a, nx, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry);
-    else if (kind == 1) chain_block<5, 1, MT, NWAVES>(a, nx, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry);
-    else chain_block<5, 2, MT, NWAVES>(a, nx, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry);
+#ifdef MKWS_FRONT_TIMING
+    unsigned long long* dt = ca.dbg_t ? ca.dbg_t + ((size_t)blockIdx.x * kChainMax + i) * 8 : nullptr;
+    if (dt && threadIdx.x == 0) dt[7] = wall_clock64();         // top of the block: before its constants are fetched
+#else
+    unsigned long long* dt = nullptr;
+#endif
+    if (kind == 0) chain_block<3, 1, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry, dt);
+    else if (kind == 1) chain_block<5, 1, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry, dt);
+    else chain_block<5, 2, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry, dt);
   }
 }
 
@@ -3984,6 +4058,12 @@ int launch_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const floa
   const int G = mt43 * 16 / 12;
   const dim3 grid((B + G - 1) / G);
   ProfScope ps("chain:" + names, std::string("mbconv_chain_kernel<") + std::to_string(mt43) + "," + std::to_string(kBlockWaves) + ">");
+#ifdef MKWS_FRONT_TIMING
+  static unsigned long long* d_ct = nullptr;
+  const size_t nstamp = (size_t)grid.x * kChainMax * 8 + grid.x;
+  if (!d_ct) (void)hipMalloc(&d_ct, sizeof(unsigned long long) * (4096 * kChainMax * 8 + 4096));
+  ca.dbg_t = (grid.x <= 4096) ? d_ct : nullptr;
+#endif
   if (mt43 == 3) {
     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_chain_kernel<3, kBlockWaves>), 160 * 1024)) return rc_;
     hipLaunchKernelGGL((mbconv_chain_kernel<3, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, ca);
@@ -3991,6 +4071,34 @@ int launch_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const floa
     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_chain_kernel<2, kBlockWaves>), 160 * 1024)) return rc_;
     hipLaunchKernelGGL((mbconv_chain_kernel<2, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, ca);
   }
+#ifdef MKWS_FRONT_TIMING
+  if (ca.dbg_t) {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(nstamp);
+    (void)hipMemcpy(h.data(), d_ct, nstamp * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (unsigned w = 0; w < grid.x; ++w) {
+      t0 = std::min(t0, h[(size_t)grid.x * kChainMax * 8 + w]);
+      t1 = std::max(t1, h[((size_t)w * kChainMax + (n - 1)) * 8 + 6]);
+    }
+    double pro = 0;
+    for (unsigned w = 0; w < grid.x; ++w) pro += (double)(h[((size_t)w * kChainMax) * 8 + 7] - h[(size_t)grid.x * kChainMax * 8 + w]);
+    fprintf(stderr, "[chain-timing] %s: %u workgroups, span %.2f us, prologue %.2f us\n", names.c_str(), grid.x, (double)(t1 - t0) / 100.0, pro / grid.x / 100.0);
+    for (int k = 0; k < n; ++k) {
+      double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+      unsigned long long e_min = ~0ull, e_max = 0;
+      for (unsigned w = 0; w < grid.x; ++w) {
+        const unsigned long long* q = &h[((size_t)w * kChainMax + k) * 8];
+        ph[0] += (double)(q[0] - q[7]);
+        for (int j = 0; j < 6; ++j) ph[j + 1] += (double)(q[j + 1] - q[j]);
+        e_min = std::min(e_min, q[6]); e_max = std::max(e_max, q[6]);
+      }
+      fprintf(stderr, "[chain-timing]   %s: args %.2f  A %.2f  B %.2f  C1 %.2f  C2 %.2f  gate %.2f  D %.2f us; end skew %.2f us\n", em->blocks[i0 + k].spec.name,
+              ph[0] / grid.x / 100.0, ph[1] / grid.x / 100.0, ph[2] / grid.x / 100.0, ph[3] / grid.x / 100.0, ph[4] / grid.x / 100.0, ph[5] / grid.x / 100.0,
+              ph[6] / grid.x / 100.0, (double)(e_max - e_min) / 100.0);
+    }
+  }
+#endif
   return MKWS_OK;
 }
 
@@ -4699,6 +4807,16 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
   if (strcmp(name, "pair_fault") == 0) { em->pair_fault = value; return MKWS_OK; }     // test hook: forces the paired kernel's failure paths
+  if (strcmp(name, "inject_exchange_error") == 0) {
+    // test hook: the state a failed exchange of an EARLIER launch leaves behind (sticky device word + host-mapped word), without running
+    // one -- what a captured graph meets when a replay before it failed.  Synchronous.
+    if (!em->pair_err_host || !em->pair_err_dev) return fail(MKWS_ERR_UNSUPPORTED, "handle has no exchange kernels");
+    const int code = value ? kPairErrTimeout : 0;
+    MKWS_HIP(hipDeviceSynchronize());
+    MKWS_HIP(hipMemcpy(em->pair_err_dev, &code, sizeof(int), hipMemcpyHostToDevice));
+    *reinterpret_cast<volatile int*>(em->pair_err_host) = code;
+    return MKWS_OK;
+  }
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
@@ -4714,6 +4832,10 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
   if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;
   if (strcmp(name, "pair_degraded") == 0) return em->pair_degraded;
+  // nonzero: a launch that has ALREADY EXECUTED recorded a failed exchange and the handle has not been healed yet (the next forward /
+  // tap / profile call heals it and returns MKWS_ERR_EXCHANGE).  A host-mapped word: no synchronisation.  This is what hipGraph users
+  // poll -- a replay does not pass through mkws_embed_forward, so "pair_degraded" cannot move under it.
+  if (strcmp(name, "exchange_error") == 0) return em->pair_err_host ? *reinterpret_cast<volatile int*>(em->pair_err_host) : 0;
   if (strcmp(name, "max_batch") == 0) return em->max_batch;
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }

@@ -88,19 +88,27 @@ class _BatchGraph:
 
     def __init__(self, embedding, heads, batch, lanes=1):
         import torch
-        from ..head import Head
         dev = embedding.device
         ems = embedding.replicas(lanes)
         self.keep = (ems, list(heads))                               # the graph holds raw handles: keep their owners alive
         self.lanes = lanes
+        self.heals = 0                                               # re-captures after a failed exchange (run)
+        self.generation = (embedding.generation, tuple(h.generation for h in heads))
         self.specs = [torch.zeros((batch, 49, 40), dtype=torch.float32, device=dev) for _ in range(lanes)]
+        self._capture()
+
+    def _capture(self):
+        import torch
+        from ..head import Head
+        ems, heads = self.keep
+        lanes, dev = self.lanes, ems[0].device
 
         def chain(i):
             return Head.forward_many(heads, ems[i].forward(self.specs[i]))
         side = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
-        for i in range(lanes):                                       # eager warm-up on side streams (lazy init outside the capture)
-            side[i].wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side[i]):
+        for i in range(lanes):                                       # eager warm-up on side streams (lazy init outside the capture); a
+            side[i].wait_stream(torch.cuda.current_stream(dev))      # handle with a recorded exchange failure is healed here (the wrapper
+            with torch.cuda.stream(side[i]):                         # repeats the call that returns MKWS_ERR_EXCHANGE)
                 chain(i)
             torch.cuda.current_stream(dev).wait_stream(side[i])
         self.graph = torch.cuda.CUDAGraph()
@@ -116,16 +124,35 @@ class _BatchGraph:
 
     @classmethod
     def get(cls, embedding, heads, batch, lanes=1):
+        # keyed on the handles AND their generation counters: a handle closed and re-created at the same address must not hit a graph
+        # that still points into the freed one
         key = (id(embedding), embedding.h.value, tuple(h.h.value for h in heads), int(batch), int(lanes))
+        gen = (embedding.generation, tuple(h.generation for h in heads))
         g = cls._cache.get(key)
+        if g is not None and g.generation != gen:
+            g = None
         if g is None:
             if len(cls._cache) >= 8:
                 cls._cache.clear()
             g = cls._cache[key] = cls(embedding, heads, batch, lanes)
         return g
 
+    @classmethod
+    def forget(cls, obj):
+        """Drop every cached graph that captured `obj` (an EmbeddingModel or Head being closed)."""
+        for k in [k for k, g in cls._cache.items() if any(obj is e for e in g.keep[0]) or any(obj is h for h in g.keep[1])]:
+            del cls._cache[k]
+
+    def exchange_failed(self):
+        return any(e.get_option("exchange_error") for e in self.keep[0])
+
     def run(self, parts):
         """parts: `lanes` tensors [batch,49,40] -> list of [n_heads, batch, 3] (views of the static outputs)."""
+        if self.exchange_failed():
+            # an earlier replay ran a failed pair / cluster exchange (its results were NaN): the captured launches would poison every
+            # later batch too.  Heal the handles (eager pass) and capture again -- the new graph holds the single-workgroup kernels
+            self._capture()
+            self.heals += 1
         for dst, src in zip(self.specs, parts):
             dst.copy_(src)
         self.graph.replay()
@@ -136,7 +163,7 @@ SERVING_LANES = 4      # concurrent batches per graph replay in streaming_infere
 
 
 def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_duration_ms=1000, clip_stride_ms=20,
-                         batch_windows=4096, max_chunk_length_sec=None, use_graph=True):
+                         batch_windows=4096, max_chunk_length_sec=None, use_graph=True, _retry=True):
     """Softmax outputs for every window.  `models`: one TransferLearnedModel or a list sharing one embedding
     (multi-keyword serving: the EfficientNet forward runs once, each keyword adds only its 18.5 k-parameter
     head).  Returns [num_windows, 3] (or a list of them)."""
@@ -147,6 +174,11 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
     stride = int(clip_stride_ms * sample_rate / 1000)
     outs = [[] for _ in mlist]
     emb_model = mlist[0].embedding
+    graphs_used = {}                           # graph -> its heal count when this stream first used it
+
+    def degraded():                            # times the handles of this stream have left the exchange kernels after a failure
+        return sum(e.get_option("pair_degraded") for e in [emb_model] + list(getattr(emb_model, "_replicas", [])))
+    degraded0 = degraded()
     from ..head import Head
     audio_arr = audio if torch.is_tensor(audio) else np.asarray(audio, dtype=np.float32)
     max_chunk = None if max_chunk_length_sec is None else int(max_chunk_length_sec * sample_rate)
@@ -161,8 +193,12 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
             if left > 0:
                 # full batches replay a captured graph, up to SERVING_LANES of them concurrently (see _BatchGraph); same launches on
                 # the same plan as the eager path, so the results equal it bit for bit
-                lanes = min(SERVING_LANES, left)
-                got = _BatchGraph.get(emb_model, heads, bw, lanes).run([specs[s + i * bw:s + (i + 1) * bw] for i in range(lanes)])
+                # (the cluster kernel of small handles spins on up to 14 co-resident members per launch: concurrent lanes could starve
+                # each other of CUs, include/mkws.h -- such handles replay one batch at a time)
+                lanes = 1 if emb_model.get_option("fuse_cluster") else min(SERVING_LANES, left)
+                bg = _BatchGraph.get(emb_model, heads, bw, lanes)
+                graphs_used.setdefault(bg, bg.heals)
+                got = bg.run([specs[s + i * bw:s + (i + 1) * bw] for i in range(lanes)])
                 for probs in got:
                     for k in range(len(mlist)):
                         outs[k].append(probs[k].clone())
@@ -172,6 +208,16 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
                 for k in range(len(mlist)):
                     outs[k].append(probs[k])
                 s += bw
+    if graphs_used:
+        # a failed exchange inside a replay leaves NaN rows and no return code: look at the handles once everything has run, and redo
+        # the stream on the healed handles (the first run() of the repeat re-captures; a healed handle cannot fail again).  A heal in
+        # the middle of the stream -- by a re-capture or by the eager call of a ragged tail -- means earlier batches were poisoned.
+        torch.cuda.synchronize(emb_model.device)
+        if _retry and (degraded() != degraded0 or any(g.exchange_failed() or g.heals != h0 for g, h0 in graphs_used.items())):
+            import warnings
+            warnings.warn("multilingual_kws_amd: an in-kernel exchange failed during a graph replay; repeating the stream on the single-workgroup kernels", RuntimeWarning)
+            return streaming_inferences(models, model_settings, audio, sample_rate, clip_duration_ms, clip_stride_ms, batch_windows, max_chunk_length_sec,
+                                        use_graph, _retry=False)
     res = [torch.cat(o).cpu().numpy() if o else np.zeros((0, 3), np.float32) for o in outs]
     return res[0] if single else res
 
@@ -203,17 +249,23 @@ class StreamingSession:
         self.audio = torch.zeros((self.batch, self.samples), dtype=torch.float32, device=dev)      # static graph input
         self._Head = Head
         self.graph = None
+        self.recaptures = 0
         self.probs = self._chain()                      # eager pass: creates every lazily-built table / attribute
         if use_graph:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                self._chain()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.probs = self._chain()
-            self.graph = g
+            self._capture()
+
+    def _capture(self):
+        import torch
+        dev = self.embedding.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._chain()                               # (heals a handle with a recorded exchange failure: the wrapper repeats the call)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.probs = self._chain()
+        self.graph = g
 
     def _chain(self):
         if self.batch == 1:
@@ -231,6 +283,11 @@ class StreamingSession:
         a = audio if torch.is_tensor(audio) else torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
         self.audio.copy_(a.reshape(self.batch, self.samples), non_blocking=True)
         if self.graph is not None:
+            if self.embedding.get_option("exchange_error"):
+                # the PREVIOUS replay ran a failed pair / cluster exchange (its output was all-NaN, never plausible numbers); the captured
+                # launches would poison every later window as well: heal the handle and capture the single-workgroup kernels
+                self._capture()
+                self.recaptures += 1
             self.graph.replay()
         else:
             self.probs = self._chain()

@@ -30,6 +30,7 @@ class EmbeddingModel:
         with torch.cuda.device(self.device):
             _lib.check(self.L.mkws_embed_create(blob.ctypes.data, blob.shape[0], int(max_batch), ctypes.byref(h)))
         self.h = h
+        self.generation = _lib.next_generation()
         self.max_batch = int(max_batch)
         self._blob, self._replicas = blob, []
 
@@ -44,6 +45,7 @@ class EmbeddingModel:
         for r in getattr(self, "_replicas", []):
             r.close()
         if getattr(self, "h", None):
+            _lib.forget_graphs(self)
             self.L.mkws_embed_destroy(self.h)
             self.h = None
 

@@ -30,6 +30,7 @@ class Head:
         with torch.cuda.device(self.device):
             _lib.check(self.L.mkws_head_create(in_dim, hidden, classes, int(max_batch), ctypes.byref(h)))
         self.h = h
+        self.generation = _lib.next_generation()
         self.max_batch = int(max_batch)
         self.nparams = _lib.check(self.L.mkws_head_param_count(self.h))
         self.step_t = 0
@@ -39,6 +40,7 @@ class Head:
 
     def close(self):
         if getattr(self, "h", None):
+            _lib.forget_graphs(self)
             self.L.mkws_head_destroy(self.h)
             self.h = None
 

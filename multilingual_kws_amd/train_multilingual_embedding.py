@@ -158,7 +158,13 @@ def train_embedding(commands, train_files, val_files, bg_datadir, save_models_di
     if model_settings is not None:
         assert num_labels == model_settings["label_count"]                      # reference :62
     AUTOTUNE = input_data.AUTOTUNE
-    train_ds = a.init_from_parent_dir(AUTOTUNE, list(train_files)[rank::world], is_training=True).shuffle(buffer_size=8000).batch(batch_size)
+    # Data parallel: every rank must take the same number of steps with the same batch sizes (each step ends in collectives, and the
+    # gradient average weights the ranks equally), so the shards are EQUAL: the len(train_files) % world leftover files are dropped.
+    all_train = list(train_files)
+    per_rank = len(all_train) // world
+    if per_rank == 0:
+        raise ValueError(f"{len(all_train)} training files cannot be sharded over {world} ranks")
+    train_ds = a.init_from_parent_dir(AUTOTUNE, all_train[rank::world][:per_rank], is_training=True).shuffle(buffer_size=8000).batch(batch_size)
     val_ds = a.init_from_parent_dir(AUTOTUNE, val_files, is_training=False).batch(batch_size)
 
     if base_checkpoint is not None:

@@ -168,3 +168,63 @@ def test_streaming_session_graph_replay_equals_eager_predict(batch):
         assert torch.equal(eager.infer(a), got)
     with pytest.raises(ValueError):
         bsa.StreamingSession(models, ms, batch=batch + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 64])
+def test_graph_serving_recovers_from_a_failed_exchange(batch, tmp_path):
+    """A failed pair / cluster exchange poisons the forward that ran it (all-NaN embeddings) and is reported by the NEXT eager call --
+    but a captured hipGraph never makes an eager call.  StreamingSession / streaming_inferences therefore poll the handle's
+    "exchange_error" word: the session re-captures before its next replay (one poisoned window, never NaN for ever), the offline
+    stream is repeated on the healed handles and returns clean results."""
+    torch = pytest.importorskip("torch")
+    import warnings
+    from multilingual_kws_amd import synth
+    from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+    from multilingual_kws_amd.head import Head
+    ms = input_data.standard_microspeech_model_settings(3)
+    emb, blob = tl.load_base_model("synthetic", max_batch=batch)
+    if emb.get_option("fuse_pair") != 1:
+        pytest.skip("the exchange kernels are not in this handle's plan on this device")
+    models = [tl.TransferLearnedModel(emb, Head(max_batch=batch, seed=s), blob, "synthetic") for s in range(3)]
+    sess = bsa.StreamingSession(models, ms, batch=batch)
+    clips = synth.clips_float32(2 * batch)
+    good = [sess.infer(clips[k * batch:(k + 1) * batch]).clone() for k in range(2)]
+    assert all(torch.isfinite(g).all() for g in good) and sess.recaptures == 0
+    emb.set_option("inject_exchange_error", 1)                  # as if the previous replay's exchange had failed
+    assert emb.get_option("exchange_error") != 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        again = [sess.infer(clips[k * batch:(k + 1) * batch]).clone() for k in range(2)]
+    torch.cuda.synchronize()
+    assert sess.recaptures == 1 and emb.get_option("exchange_error") == 0 and emb.get_option("fuse_pair") == 0 and emb.get_option("pair_degraded") == 1
+    for g, a in zip(good, again):                               # healed plan = other kernels: equal up to fp32 rounding, labels exact
+        assert torch.isfinite(a).all() and torch.allclose(a, g, rtol=1e-4, atol=1e-6) and torch.equal(a.argmax(-1), g.argmax(-1))
+    # offline stream: the failure is met INSIDE the run (graph replays give no return code); the result must still be clean
+    emb2, _ = tl.load_base_model("synthetic", max_batch=batch)
+    models2 = [tl.TransferLearnedModel(emb2, m.head, blob, "synthetic") for m in models]
+    rng = np.random.default_rng(3)
+    pcm = np.concatenate([tone_clip(500 + 200 * k, rng, n=8000) for k in range(8)])       # 4 s: 150 windows
+    audio = pcm.astype(np.float32) / 32768
+    ref = bsa.streaming_inferences(models2, ms, audio, batch_windows=min(batch, 32))
+    for e in emb2.replicas(1 if emb2.get_option("fuse_cluster") else bsa.SERVING_LANES):
+        e.set_option("fuse_pair", 1)
+    orig_run, state = bsa._BatchGraph.run, {"calls": 0}
+
+    def run_then_fail(self, parts):                             # the exchange "fails" after the first replay of the stream
+        out = orig_run(self, parts)
+        state["calls"] += 1
+        if state["calls"] == 1:
+            emb2.set_option("inject_exchange_error", 1)
+        return out
+    bsa._BatchGraph.run = run_then_fail
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = bsa.streaming_inferences(models2, ms, audio, batch_windows=min(batch, 32))
+    finally:
+        bsa._BatchGraph.run = orig_run
+    assert emb2.get_option("exchange_error") == 0 and emb2.get_option("pair_degraded") == 1
+    assert any("repeating the stream" in str(x.message) for x in w)
+    for r, g in zip(ref, got):
+        assert np.isfinite(g).all() and np.allclose(g, r, rtol=1e-4, atol=1e-6) and np.array_equal(g.argmax(1), r.argmax(1))
