@@ -186,8 +186,8 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 ONE kernel behind the fused expand+depthwise kernel (the clip's depthwise output is staged in LDS once);
  *                 0 = se_reduce + se_expand + projection GEMM launches.
  *   "fuse_mid" (default 1): blocks with big images run expand -> depthwise -> SE ->
- *                 project as ONE kernel per block (depthwise output of all channels resident in LDS): 1 = blocks 3a and 4a
- *                 (where it measured faster than the three-kernel path), 2 = all of 2a..4a, 0 = never.
+ *                 project as ONE kernel per block (depthwise output of all channels resident in LDS): 1 = blocks 2b, 3a and 4a
+ *                 (where it measured faster than the front / back kernel pair), 2 = all of 2a..4a, 3 = 3a and 4a only, 0 = never.
  *   "fuse_gap" (default 1): global average pool fused into the top conv epilogue (its [B*4,1280] output is never stored).
  *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (persistent workgroups, one per CU, each walking
  *                 clips blockIdx, blockIdx + grid, ... with the next clip's spectrogram prefetched; both 25x20x32 activations stay

@@ -457,3 +457,323 @@ def import_savedmodel(path, verify=True):
             v = v.reshape(t["shape"])
         out[t["name"]] = v
     return weights.from_named_tensors(out)
+
+
+# =====================================================================================================================
+# Keras `.h5` checkpoints (tf.keras.models.load_model / load_weights accept them: transfer_learning.py:36) -- HDF5 without libhdf5.
+#
+# What h5py / HDF5 1.8-1.10 write with default settings (libver "earliest"), and all this reader accepts (HDF5 File Format
+# Specification 2.0, sections III and IV):
+#   superblock version 0 / 1 (8-byte offsets and lengths) -> root symbol-table entry -> object headers VERSION 1 (16-byte prefix,
+#   8-byte aligned messages, continuation blocks) -> old-style groups (symbol table message -> v1 B-tree of SNOD nodes, names in a
+#   local heap) -> datasets with a CONTIGUOUS or COMPACT layout, fixed-point / floating-point / fixed-length string datatypes ->
+#   attributes (message versions 1-3) holding fixed-length strings, variable-length strings in the global heap (what h5py 3 writes for
+#   Keras' layer_names / weight_names lists) or numbers.
+# Refused loudly (CheckpointFormatError), never guessed: superblock 2 / 3 and version-2 object headers ("OHDR", libver "latest"),
+# chunked / compressed / virtual layouts, variable-length or compound datatypes of DATASETS, external files, shared messages.
+# Keras' layout on top of it (keras/saving/hdf5_format.py): see tests/golden/make_h5_fixture.py.
+# Verified against files written by h5py (HDF5 1.10.6), tests/golden/keras_h5/ -- a writer this project did not write.
+# =====================================================================================================================
+HDF5_SIGNATURE = b"\x89HDF\r\n\x1a\n"
+_UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class H5File:
+    """Minimal read-only view of an HDF5 file: groups as {name: object-header address}, datasets as numpy arrays, attributes."""
+
+    def __init__(self, path):
+        with open(path, "rb") as f:
+            self.buf = f.read()
+        b = self.buf
+        base = None
+        for off in [0] + [512 << k for k in range(0, 12)]:
+            if b[off:off + 8] == HDF5_SIGNATURE:
+                base = off
+                break
+        if base is None:
+            raise CheckpointFormatError(f"{path}: no HDF5 signature")
+        ver = b[base + 8]
+        if ver not in (0, 1):
+            raise CheckpointFormatError(f"{path}: HDF5 superblock version {ver} (written with libver='latest'?): only versions 0 and 1 are read; "
+                                        "re-save with h5py's default libver or convert with `h5repack --low=EARLIEST --high=V18`")
+        so, sl = b[base + 13], b[base + 14]
+        if (so, sl) != (8, 8):
+            raise CheckpointFormatError(f"{path}: {so}-byte offsets / {sl}-byte lengths (only 8 / 8 are read)")
+        p = base + 24 + (4 if ver == 1 else 0)
+        self.base_addr, _free, self.eof, _drv = struct.unpack_from("<4Q", b, p)
+        p += 32
+        _name_off, root_oh, cache, _r = struct.unpack_from("<QQII", b, p)
+        self.root = root_oh
+        if self.eof > len(b) + self.base_addr:
+            raise CheckpointFormatError(f"{path}: truncated (end-of-file address {self.eof}, file has {len(b)} bytes)")
+
+    # ---- object headers ------------------------------------------------------------------------------------------
+    def messages(self, addr):
+        """[(type, flags, payload bytes)] of the version-1 object header at addr (continuation blocks followed)."""
+        b = self.buf
+        a = addr + self.base_addr
+        if b[a:a + 4] == b"OHDR":
+            raise CheckpointFormatError("version-2 object header (file written with libver='latest'): not read")
+        if b[a] != 1:
+            raise CheckpointFormatError(f"object header version {b[a]} at {addr}")
+        nmsg, _ref, hsize = struct.unpack_from("<HII", b, a + 2)
+        blocks = [(a + 16, hsize)]
+        out = []
+        while blocks and len(out) < nmsg:
+            p, left = blocks.pop(0)
+            end = p + left
+            while p + 8 <= end and len(out) < nmsg:
+                mtype, msize, mflags = struct.unpack_from("<HHB", b, p)
+                payload = b[p + 8:p + 8 + msize]
+                if mflags & 0x02:
+                    raise CheckpointFormatError(f"shared object-header message (type {mtype:#x}): not read")
+                if mtype == 0x0010:                                  # continuation: (address, length)
+                    ca, cl = struct.unpack_from("<QQ", payload, 0)
+                    blocks.append((ca + self.base_addr, cl))
+                out.append((mtype, mflags, payload))
+                p += 8 + msize
+        return out
+
+    # ---- groups --------------------------------------------------------------------------------------------------
+    def _heap_string(self, heap_addr, off):
+        b = self.buf
+        h = heap_addr + self.base_addr
+        if b[h:h + 4] != b"HEAP":
+            raise CheckpointFormatError("bad local heap signature")
+        data_addr = struct.unpack_from("<Q", b, h + 24)[0] + self.base_addr
+        e = b.index(b"\x00", data_addr + off)
+        return b[data_addr + off:e].decode("utf-8")
+
+    def _btree_group(self, node_addr, heap_addr, out):
+        b = self.buf
+        a = node_addr + self.base_addr
+        if b[a:a + 4] == b"SNOD":
+            nsym = struct.unpack_from("<H", b, a + 6)[0]
+            for i in range(nsym):
+                name_off, oh = struct.unpack_from("<QQ", b, a + 8 + 40 * i)
+                out[self._heap_string(heap_addr, name_off)] = oh
+            return
+        if b[a:a + 4] != b"TREE":
+            raise CheckpointFormatError(f"bad group B-tree node signature at {node_addr}")
+        ntype, _level, used = struct.unpack_from("<BBH", b, a + 4)
+        if ntype != 0:
+            raise CheckpointFormatError("group B-tree node of type %d" % ntype)
+        p = a + 24                                                   # after left / right sibling addresses
+        for i in range(used):                                        # key_i (8), child_i (8), ..., key_used
+            child = struct.unpack_from("<Q", b, p + 8 + 16 * i)[0]
+            self._btree_group(child, heap_addr, out)
+
+    def members(self, addr):
+        """{link name: object-header address} of the group at addr, in name order (old-style groups only)."""
+        for mtype, _f, pl in self.messages(addr):
+            if mtype == 0x0011:
+                btree, heap = struct.unpack_from("<QQ", pl, 0)
+                out = {}
+                self._btree_group(btree, heap, out)
+                return out
+            if mtype in (0x0002, 0x0006):
+                raise CheckpointFormatError("new-style group (link messages): not read")
+        return None                                                  # not a group
+
+    # ---- datatypes / dataspaces ------------------------------------------------------------------------------------
+    @staticmethod
+    def _dtype(pl):
+        cv, b0, _b1, _b2, size = struct.unpack_from("<BBBBI", pl, 0)
+        cls, ver = cv & 0x0F, cv >> 4
+        if ver not in (1, 2, 3):
+            raise CheckpointFormatError(f"datatype message version {ver}")
+        order = ">" if (b0 & 1) else "<"
+        if cls == 0:                                                 # fixed point
+            signed = bool(b0 & 0x08)
+            return np.dtype(f"{order}{'i' if signed else 'u'}{size}")
+        if cls == 1:                                                 # IEEE floating point (sizes 2, 4, 8)
+            if size not in (2, 4, 8):
+                raise CheckpointFormatError(f"{size}-byte floating-point type")
+            return np.dtype(f"{order}f{size}")
+        if cls == 3:                                                 # fixed-length string
+            return np.dtype(f"S{size}")
+        if cls == 9 and (b0 & 0x0F) == 1:                            # variable-length STRING: (length, global-heap address, index) per element
+            return "vlen-string"
+        names = {2: "time", 4: "bit field", 5: "opaque", 6: "compound", 7: "reference", 8: "enum", 9: "variable-length", 10: "array"}
+        raise CheckpointFormatError(f"HDF5 datatype class {cls} ({names.get(cls, '?')}): not read")
+
+    @staticmethod
+    def _shape(pl):
+        ver, rank, flags = pl[0], pl[1], pl[2]
+        if ver == 1:
+            p = 8
+        elif ver == 2:
+            if pl[3] == 2:
+                return None                                          # null dataspace
+            p = 4
+        else:
+            raise CheckpointFormatError(f"dataspace message version {ver}")
+        return tuple(struct.unpack_from("<%dQ" % rank, pl, p)) if rank else ()
+
+    def _global_heap_object(self, coll_addr, index):
+        """Object `index` of the global heap collection at coll_addr (variable-length data lives there)."""
+        b = self.buf
+        a = coll_addr + self.base_addr
+        if b[a:a + 4] != b"GCOL":
+            raise CheckpointFormatError("bad global heap signature")
+        size = struct.unpack_from("<Q", b, a + 8)[0]
+        p, end = a + 16, a + size
+        while p + 16 <= end:
+            idx, _ref, _r, osz = struct.unpack_from("<HHIQ", b, p)
+            if idx == 0:
+                break                                                # free space: end of the objects
+            if idx == index:
+                return b[p + 16:p + 16 + osz]
+            p += 16 + ((osz + 7) & ~7)
+        raise CheckpointFormatError(f"global heap object {index} not found in the collection at {coll_addr}")
+
+    # ---- datasets --------------------------------------------------------------------------------------------------
+    def dataset(self, addr):
+        dt = shape = layout = None
+        for mtype, _f, pl in self.messages(addr):
+            if mtype == 0x0001:
+                shape = self._shape(pl)
+            elif mtype == 0x0003:
+                dt = self._dtype(pl)
+            elif mtype == 0x0008:
+                layout = pl
+            elif mtype == 0x000B:
+                raise CheckpointFormatError("dataset with a filter pipeline (compressed): not read")
+            elif mtype == 0x0007:
+                raise CheckpointFormatError("dataset stored in external files: not read")
+        if dt is None or shape is None or layout is None:
+            raise CheckpointFormatError(f"object at {addr} is not a dataset")
+        if isinstance(dt, str):
+            raise CheckpointFormatError("dataset of variable-length strings: not read")
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        ver, cls = layout[0], layout[1]
+        if ver != 3:
+            raise CheckpointFormatError(f"data layout message version {ver} (only version 3 is read)")
+        if cls == 0:                                                 # compact: data inside the header
+            size = struct.unpack_from("<H", layout, 2)[0]
+            raw = layout[4:4 + size]
+        elif cls == 1:                                               # contiguous
+            daddr, size = struct.unpack_from("<QQ", layout, 2)
+            if daddr == _UNDEF:
+                return np.zeros(shape, dt.newbyteorder("="))          # never written: fill value 0
+            raw = self.buf[daddr + self.base_addr:daddr + self.base_addr + size]
+        else:
+            raise CheckpointFormatError("chunked dataset layout (chunking / compression): not read -- Keras writes contiguous datasets; "
+                                        "h5repack -l CONTI converts")
+        if len(raw) < n * dt.itemsize:
+            raise CheckpointFormatError(f"dataset at {addr}: {len(raw)} bytes for {n} x {dt}")
+        return np.frombuffer(raw, dtype=dt, count=n).reshape(shape).astype(dt.newbyteorder("="))
+
+    # ---- attributes ------------------------------------------------------------------------------------------------
+    def attributes(self, addr):
+        """{name: ndarray} for the attributes this reader understands (others are skipped: Keras' JSON configs may be variable-length)."""
+        out = {}
+        for mtype, _f, pl in self.messages(addr):
+            if mtype != 0x000C:
+                continue
+            ver = pl[0]
+            nsz, dsz, ssz = struct.unpack_from("<HHH", pl, 2)
+            if ver == 1:
+                p = 8
+                pad = lambda n: (n + 7) & ~7
+            elif ver in (2, 3):
+                p = 8 if ver == 2 else 9
+                pad = lambda n: n
+                if pl[1] & 0x03:
+                    continue                                         # shared datatype / dataspace
+            else:
+                continue
+            name = pl[p:p + nsz].split(b"\x00")[0].decode("utf-8")
+            p += pad(nsz)
+            try:
+                dt = self._dtype(pl[p:p + dsz])
+            except CheckpointFormatError:
+                continue                                             # e.g. variable-length strings
+            p += pad(dsz)
+            shape = self._shape(pl[p:p + ssz])
+            p += pad(ssz)
+            if shape is None:
+                continue
+            n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+            if dt == "vlen-string":                                  # what h5py 3 writes for a list of (byte) strings
+                vals = []
+                for i in range(n):
+                    ln, coll, idx = struct.unpack_from("<IQI", pl, p + 16 * i)
+                    vals.append(self._global_heap_object(coll, idx)[:ln] if ln else b"")
+                arr = np.empty(n, dtype=object)
+                arr[:] = vals
+                out[name] = arr.reshape(shape)
+            else:
+                out[name] = np.frombuffer(pl[p:p + n * dt.itemsize], dtype=dt, count=n).reshape(shape)
+        return out
+
+    def walk(self, addr, prefix=""):
+        """Yields (path, object-header address) of every dataset below the group at addr."""
+        mem = self.members(addr)
+        if mem is None:
+            yield prefix, addr
+            return
+        for name in mem:
+            yield from self.walk(mem[name], f"{prefix}/{name}" if prefix else name)
+
+
+def _attr_strings(attrs, name):
+    """Keras' (possibly chunked: name0, name1, ...) list-of-strings attribute -> [str]."""
+    parts = [attrs[name]] if name in attrs else []
+    k = 0
+    while not parts or k > 0:
+        key = f"{name}{k}"
+        if key not in attrs:
+            break
+        parts.append(attrs[key])
+        k += 1
+    out = []
+    for a in parts:
+        for s in np.atleast_1d(a).tolist():
+            out.append(s.decode("utf-8") if isinstance(s, bytes) else str(s))
+    return out
+
+
+def load_h5(path):
+    """Keras `.h5` (model.save or model.save_weights) -> {"named": {Keras variable name: ndarray}, "layers": [(layer, [weight names])]}.
+    Variable names are the dataset names without ':0' ("stem_conv/kernel"); names inside a nested model keep their own prefix."""
+    f = H5File(path)
+    root = f.members(f.root)
+    if root is None:
+        raise CheckpointFormatError(f"{path}: root object is not a group")
+    top = root["model_weights"] if "model_weights" in root else f.root
+    attrs = f.attributes(top)
+    members = f.members(top)
+    layer_names = _attr_strings(attrs, "layer_names") or sorted(k for k, v in members.items() if f.members(v) is not None)
+    named, layers = {}, []
+    for lname in layer_names:
+        if lname not in members:
+            raise CheckpointFormatError(f"{path}: layer_names lists '{lname}' but the file has no such group")
+        g = members[lname]
+        wnames = _attr_strings(f.attributes(g), "weight_names")
+        datasets = dict(f.walk(g))
+        if not wnames:
+            wnames = sorted(datasets)
+        for w in wnames:
+            if w not in datasets:
+                raise CheckpointFormatError(f"{path}: layer '{lname}' lists weight '{w}' but holds {sorted(datasets)[:4]}...")
+            named[_short(w)] = f.dataset(datasets[w])
+        layers.append((lname, wnames))
+    return {"named": named, "layers": layers}
+
+
+def import_h5(path):
+    """Keras `.h5` checkpoint -> weight blob of multilingual_kws_amd.weights (every manifest tensor must be present, shapes checked)."""
+    from . import weights
+    named = load_h5(path)["named"]
+    out = {}
+    for t in weights.manifest():
+        if t["name"] not in named:
+            raise CheckpointFormatError(f"{path}: no variable '{t['name']}' (file has {len(named)} variables, e.g. {sorted(named)[:3]})")
+        v = np.asarray(named[t["name"]], dtype=np.float32)
+        if t["name"].startswith("normalization/") and v.size == 1:
+            v = v.reshape(t["shape"])
+        if list(v.shape) != list(t["shape"]):
+            raise CheckpointFormatError(f"{path}: '{t['name']}' has shape {list(v.shape)}, the embedding needs {t['shape']}")
+        out[t["name"]] = v
+    return weights.from_named_tensors(out)

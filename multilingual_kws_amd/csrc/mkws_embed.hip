@@ -2314,23 +2314,28 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
     for (int task = tid; task < G * Q; task += NTHR) {
       const int gi = task / Q, q4 = (task - gi * Q) * 4;
       float* Eg = s_E + (size_t)gi * HW * LDE + q4;
-      // every tap this image uses and the BN constants are requested FIRST, in source order: hipcc leaves this region in source order
-      // (in mbconv_block_kernel its scheduler hoists the loads by itself; here, "load a tap, use it" ran one L2 latency per tap)
-      f32x4 wv[KS * KS];
+      // The taps are requested in SOURCE order ahead of their use (hipcc leaves this region in source order: with "load a tap, use it"
+      // the phase ran one L2 latency per tap; mbconv_block_kernel's scheduler hoists all 25 loads by itself, but here 12 inputs + 12
+      // outputs + 25 taps do not fit next to what the block loop keeps alive).  Kernel rows [0, PRE) first; row i + PRE goes into the
+      // registers of row i once row i has been used, so at most PRE rows of taps are live.
+      constexpr int PRE = (KS == 5) ? (MT >= 3 ? 3 : 2) : KS;      // (2-clip workgroups carry a wider expand ring: one row less in flight)
+      auto tap_used = [](int i, int jx) {
+        bool used = false;
+        for (int oh = 0; oh < HoT; ++oh)
+          for (int ow = 0; ow < WoT; ++ow) {
+            const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+            used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+          }
+        return used;
+      };
+      f32x4 wv[KS][KS];
+      auto load_row = [&](int i) {
 #pragma unroll
-      for (int i = 0; i < KS; ++i)
+        for (int jx = 0; jx < KS; ++jx)
+          if (tap_used(i, jx)) wv[i][jx] = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + q4);
+      };
 #pragma unroll
-        for (int jx = 0; jx < KS; ++jx) {
-          bool used = false;
-#pragma unroll
-          for (int oh = 0; oh < HoT; ++oh)
-#pragma unroll
-            for (int ow = 0; ow < WoT; ++ow) {
-              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
-              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
-            }
-          if (used) wv[i * KS + jx] = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + q4);
-        }
+      for (int i = 0; i < PRE; ++i) load_row(i);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + q4);
       const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + q4);
       f32x4 ein[HW];
@@ -2349,8 +2354,13 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
 #pragma unroll
             for (int ow = 0; ow < WoT; ++ow) {
               const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
-              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv[i * KS + jx];
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv[i][jx];
             }
+        }
+        if (i + PRE < KS) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_row(i + PRE);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
@@ -3555,7 +3565,7 @@ struct mkws_embed {
   int fuse_gap = 1;                // global average pool fused into the top conv's epilogue (2x2 image: 4 rows per clip)
   int fuse_stem = 1;               // 1: stem + whole block 1a in one kernel (stem_block1a_kernel); 0: separate kernels (parity taps)
   int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
-  int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 3a and 4a (where it measured faster), 2 = 2a..4a, 0 = never
+  int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 2b, 3a and 4a (where it measured faster), 2 = 2a..4a, 3 = 3a and 4a only, 0 = never
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   int fuse_chain = 1;              // consecutive 4x3-image blocks (4b..6a) in ONE launch (mbconv_chain_kernel): activations stay in LDS from block to block
   mkws::BlockArgs* d_chain_tab = nullptr;   // device copy of every block's constants (BlockArgs without X / Y / dbg) for the chain kernels
@@ -4303,11 +4313,12 @@ int launch_mid_inst(hipStream_t s, const char* stage, const MidArgs& a) {
   return MKWS_OK;
 }
 
-// fuse_mid: 1 = the blocks where the whole-block kernel measured faster (3a, 4a); 2 = all five big-image blocks
+// fuse_mid: 1 = the blocks where the whole-block kernel measured faster (2b, 3a, 4a); 3 = 3a and 4a only (rounds 2-3); 2 = all five big-image blocks
 // (A/B and parity runs); 0 = the three-kernel path everywhere.
 bool mid_enabled(const BlockPlan& b, int fuse_mid) {
   if (!fuse_mid || !mid_supported(b)) return false;
-  if (fuse_mid >= 2) return true;
+  if (fuse_mid == 2) return true;
+  if (b.H == 13 && b.spec.kernel == 3) return fuse_mid == 1;           // 2b: 67.9 us against 40.4 + 31.8 for the front / back pair (round 4; before the round-3 mid-kernel work it tied)
   return (b.H == 13 && b.spec.kernel == 5) || (b.H == 7 && b.spec.stride == 2);
 }
 

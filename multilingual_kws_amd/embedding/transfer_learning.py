@@ -26,7 +26,8 @@ CATEGORIES = 3   # silence + unknown + target keyword
 def load_base_model(base_model_path, max_batch=1024, base_model_output="dense_2"):
     """The frozen embedding model.  base_model_path: what the reference passes to tf.keras.models.load_model
     (transfer_learning.py:36) -- a Keras SavedModel directory such as multilingual_context_73_0.8011, read without
-    TensorFlow by multilingual_kws_amd.checkpoint_import -- or a weight-container directory written by
+    TensorFlow by multilingual_kws_amd.checkpoint_import -- or a Keras `.h5` file (model.save / save_weights; read by the same module's
+    pure-Python HDF5 reader) -- or a weight-container directory written by
     multilingual_kws_amd.weights.save() (flat float32 blob + manifest with Keras variable names), or
     "synthetic[:SEED]" for the seeded random weights used by benchmarks."""
     p = str(base_model_path)
@@ -36,6 +37,9 @@ def load_base_model(base_model_path, max_batch=1024, base_model_output="dense_2"
     elif os.path.exists(os.path.join(p, "variables", "variables.index")):
         from .. import checkpoint_import
         blob = checkpoint_import.import_savedmodel(p)
+    elif os.path.isfile(p) and p.lower().endswith((".h5", ".hdf5", ".keras.h5")):
+        from .. import checkpoint_import                # the other format tf.keras.models.load_model takes: read without libhdf5
+        blob = checkpoint_import.import_h5(p)
     else:
         blob = weights.load(p)
     return EmbeddingModel(blob, max_batch=max_batch, output=base_model_output), blob

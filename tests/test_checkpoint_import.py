@@ -34,6 +34,19 @@ def test_snappy_known_answer_vectors():
         ci.snappy_decompress(bytes([9, 0, ord("x")]))                        # shorter than its header says
 
 
+def test_snappy_decoder_against_the_reference_library(golden_dir):
+    """Streams compressed by Google's libsnappy 1.1.8 (tests/golden/make_snappy_fixture.py, ctypes; fixture = bytes in / bytes out):
+    literals of every length class, 1- and 2-byte-offset copies, overlapping copies, multi-block inputs, SSTable-like blocks."""
+    G = np.load(os.path.join(golden_dir, "snappy_vectors.npz"))
+    names = [k[2:] for k in G.files if k.startswith("z/")]
+    assert len(names) == 14
+    for n in names:
+        assert bytes(ci.snappy_decompress(G["z/" + n].tobytes())) == G["in/" + n].tobytes(), n
+    z = G["z/text"].tobytes()
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.snappy_decompress(z[:len(z) // 2])                    # truncated stream
+
+
 @pytest.mark.parametrize("compress", [False, True])
 @pytest.mark.parametrize("block_entries,restart", [(1, 1), (7, 4), (1000, 16)])
 def test_table_round_trip(tmp_path, compress, block_entries, restart):
@@ -186,3 +199,73 @@ def test_hand_assembled_bundle_from_the_format_specs(golden_dir, tmp_path):
         line = [ln for ln in out.stdout.splitlines() if ln.startswith(key + " ")]
         assert len(line) == 1 and exp["sha1"] in line[0] and "crc32c ok" in line[0] and str(exp["shape"]).replace(" ", "") in line[0].replace(" ", "")
     assert "2 tensors, 0 bad" in out.stdout
+
+
+# ---- Keras .h5 (HDF5 without libhdf5) against files written by h5py: tests/golden/keras_h5/, tests/golden/make_h5_fixture.py ----------------
+def test_h5_reader_against_h5py_written_files(golden_dir):
+    """Every tensor of the two Keras-layout files (save_weights form and whole-model form) equals what the generator put in: 321
+    datasets, ranks 0-4, float32 / float64 / int64 / big-endian, nested-model layer group, B-trees with several SNOD leaves,
+    variable-length (h5py 3) / fixed-length / chunked (name0, name1) string attributes -- all written by h5py + libhdf5 1.10.6."""
+    exp = np.load(os.path.join(golden_dir, "keras_h5", "expected.npz"))
+    for fn in ("weights.h5", "model.h5"):
+        r = ci.load_h5(os.path.join(golden_dir, "keras_h5", fn))
+        named = r["named"]
+        assert len(named) == len(exp.files) == 321
+        for k in exp.files:
+            got = named[k.replace("|", "/")]
+            assert got.shape == exp[k].shape and got.dtype.kind == exp[k].dtype.kind and got.dtype.itemsize == exp[k].dtype.itemsize, k
+            assert np.array_equal(got, exp[k]), (fn, k)
+        assert [l for l, _ in r["layers"]] == ["efficientnetb0", "global_average_pooling2d", "dense", "dense_1", "dense_2"]     # layer_names order, not alphabetical
+        assert r["layers"][0][1][:3] == ["normalization/mean:0", "normalization/variance:0", "normalization/count:0"] and len(r["layers"][0][1]) == 312
+        assert r["layers"][3][1] == ["dense_1/kernel:0", "dense_1/bias:0"]            # joined from weight_names0 + weight_names1
+    f = ci.H5File(os.path.join(golden_dir, "keras_h5", "model.h5"))
+    attrs = f.attributes(f.root)
+    assert attrs["keras_version"].item() == b"2.7.0" and attrs["backend"].item() == b"tensorflow" and b"Functional" in attrs["model_config"].item()
+    root = f.members(f.root)
+    assert set(root) == {"model_weights", "optimizer_weights", "compressed_extra"}
+    assert int(f.dataset(dict(f.walk(root["optimizer_weights"]))["Adam/iter:0"])) == 12345
+    with pytest.raises(ci.CheckpointFormatError, match="compressed|chunked"):        # refused loudly, never misread
+        f.dataset(root["compressed_extra"])
+
+
+def test_h5_errors(tmp_path, golden_dir):
+    p = tmp_path / "not.h5"
+    p.write_bytes(b"PK\x03\x04" + b"\x00" * 600)
+    with pytest.raises(ci.CheckpointFormatError, match="signature"):
+        ci.load_h5(str(p))
+    raw = open(os.path.join(golden_dir, "keras_h5", "weights.h5"), "rb").read()
+    q = tmp_path / "cut.h5"
+    q.write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(ci.CheckpointFormatError, match="truncated"):
+        ci.load_h5(str(q))
+    v2 = bytearray(raw); v2[8] = 2
+    (tmp_path / "v2.h5").write_bytes(bytes(v2))
+    with pytest.raises(ci.CheckpointFormatError, match="superblock version 2"):
+        ci.load_h5(str(tmp_path / "v2.h5"))
+    with pytest.raises(ci.CheckpointFormatError, match="no variable|shape"):          # the reduced-extent fixture is not a full checkpoint
+        ci.import_h5(os.path.join(golden_dir, "keras_h5", "weights.h5"))
+
+
+H5PY_PYTHON = "/opt/conda/bin/python3.9"
+
+
+@pytest.mark.skipif(not os.path.exists(H5PY_PYTHON), reason="no interpreter with h5py in this image")
+def test_full_size_h5_checkpoint_round_trip(tmp_path, golden_dir, monkeypatch):
+    """The whole 13 M-parameter blob written as a Keras whole-model .h5 by h5py at test time, imported back bit for bit, and
+    load_base_model dispatching on the file name (the reference: tf.keras.models.load_model(base_model_path), transfer_learning.py:36)."""
+    import subprocess
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding import transfer_learning as tl
+    blob = weights.synthetic_blob(5, calibrate=False)
+    np.save(tmp_path / "blob.npy", blob)
+    manifest = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "embedding_manifest.json")
+    out = str(tmp_path / "multilingual_context_73_0.8011.h5")
+    subprocess.run([H5PY_PYTHON, os.path.join(golden_dir, "make_h5_fixture.py"), "--full", out, str(tmp_path / "blob.npy"), manifest], check=True,
+                   env={k: v for k, v in os.environ.items() if not k.startswith("PYTHON")})
+    assert os.path.getsize(out) > 50e6
+    got = ci.import_h5(out)
+    assert got.dtype == np.float32 and np.array_equal(got, blob)
+    seen = {}
+    monkeypatch.setattr(tl, "EmbeddingModel", lambda b, max_batch, output: seen.setdefault("blob", b) is None or "handle")
+    tl.load_base_model(out, max_batch=4)
+    assert np.array_equal(seen["blob"], blob)

@@ -101,6 +101,20 @@ def test_depth_fused_chain_is_bit_identical_to_the_single_block_kernels(ctx):
         em.set_option("fuse_chain", 1)
     ref = ctx["oracle"].forward(spec[:16]).numpy()
     assert _rel(got[1024][:16].cpu().numpy(), ref) < REL_TOL
+    # handles of at most 512 clips give the 4x3-image workgroups 2 clips (24 of 32 rows): the other instantiation of the chain
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    em2 = EmbeddingModel(ctx["blob"], max_batch=512)
+    try:
+        got2 = {b: em2.forward(x[:b]).clone() for b in (512, 511, 37, 2, 1)}
+        taps2 = {n: em2.tap(x[:9], n).clone() for n in ("block4c", "block5a", "block5c", "block6a")}
+        em2.set_option("fuse_chain", 0)
+        for b, e in got2.items():
+            assert torch.equal(em2.forward(x[:b]), e), b
+        for n, t in taps2.items():
+            assert torch.equal(em2.tap(x[:9], n), t), n
+        assert _rel(got2[512][:16].cpu().numpy(), ref) < REL_TOL
+    finally:
+        em2.close()
 
 
 def test_golden_embedding_on_device(ctx, golden_dir):

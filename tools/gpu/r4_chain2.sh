@@ -8,3 +8,4 @@ AB_OPTION=fuse_chain timeout 300 python tools/kernel_table.py 512 20 "" > $O/tab
 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/embed.json 2> $O/embed.err; echo "bench rc=$?"; cat $O/embed.json | python -c "
 import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'],d['roofline']['whole_step_frac'])
 for k,v in list(d['kernels'].items())[:6]: print('  %-50s %.4f ms  %.3f'%(k,v['ms_per_step'],v['frac']))"
+AB_OPTION=fuse_mid AB_VALUES=1,2 timeout 300 python tools/kernel_table.py 1024 20 "" > $O/table_mid.txt 2>&1; grep -E "pass|block2a|block2b|block3b" $O/table_mid.txt

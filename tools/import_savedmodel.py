@@ -5,7 +5,9 @@ WITHOUT TensorFlow (multilingual_kws_amd/checkpoint_import.py reads the variable
     python tools/import_savedmodel.py /path/to/multilingual_context_73_0.8011 out_dir
     python tools/import_savedmodel.py --verify /path/to/multilingual_context_73_0.8011
 
-(transfer_learn / load_base_model also accept the SavedModel directory itself.)
+    python tools/import_savedmodel.py /path/to/model.h5 out_dir            (a Keras .h5 checkpoint: pure-Python HDF5 reader)
+
+(transfer_learn / load_base_model also accept the SavedModel directory or the .h5 file itself.)
 
 --verify imports nothing: it walks the variables bundle (<dir>/variables/variables.* or <dir>/variables.*), checks every
 block CRC of the index and every tensor's stored CRC-32C against its bytes, and prints one line per tensor
@@ -22,9 +24,25 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def verify_h5(path):
+    """One line per dataset of a Keras .h5 file: <variable> <dtype> <shape> <bytes> sha1 (compare with h5py: hashlib.sha1(np.asarray(d).tobytes()))."""
+    import numpy as np
+    from multilingual_kws_amd import checkpoint_import as ci, weights
+    r = ci.load_h5(path)
+    for name, v in r["named"].items():
+        v = np.ascontiguousarray(v)
+        print(f"{name} {v.dtype.name} {list(v.shape)} {v.nbytes} sha1 {hashlib.sha1(v.tobytes()).hexdigest()}")
+    missing = [t["name"] for t in weights.manifest() if t["name"] not in r["named"]]
+    print(f"# {len(r['named'])} variables in layers {[l for l, _ in r['layers']]}; embedding architecture: {len(weights.manifest()) - len(missing)} of "
+          f"{len(weights.manifest())} tensors found by name" + (f"; missing e.g. {missing[:3]}" if missing else ""))
+    return 1 if missing else 0
+
+
 def verify(path):
     import numpy as np
     from multilingual_kws_amd import checkpoint_import as ci
+    if os.path.isfile(path):
+        return verify_h5(path)
     prefix = os.path.join(path, "variables", "variables")
     if not os.path.exists(prefix + ".index"):
         prefix = os.path.join(path, "variables")
@@ -71,6 +89,6 @@ if __name__ == "__main__":
         raise SystemExit(__doc__)
     from multilingual_kws_amd import checkpoint_import, weights
     src, dst = sys.argv[1], sys.argv[2]
-    blob = checkpoint_import.import_savedmodel(src)
+    blob = checkpoint_import.import_h5(src) if os.path.isfile(src) else checkpoint_import.import_savedmodel(src)      # a Keras .h5 file, or a SavedModel directory
     weights.save(dst, blob)
     print(f"wrote {blob.shape[0]} floats to {dst}")
