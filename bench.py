@@ -261,7 +261,7 @@ def embed_roofline(em, spec, B, reps, arch, extra=None):
             act = {n: (ci, co, s_) for n, ci, co, _, s_, _ in arch.BLOCKS}
             by = sum(costs["block" + n + "_block"][1] for n in names)
             for a_, b_ in zip(names[:-1], names[1:]):
-                m = B * 12
+                m = B * (12 if a_[0] in "45" else 4)                   # pixels per clip of the activation between the two blocks
                 co = act[a_][1]
                 by -= 4 * m * co * 2                                    # a_'s output store + b_'s input load
                 if act[b_][2] == 1 and act[b_][0] == act[b_][1]:

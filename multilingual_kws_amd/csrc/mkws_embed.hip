@@ -2184,7 +2184,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
 //     a lane-linear ds_write_b128, no transpose) -- the activations of the chain never leave the CU;
 //   * the same lane finishes the same (tile, row tile) in the next block (Cin == Cout whenever a block has a residual), so
 //     the residual rides in registers (carry) instead of being re-read;
-//   * block k + 1's expand ring and BN constants are requested while block k's gate / projection phases run.
+//   * block k + 1's expand BN constants are requested while block k's SE phases run (its weight ring is requested at the top of the
+//     block: see chain_block).
 // Only the chain's input and its last block's output touch HBM (the launcher stops the chain at a tapped block, so the
 // parity taps see the chain's own arithmetic).  Same operations in the same order as mbconv_block_kernel: bit-identical.
 constexpr int kChainMax = 6;
@@ -2233,7 +2234,7 @@ __device__ __forceinline__ BlockArgs sgpr_block_args(const BlockArgs& t) {
 
 template <int KS, int S, int MT, int NWAVES>
 __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs* nxp, bool has_next, float* s_blk, int ldsU, int ldsE, bool first,
-                                            f32x4 (&wqa)[4][(MT >= 3) ? 1 : 2], f32x4 (&carry)[MT], unsigned long long* dbg_t) {
+                                            f32x4 (&carry)[MT], unsigned long long* dbg_t) {
   constexpr int NTHR = NWAVES * 64;
   const BlockArgs* nx = has_next ? nxp : nullptr;      // nxp is always a valid table entry (the block itself when there is no next one)
   constexpr int HT = 4, WT = 3, HW = HT * WT;
@@ -2274,6 +2275,11 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   const int a_runs = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
   auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
   {
+    // The expand ring is requested HERE.  Requesting it during the previous block's projection (so that phase A never starts on an
+    // empty ring) was measured and lost: carried across the block loop the ring's 16-32 registers cost the kernel ~30-50 (227 / 247
+    // instead of 199 / 195 VGPRs) and 3 us per launch (profiles/r04_notes.md); its L2 round trip now runs once per block.
+    f32x4 wqa[4][NTWA];
+    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, a_runs, a.KCe, a_tile_of);
     auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
     auto xmake = [](const f32x4& v) { return v; };
     auto epi = [&](int t0, const f32x4 (&acc)[NTWA][MT]) {
@@ -2308,7 +2314,12 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   f32x4 wq1[3][3];
   // (5x5: a thread holds 12 inputs + 12 outputs + 25 taps -- 196 registers; C1's ring is requested behind the depthwise loop there,
   // where waves that own one round of tasks wait for those that own two)
-  if (KS == 3) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+#ifdef MKWS_CHAIN_WQ1_EARLY
+  constexpr bool kWq1Early = true;
+#else
+  constexpr bool kWq1Early = (KS == 3);
+#endif
+  if (kWq1Early) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   {
     const int Q = Cexp / 4;
     for (int task = tid; task < G * Q; task += NTHR) {
@@ -2375,7 +2386,7 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
       *reinterpret_cast<f32x4*>(s_S + (size_t)gi * Cexp + q4) = ssum * (1.0f / (float)HoWo);
     }
   }
-  if (KS != 3) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  if (!kWq1Early) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   __syncthreads();
 
 #ifdef MKWS_FRONT_TIMING
@@ -2486,15 +2497,6 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   // ---- phase D: gated project (+ residual).  The next block's expand ring is requested first; the output tile becomes the
   //      next block's input fragments in U (free since the gate was applied) and this lane's residual (carry) ----
   {
-    // UNCONDITIONAL (the last block of a chain re-requests its own first fragments, four wasted loads per wave): a ring that is
-    // refilled only "if there is a next block" stays live across the block loop, and its 16-32 registers push the depthwise phase
-    // into spills
-    const int nNTe = sgpr_(nxp->NTe), nKCe = sgpr_(nxp->KCe);
-    const int n_groups = (nNTe + NTWA - 1) / NTWA;
-    const int n_runs = (n_groups > wave) ? (n_groups - wave + NWAVES - 1) / NWAVES : 0;
-    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(sgpr_(nxp->WpE), loff), (size_t)nNTe * 256, nNTe, n_runs, nKCe, a_tile_of);
-  }
-  {
     const size_t cstride = (size_t)a.NTp * 256;
     const float* erow[MTO];
 #pragma unroll
@@ -2566,30 +2568,23 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca)
   extern __shared__ __attribute__((aligned(16))) float s_blk[];
   constexpr int NTHR = NWAVES * 64;
   constexpr int HW = 12, G = MT * 16 / HW;
-  constexpr int NTWA = (MT >= 3) ? 1 : 2;
   const BlockArgs* __restrict__ tab = ca.tab + ca.i0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const unsigned loff = (unsigned)(g * 64 + c * 4);
 #ifdef MKWS_FRONT_TIMING
   if (ca.dbg_t && threadIdx.x == 0) ca.dbg_t[(size_t)gridDim.x * kChainMax * 8 + blockIdx.x] = wall_clock64();
 #endif
-  f32x4 wqa[4][NTWA];
   f32x4 carry[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) carry[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     // prologue = the head of mbconv_block_kernel: first block's expand ring, then its input tile and BN constants
-    const int Cin = sgpr_(tab[0].Cin), KCe = sgpr_(tab[0].KCe), NTe = sgpr_(tab[0].NTe), Cexp = sgpr_(tab[0].Cexp);
+    const int Cin = sgpr_(tab[0].Cin), KCe = sgpr_(tab[0].KCe), Cexp = sgpr_(tab[0].Cexp);
     const int b0 = blockIdx.x * G;
     const int gvalid = (ca.B - b0 < G) ? (ca.B - b0) : G;
     const int rows_in = gvalid * HW;
     const size_t row0_in = (size_t)b0 * HW;
-    const int a_groups = (NTe + NTWA - 1) / NTWA;
-    const int a_runs = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
-    auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
-    stream_mfma_runs_prefetch<NTWA, 4>(wqa, WBuf(sgpr_(tab[0].WpE), loff), (size_t)NTe * 256, NTe, a_runs, KCe, a_tile_of);
     float* s_X = s_blk;
     float* s_scE = s_blk + ca.ldsU + ca.ldsE;
     for (int jm = wave; jm < KCe * MT; jm += NWAVES) {
@@ -2615,9 +2610,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca)
 #else
     unsigned long long* dt = nullptr;
 #endif
-    if (kind == 0) chain_block<3, 1, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry, dt);
-    else if (kind == 1) chain_block<5, 1, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry, dt);
-    else chain_block<5, 2, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, wqa, carry, dt);
+    if (kind == 0) chain_block<3, 1, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, carry, dt);
+    else if (kind == 1) chain_block<5, 1, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, carry, dt);
+    else chain_block<5, 2, MT, NWAVES>(a, nxp, !last, s_blk, ca.ldsU, ca.ldsE, i == 0, carry, dt);
   }
 }
 
@@ -3028,6 +3023,399 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_kernel(PairArgs pa) {
   __syncthreads();
   if (threadIdx.x == 0) { a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64(); a.dbg_t[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - dbg_c0); }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depth-fused chain of PAIRED whole-block kernels: the stride-1 2x2-image blocks 6b -> 6c -> 6d -> 7a in ONE launch.  mbconv_pair_kernel's
+// two halves (workgroups b and b ^ 8 of one XCD, sharing 4 * MT clips, each owning half of the expanded channels) walk the blocks
+// themselves, like mbconv_chain_kernel's workgroups.  What changes against one launch per block:
+//   * exchange 2 of a block that has a successor carries ALL projection tiles in both directions (not one parity each way), and BOTH
+//     halves finish every tile (p0 + p1 in that order on both sides: identical bits): each half then holds the whole block output,
+//     which it writes into U as the next block's input fragments; residual in registers (the same lane finishes the same tile);
+//   * flags: one set per (block, exchange) -- a slot is published and reset once per launch, as in mbconv_pair_kernel (a reset that
+//     lands after the next publish of the SAME slot would swallow it);
+//   * the exchange buffers are reused from block to block: between two uses of a buffer lies the other exchange of the pair, which
+//     orders the partner's reads before my next writes.
+// The last block of the chain exchanges by parity and stores to HBM exactly like mbconv_pair_kernel.  Failure contract unchanged.
+constexpr int kPairChainMax = 4;
+struct PairChainArgs {
+  const BlockArgs* tab;       // device table (see ChainArgs)
+  int i0, n;
+  unsigned kinds;             // 1 bit per chain position: 0 = 5x5, 1 = 3x3 (stride 1 both)
+  const float* X; float* Y;
+  int B;
+  int ldsU, ldsE, ldsZ;       // LDS carve (floats): maxima over the chain's blocks; the last 4 words of Z hold the error flag
+  float* xc1;                 // [pairs][2][kPairXc1]
+  float* xd;                  // [pairs][2][kPairXdAll][2][256]
+  int* flags;                 // [pairs][kPairChainMax][2 exchanges][2 halves], zero between launches
+  int* err_dev; int* err_host; int fault;
+};
+static constexpr int kPairXdAll = 20;
+
+template <int KS, int MT, int NWAVES>
+__device__ __forceinline__ void pair_chain_block(const BlockArgs& a, const BlockArgs* nxp, bool has_next, bool first, int blk, const PairChainArgs& pa,
+                                                 float* s_blk, int h, int pair, int xcc_expect, unsigned xcc, f32x4 (&carry)[2][MT]) {
+  constexpr int NTHR = NWAVES * 64;
+  constexpr int HT = 2, WT = 2, HW = 4, G = 4 * MT;
+  constexpr int PT = KS / 2, PLF = KS / 2;
+  constexpr int LDR = 52;
+  constexpr int RDA = 4, NTWA = 3;
+  const BlockArgs* nx = has_next ? nxp : nullptr;
+  const int b0 = pair * G;
+  const int Cexp = a.Cexp, CH = Cexp / 2, LDE = CH + 4;
+  const int KH = CH / 16;
+  const int KCx = Cexp / 16;
+  float* s_X = s_blk;
+  float* s_S = s_blk;
+  float* s_G = s_S + G * CH;
+  float* s_P = s_G;
+  float* s_E = s_blk + pa.ldsU;
+  float* s_scE = s_E + pa.ldsE;
+  float* s_shE = s_scE + CH;
+  float* s_R = s_scE;
+  float* s_be = s_R + 16 * LDR;
+  volatile int* s_bad = reinterpret_cast<volatile int*>(s_scE + pa.ldsZ - 4);
+  const int tid = opaque_((int)threadIdx.x), lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int gvalid = (a.B - b0 < G) ? (a.B - b0) : G;
+  const int rows = gvalid * HW;
+  const size_t row0 = (size_t)b0 * HW;
+  const int chan0 = h * CH;
+  const unsigned loff = (unsigned)(g * 64 + c * 4);
+  int* fl = pa.flags + ((size_t)pair * kPairChainMax + blk) * 4;
+
+  // ---- phase A: expand, this half's KH n-tiles (input fragments in s_X, ring in flight) ----
+  const int a_groups = (KH + NTWA - 1) / NTWA;
+  const int a_nruns = (a_groups > wave) ? (a_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto a_tile_of = [&](int r) { return (wave + NWAVES * r) * NTWA; };
+  {
+    // the expand ring is requested HERE, not during the previous block's projection as in chain_block: carried across the block loop its 48
+    // registers cost the kernel ~90 (165 -> 256 + spills); the price is one L2 round trip at the top of every block
+    const WBuf a_w(a.WpE + (size_t)(h * KH) * 256, loff);
+    f32x4 wqa[RDA][NTWA];
+    stream_mfma_runs_prefetch<NTWA, RDA>(wqa, a_w, (size_t)a.NTe * 256, KH, a_nruns, a.KCe, a_tile_of);
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
+    auto xmake = [](const f32x4& v) { return v; };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTWA][MT]) {
+#pragma unroll
+      for (int q = 0; q < NTWA; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < KH) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(s_scE + n), sh = *reinterpret_cast<const f32x4*>(s_shE + n);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 y = acc[q][m] * sc + sh;
+            y = swish4_(y);
+            if (m * 16 + c >= rows) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(s_E + (size_t)(m * 16 + c) * LDE + n) = y;
+          }
+        }
+      }
+    };
+    stream_mfma_runs<NTWA, RDA, MT, true>(wqa, a_w, (size_t)a.NTe * 256, KH, a_nruns, a.KCe, a_tile_of, xload, xmake, epi);
+  }
+  __syncthreads();
+
+  // ---- phase B: depthwise + BN + swish in place, SE means (thread = clip x channel quad of the half) ----
+  for (int i = tid; i < CH; i += NTHR) s_be[i] = a.be[chan0 + i];
+  const int c1_per = (KH + NWAVES - 1) / NWAVES;
+  const int c1_j0 = wave * c1_per;
+  const int c1_kc = (c1_j0 + c1_per <= KH) ? c1_per : (KH > c1_j0 ? KH - c1_j0 : 0);
+  const WBuf c1_w(a.WrP + (size_t)(h * KH + c1_j0) * a.NTR * 256, loff);
+  f32x4 wq1[3][3];
+  stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  {
+    const int Q = CH / 4;
+    for (int task = tid; task < G * Q; task += NTHR) {
+      const int gi = task / Q, q4 = (task - gi * Q) * 4;
+      float* Eg = s_E + (size_t)gi * HW * LDE + q4;
+      // taps and constants requested first, in source order (see chain_block)
+      f32x4 wv[KS][KS];
+#pragma unroll
+      for (int i = 0; i < KS; ++i)
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx) {
+          bool used = false;
+#pragma unroll
+          for (int oh = 0; oh < HT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WT; ++ow) {
+              const int ih = oh - PT + i, iw = ow - PLF + jx;
+              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+            }
+          if (used) wv[i][jx] = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)(i * KS + jx) * Cexp + chan0 + q4);
+        }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + chan0 + q4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + chan0 + q4);
+      f32x4 ein[HW];
+#pragma unroll
+      for (int pix = 0; pix < HW; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(Eg + (size_t)pix * LDE);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[HW];
+#pragma unroll
+      for (int o = 0; o < HW; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i)
+#pragma unroll
+        for (int jx = 0; jx < KS; ++jx)
+#pragma unroll
+          for (int oh = 0; oh < HT; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < WT; ++ow) {
+              const int ih = oh - PT + i, iw = ow - PLF + jx;
+              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WT + ow] += ein[ih * WT + iw] * wv[i][jx];
+            }
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < HW; ++o) {
+        f32x4 y = acc[o] * sc + sh;
+        y = swish4_(y);
+        if (gi >= gvalid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Eg + (size_t)o * LDE) = y;
+        ssum += y;
+      }
+      *reinterpret_cast<f32x4*>(s_S + (size_t)gi * CH + q4) = ssum * (1.0f / (float)HW);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C1: partial r^T over the half's channels, then exchange 1 ----
+  constexpr int NCST = 2;                                       // CH <= NCST * NTHR (host-checked)
+  float nsc[NCST], nsh[NCST];
+  const int nxCH = nx ? sgpr_(nx->Cexp) / 2 : 0;
+  if (nx) {
+    const float* nscE = sgpr_(nx->scE) + h * nxCH; const float* nshE = sgpr_(nx->shE) + h * nxCH;
+#pragma unroll
+    for (int k = 0; k < NCST; ++k) {
+      const int i = tid + k * NTHR;
+      if (i < nxCH) { nsc[k] = nscE[i]; nsh[k] = nshE[i]; }
+    }
+  }
+  constexpr int NTW2 = 3;
+  const int c2_groups = (KH + NTW2 - 1) / NTW2;
+  const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
+  auto c2_tile_of = [&](int r) { return (wave + NWAVES * r) * NTW2; };
+  const WBuf c2_w(a.We2P + (size_t)(h * KH) * 256, loff);
+  f32x4 wq2[3][NTW2];
+  {
+    f32x4 acc[3][1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* srow = s_S + (size_t)(c < G ? c : 0) * CH + 16 * c1_j0 + 4 * g;
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
+    stream_mfma_runs_prefetch<NTW2, 3>(wq2, c2_w, (size_t)KCx * 256, KH, c2_runs, a.NTR, c2_tile_of);
+    if (c < G) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+    }
+  }
+  const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
+  __syncthreads();
+  float c1_part = 0.0f;
+  float* xc1_mine = pa.xc1 + ((size_t)pair * 2 + h) * kPairXc1;
+  const float* xc1_theirs = pa.xc1 + ((size_t)pair * 2 + (h ^ 1)) * kPairXc1;
+  if (tid < 48 * G) {
+    if (tid / G < a.se) {
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) c1_part += s_P[(w * 48 + tid / G) * G + (tid % G)];
+    }
+    xc1_mine[tid] = c1_part;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0 && *s_bad == 0) {
+    const int got = pair_signal_wait(fl + h, fl + (h ^ 1), 1 + (int)xcc);
+    if (got != xcc_expect) {
+      *s_bad = 1;
+      pair_report(pa.err_dev, pa.err_host, got == 0 ? kPairErrTimeout : kPairErrXcc);
+    }
+  }
+  __syncthreads();
+  if (tid < 48 * G) {
+    const int n = tid / G, clip = tid - n * G;
+    float v = 0.0f;
+    if (n < a.se) {
+      const float other = __hip_atomic_load(xc1_theirs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = swishf_((h == 0 ? c1_part + other : other + c1_part) + br_pre);
+    }
+    s_R[clip * LDR + n] = v;
+  }
+  __syncthreads();
+
+  // ---- phase C2: gate for the half's channels; phase D's weight stream is requested first ----
+  const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NWAVES - 1) / NWAVES : 0;
+  const WBuf d_w(a.WpP + (size_t)(h * KH) * a.NTp * 256, loff);
+  f32x4 wqd[4][3];
+  if (d_ntw > 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KH);
+  {
+    const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
+    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
+#pragma unroll
+      for (int q = 0; q < NTW2; ++q) {
+        const int n = (t0 + q) * 16 + 4 * g;
+        if (t0 + q < KH && c < G) {
+          f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
+          y = sigmoid4_(y);
+          *reinterpret_cast<f32x4*>(s_G + (size_t)c * CH + n) = y;
+        }
+      }
+    };
+    stream_mfma_runs<NTW2, 3, 1, true>(wq2, c2_w, (size_t)KCx * 256, KH, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
+  }
+  __syncthreads();
+
+  // ---- gate in place; the next block's expand BN constants (this half's) go to Z ----
+  {
+    const int Q = CH / 4;
+    for (int i = tid; i < G * HW * Q; i += NTHR) {
+      const int r = i / Q, q4 = (i - r * Q) * 4;
+      float* e = s_E + (size_t)r * LDE + q4;
+      *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)(r / HW) * CH + q4);
+    }
+  }
+  if (nx) {
+#pragma unroll
+    for (int k = 0; k < NCST; ++k) {
+      const int i = tid + k * NTHR;
+      if (i < nxCH) { s_scE[i] = nsc[k]; s_scE[nxCH + i] = nsh[k]; }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase D: partial projection over the half's K; exchange 2; finish ----
+  {
+    const size_t cstride = (size_t)a.NTp * 256;
+    const float* erow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) erow[m] = s_E + (size_t)(m * 16 + c) * LDE + 4 * g;
+    auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(erow[m] + 16 * j); };
+    auto xmake = [](const f32x4& v) { return v; };
+    const bool all_tiles = has_next;                            // both halves finish every tile (the whole output becomes the next input)
+    const bool my_parity = ((wave & 1) == h);                   // tiles wave + NWAVES*q share the wave's parity
+    const bool sends = all_tiles || !my_parity, finishes = all_tiles || my_parity;
+    float* xd_mine = pa.xd + ((size_t)pair * 2 + h) * (kPairXdAll * 2 * 256);
+    const float* xd_theirs = pa.xd + ((size_t)pair * 2 + (h ^ 1)) * (kPairXdAll * 2 * 256);
+    auto run = [&](auto ntw_tag) {
+      constexpr int NTW = decltype(ntw_tag)::value;
+      f32x4 acc[NTW > 0 ? NTW : 1][MT];
+#pragma unroll
+      for (int q = 0; q < (NTW > 0 ? NTW : 1); ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (NTW > 0) {
+        stream_mfma<NTW, 4, MT, true>(acc, wqd, d_w, cstride, wave, NWAVES, a.NTp, KH, xload, xmake);
+        if (sends) {
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) {
+            const int t = wave + NWAVES * q;
+            if (t < a.NTp) {
+#pragma unroll
+              for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(xd_mine + ((size_t)(t * 2 + m) * 64 + lane) * 4) = acc[q][m];
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0 && *s_bad == 0) {
+        const int got = pair_signal_wait(fl + 2 + h, fl + 2 + (h ^ 1), 1);
+        if (got != 1) { *s_bad = 1; pair_report(pa.err_dev, pa.err_host, kPairErrTimeout); }
+      }
+      __syncthreads();
+      if constexpr (NTW > 0) {
+        if (finishes) {
+          const bool bad = *s_bad != 0;
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) {
+            const int t = wave + NWAVES * q;
+            const int n = t * 16 + 4 * g;
+            if (t < a.NTp) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scP + n), sh = *reinterpret_cast<const f32x4*>(a.shP + n);
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                const int r = m * 16 + c;
+                const f32x4 other = ld_agent_x4(xd_theirs + ((size_t)(t * 2 + m) * 64 + lane) * 4);
+                f32x4 y = ((h == 0) ? acc[q][m] + other : other + acc[q][m]) * sc + sh;
+                if (a.residual) {
+                  if (first) { if (r < rows) y += *reinterpret_cast<const f32x4*>(a.X + (row0 + r) * a.Cin + n); }
+                  else if (q < 2) y += carry[q][m];            // (blocks inside a chain have at most 2 tiles per wave: host-checked)
+                }
+                if (bad) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                if (!nx && r < rows) *reinterpret_cast<f32x4*>(a.Y + (row0 + r) * a.Cout + n) = y;
+                if (r >= rows) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (q < 2) carry[q][m] = y;
+                if (nx) *reinterpret_cast<f32x4*>(s_X + ((size_t)(t * MT + m) * 64 + lane) * 4) = y;
+              }
+            }
+          }
+        }
+      }
+    };
+    if (d_ntw == 0) run(std::integral_constant<int, 0>{});
+    else if (d_ntw == 1) run(std::integral_constant<int, 1>{});
+    else if (d_ntw == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+  }
+  if (nx) __syncthreads();
+}
+
+template <int MT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_chain_kernel(PairChainArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) float s_blk[];
+  constexpr int NTHR = NWAVES * 64;
+  constexpr int HW = 4, G = 4 * MT;
+  const BlockArgs* __restrict__ tab = pa.tab + pa.i0;
+  const int h = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+  const int b0 = pair * G;
+  if (b0 >= pa.B) return;                                       // both halves of a padding pair leave together
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 0xf;
+  if (pa.fault == 2 && h == 1) return;                          // test hook: the partner never arrives
+  volatile int* s_bad = reinterpret_cast<volatile int*>(s_blk + pa.ldsU + pa.ldsE + pa.ldsZ - 4);
+  if (tid == 0) *s_bad = __hip_atomic_load(pa.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int xcc_expect = 1 + (int)(pa.fault == 1 ? (xcc ^ 1u) : xcc);
+  f32x4 carry[2][MT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) carry[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const int Cin = sgpr_(tab[0].Cin), KCe = sgpr_(tab[0].KCe), CH = sgpr_(tab[0].Cexp) / 2;
+    const int gvalid = (pa.B - b0 < G) ? (pa.B - b0) : G;
+    const int rows = gvalid * HW;
+    const size_t row0 = (size_t)b0 * HW;
+    float* s_X = s_blk;
+    float* s_scE = s_blk + pa.ldsU + pa.ldsE;
+    for (int jm = wave; jm < KCe * MT; jm += NWAVES) {
+      const int j = jm / MT, m = jm - j * MT;
+      const int r = m * 16 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows && 16 * j + 4 * g < Cin) v = *reinterpret_cast<const f32x4*>(pa.X + (row0 + r) * Cin + 16 * j + 4 * g);
+      *reinterpret_cast<f32x4*>(s_X + ((size_t)jm * 64 + lane) * 4) = v;
+    }
+    const float* scE = sgpr_(tab[0].scE) + h * CH; const float* shE = sgpr_(tab[0].shE) + h * CH;
+    for (int i = tid; i < CH; i += NTHR) { s_scE[i] = scE[i]; s_scE[CH + i] = shE[i]; }
+    __syncthreads();
+  }
+  for (int i = 0; i < pa.n; ++i) {
+    BlockArgs a = sgpr_block_args(tab[i]);
+    const bool last = (i + 1 == pa.n);
+    a.X = pa.X; a.Y = pa.Y; a.B = pa.B;
+    const BlockArgs* nxp = last ? tab + i : tab + i + 1;
+    if (((pa.kinds >> i) & 1u) == 0) pair_chain_block<5, MT, NWAVES>(a, nxp, !last, i == 0, i, pa, s_blk, h, pair, xcc_expect, xcc, carry);
+    else pair_chain_block<3, MT, NWAVES>(a, nxp, !last, i == 0, i, pa, s_blk, h, pair, xcc_expect, xcc, carry);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3567,13 +3955,14 @@ struct mkws_embed {
   int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 2b, 3a and 4a (where it measured faster), 2 = 2a..4a, 3 = 3a and 4a only, 0 = never
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
-  int fuse_chain = 1;              // consecutive 4x3-image blocks (4b..6a) in ONE launch (mbconv_chain_kernel): activations stay in LDS from block to block
+  int fuse_chain = 1;              // depth-fused chains: 1 = blocks 4b..6a in ONE launch (mbconv_chain_kernel) and 6b..7a in ONE paired launch (mbconv_pair_chain_kernel); 2 / 3 = only the first / second; 0 = one launch per block
   mkws::BlockArgs* d_chain_tab = nullptr;   // device copy of every block's constants (BlockArgs without X / Y / dbg) for the chain kernels
   int fuse_pair = 1;               // stride-1 2x2 blocks on mbconv_pair_kernel: two workgroups share 8 clips and split the channels
   float* pair_xc1 = nullptr; float* pair_xd = nullptr; int* pair_flags = nullptr;   // exchange buffers of the paired kernel
   int* pair_err_dev = nullptr;     // sticky failure word of the paired kernel (device memory)
   int* pair_err_host = nullptr;    // the same in host-mapped memory (hipHostMalloc): read by the host without synchronising
   size_t pair_flag_count = 0;
+  int* pair_chain_flags = nullptr;  // flags of the paired chain kernel (behind pair_flags, cleared with them)
   int pair_fault = 0;              // test hook, see PairArgs::fault
   int pair_degraded = 0;           // how many times this handle left the paired kernel because an exchange failed
   int fuse_cluster = 0;            // small-batch handles: tiny-image blocks on mbconv_cluster_kernel (6 workgroups per 16-row tile split the channels)
@@ -4039,8 +4428,9 @@ static bool chain_link_ok(const BlockPlan& b, const BlockPlan& next) {
   return next.ce <= 3 * kBlockWaves * 64;
 }
 bool cluster_supported(const BlockPlan& b);
+bool pair_supported(const BlockPlan& b);
 static bool chain_member(const mkws_embed* em, const BlockPlan& b) {
-  if (!em->fuse_chain || !em->fuse_block || !block_supported(b, em->fuse_block)) return false;
+  if (!(em->fuse_chain == 1 || em->fuse_chain == 2) || !em->fuse_block || !block_supported(b, em->fuse_block)) return false;
   if (!(b.H == 4 && b.W == 3)) return false;
   if (em->fuse_cluster && cluster_supported(b) && em->cl_flags) return false;
   return true;
@@ -4115,7 +4505,7 @@ int launch_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const floa
 // Paired whole-block kernel (mbconv_pair_kernel): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a).
 struct PairWs { float* xc1 = nullptr; float* xd = nullptr; int* flags = nullptr; int* err_dev = nullptr; int* err_host = nullptr; int fault = 0; int mt = 2; };
 static int pair_count(int B, int mt) { const int G = 4 * mt; return ((B + G - 1) / G + 7) / 8 * 8; }   // padded to whole groups of 8 pairs (16 workgroups)
-static size_t pair_ws_floats(int max_batch, int mt) { return (size_t)pair_count(max_batch, mt) * (2 * kPairXc1 + 2 * kPairXdTiles * 2 * 256 + 4); }
+static size_t pair_ws_floats(int max_batch, int mt) { return (size_t)pair_count(max_batch, mt) * (2 * kPairXc1 + 2 * kPairXdAll * 2 * 256 + 4 + 4 * kPairChainMax); }   // exchange buffers (sized for the chain's all-tiles exchange) + flags of both kernels
 // Row tiles per pair for a handle: 8 clips per pair fill the chip from ~1024 clips up; smaller handles use 4-clip pairs so
 // that twice as many workgroups exist (512 clips: 256 instead of 128).  Per handle, like every other plan decision.
 static int pair_row_tiles(int max_batch) { return (2 * ((max_batch + 3) / 4) <= device_cu_count()) ? 1 : 2; }   // 4-clip pairs while they still fit in one round
@@ -4183,6 +4573,45 @@ int launch_pair(hipStream_t s, const char* stage, const BlockPlan& b, const Pair
 #ifdef MKWS_FRONT_TIMING
   report_block_timing(s, stage, grid.x, d_bt);
 #endif
+  return MKWS_OK;
+}
+
+// Paired chain (mbconv_pair_chain_kernel): consecutive stride-1 2x2-image blocks [i0, i1] in one paired launch.
+static bool pair_chain_member(const mkws_embed* em, const BlockPlan& b) {
+  if (!(em->fuse_chain == 1 || em->fuse_chain == 3) || !em->fuse_block || !em->fuse_pair || !block_supported(b, em->fuse_block) || !pair_supported(b)) return false;
+  if (em->fuse_cluster && cluster_supported(b) && em->cl_flags) return false;
+  return b.ce / 2 <= 2 * kBlockWaves * 64 && b.project.NTtot <= kPairXdAll && b.project.NTtot <= 3 * kBlockWaves;
+}
+static bool pair_chain_link_ok(const BlockPlan& b, const BlockPlan& next) {
+  if (b.project.NTtot > 2 * kBlockWaves) return false;                   // the residual carry holds two tiles per wave
+  return b.spec.stride == 1 && next.spec.in_ch == b.spec.out_ch && next.expand.KC == b.project.NTtot;
+}
+int launch_pair_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const float* X, float* Y, int B) {
+  PairChainArgs pa;
+  const int n = i1 - i0 + 1, mt = em->pair_mt;
+  if (!em->d_chain_tab || n > kPairChainMax) return fail(MKWS_ERR_UNSUPPORTED, "pair chain: no block table / too many blocks");
+  pa.tab = em->d_chain_tab; pa.i0 = i0; pa.n = n; pa.kinds = 0; pa.ldsU = pa.ldsE = pa.ldsZ = 0;
+  pa.X = X; pa.Y = Y; pa.B = B;
+  pa.xc1 = em->pair_xc1; pa.xd = em->pair_xd; pa.flags = em->pair_chain_flags; pa.err_dev = em->pair_err_dev; pa.err_host = em->pair_err_host; pa.fault = em->pair_fault;
+  std::string names;
+  for (int k = 0; k < n; ++k) {
+    const BlockPlan& b = em->blocks[i0 + k];
+    if (b.spec.kernel == 3) pa.kinds |= 1u << k;
+    const PairLds L = pair_lds(b.expand.KC, b.ce / 2, mt);
+    pa.ldsU = std::max(pa.ldsU, L.U); pa.ldsE = std::max(pa.ldsE, L.E); pa.ldsZ = std::max(pa.ldsZ, L.Z);
+    names += (k ? "," : "") + std::string(b.spec.name);
+  }
+  const size_t lds = ((size_t)pa.ldsU + pa.ldsE + pa.ldsZ) * sizeof(float);
+  if (lds > 160 * 1024) return fail(MKWS_ERR_UNSUPPORTED, "pair chain: LDS carve %zu bytes", lds);
+  const dim3 grid(2 * pair_count(B, mt));
+  ProfScope ps("chain:" + names, std::string("mbconv_pair_chain_kernel<") + std::to_string(mt) + "," + std::to_string(kBlockWaves) + ">");
+  if (mt == 2) {
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_chain_kernel<2, kBlockWaves>), 160 * 1024)) return rc_;
+    hipLaunchKernelGGL((mbconv_pair_chain_kernel<2, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa);
+  } else {
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_pair_chain_kernel<1, kBlockWaves>), 160 * 1024)) return rc_;
+    hipLaunchKernelGGL((mbconv_pair_chain_kernel<1, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, pa);
+  }
   return MKWS_OK;
 }
 
@@ -4496,6 +4925,17 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
         i = e;
         continue;
       }
+      if (pair_chain_member(em, b) && !inner_tap(i)) {
+        int e = i;
+        while (e + 1 < kNumBlocks && e + 1 - i < kPairChainMax && !(stop && (std::string("block") + em->blocks[e].spec.name) == stop) &&
+               pair_chain_member(em, em->blocks[e + 1]) && pair_chain_link_ok(em->blocks[e], em->blocks[e + 1]) && !inner_tap(e + 1)) ++e;
+        const BlockPlan& bl = em->blocks[e];
+        if (int rc = launch_pair_chain(s, em, i, e, cur, nxt, B)) return rc;
+        if (hit(std::string("block") + bl.spec.name, nxt, (size_t)B * bl.Ho * bl.Wo * bl.spec.out_ch)) return MKWS_OK;
+        float* t = cur; cur = nxt; nxt = t;
+        i = e;
+        continue;
+      }
     }
     if (em->fuse_block && block_supported(b, em->fuse_block) && !want_expand_tap) {
       // one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
@@ -4753,11 +5193,12 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   {
     const size_t np = (size_t)pair_count(max_batch, em->pair_mt);
     em->pair_xc1 = w; w += np * 2 * kPairXc1;
-    em->pair_xd = w; w += np * 2 * kPairXdTiles * 2 * 256;
-    em->pair_flags = reinterpret_cast<int*>(w); w += np * 4;
-    em->pair_err_dev = em->pair_flags + np * 4; w += 4;          // cleared with the flags
-    em->pair_flag_count = np * 4;
-    if (hipMemset(em->pair_flags, 0, (np * 4 + 4) * sizeof(int)) != hipSuccess ||
+    em->pair_xd = w; w += np * 2 * kPairXdAll * 2 * 256;
+    em->pair_flags = reinterpret_cast<int*>(w); w += np * 4;                          // mbconv_pair_kernel: [pairs][2 exchanges][2 halves]
+    em->pair_chain_flags = reinterpret_cast<int*>(w); w += np * 4 * kPairChainMax;    // mbconv_pair_chain_kernel: [pairs][blocks][2][2]
+    em->pair_flag_count = np * 4 + np * 4 * kPairChainMax;
+    em->pair_err_dev = em->pair_flags + em->pair_flag_count; w += 4;                   // cleared with the flags
+    if (hipMemset(em->pair_flags, 0, (em->pair_flag_count + 4) * sizeof(int)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&em->pair_err_host), 64, hipHostMallocMapped) != hipSuccess) {
       (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "setting up the pair flags failed");
     }

@@ -81,22 +81,25 @@ def test_execution_options_agree(ctx):
 
 
 def test_depth_fused_chain_is_bit_identical_to_the_single_block_kernels(ctx):
-    """mbconv_chain_kernel (blocks 4b..6a in one launch, activations in LDS, residual in registers) performs the same operations in the
-    same order as one mbconv_block_kernel launch per block: embeddings and every block output inside the chain are bit-identical,
-    for full, ragged and multi-round batches."""
+    """mbconv_chain_kernel (blocks 4b..6a in one launch, activations in LDS, residual in registers) and mbconv_pair_chain_kernel (6b..7a in
+    one paired launch, all projection tiles exchanged and finished by both halves) perform the same operations in the same order as one
+    whole-block launch per block: embeddings and every block output inside the chains are bit-identical, for full, ragged and
+    multi-round batches."""
     rng = np.random.default_rng(21)
     spec = _spec(rng, 1024)
     x = torch.from_numpy(spec).to(ctx["dev"])
     em = ctx["em"]
     assert em.get_option("fuse_chain") == 1
     try:
-        got = {b: em.forward(x[:b]).clone() for b in (1024, 1023, 37, 6, 5, 4, 3, 1)}
-        taps = {n: em.tap(x[:9], n).clone() for n in ("block4b", "block4c", "block5a", "block5b", "block5c", "block6a", "block5b_dw", "block5c_gate", "block6a_dw")}
-        em.set_option("fuse_chain", 0)
-        for b, e in got.items():
-            assert torch.equal(em.forward(x[:b]), e), b
-        for n, t in taps.items():
-            assert torch.equal(em.tap(x[:9], n), t), n
+        got = {b: em.forward(x[:b]).clone() for b in (1024, 1023, 37, 9, 8, 7, 6, 5, 4, 3, 1)}
+        taps = {n: em.tap(x[:9], n).clone() for n in ("block4b", "block4c", "block5a", "block5b", "block5c", "block6a", "block5b_dw", "block5c_gate", "block6a_dw",
+                                                      "block6b", "block6c", "block6d", "block7a", "block6c_dw", "block7a_gate")}
+        for mode in (0, 2, 3):             # no chain / only the 4x3-image chain / only the paired 2x2-image chain
+            em.set_option("fuse_chain", mode)
+            for b, e in got.items():
+                assert torch.equal(em.forward(x[:b]), e), (mode, b)
+            for n, t in taps.items():
+                assert torch.equal(em.tap(x[:9], n), t), (mode, n)
     finally:
         em.set_option("fuse_chain", 1)
     ref = ctx["oracle"].forward(spec[:16]).numpy()
@@ -105,13 +108,14 @@ def test_depth_fused_chain_is_bit_identical_to_the_single_block_kernels(ctx):
     from multilingual_kws_amd.embedding_model import EmbeddingModel
     em2 = EmbeddingModel(ctx["blob"], max_batch=512)
     try:
-        got2 = {b: em2.forward(x[:b]).clone() for b in (512, 511, 37, 2, 1)}
-        taps2 = {n: em2.tap(x[:9], n).clone() for n in ("block4c", "block5a", "block5c", "block6a")}
-        em2.set_option("fuse_chain", 0)
-        for b, e in got2.items():
-            assert torch.equal(em2.forward(x[:b]), e), b
-        for n, t in taps2.items():
-            assert torch.equal(em2.tap(x[:9], n), t), n
+        got2 = {b: em2.forward(x[:b]).clone() for b in (512, 511, 37, 5, 4, 2, 1)}
+        taps2 = {n: em2.tap(x[:9], n).clone() for n in ("block4c", "block5a", "block5c", "block6a", "block6b", "block6d", "block7a")}
+        for mode in (0, 2, 3):
+            em2.set_option("fuse_chain", mode)
+            for b, e in got2.items():
+                assert torch.equal(em2.forward(x[:b]), e), (mode, b)
+            for n, t in taps2.items():
+                assert torch.equal(em2.tap(x[:9], n), t), (mode, n)
         assert _rel(got2[512][:16].cpu().numpy(), ref) < REL_TOL
     finally:
         em2.close()
@@ -244,8 +248,9 @@ def test_whole_block_plan_replays_in_a_hip_graph(ctx):
         assert torch.equal(out, refs[k]), k
 
 
+@pytest.mark.parametrize("chain", [1, 2])          # 1: the paired CHAIN kernel (6b..7a in one launch); 2: one paired launch per block
 @pytest.mark.parametrize("fault", [1, 2])
-def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault):
+def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault, chain):
     """include/mkws.h, "Failure contract of the paired whole-block kernel": when the two halves of a pair land on different
     XCDs (fault 1, forced through the test hook) or a half never arrives (fault 2: the other times out), the failing forward is
     NaN-poisoned, the NEXT call returns MKWS_ERR_EXCHANGE having moved the handle to the single-workgroup kernel, and the
@@ -258,6 +263,7 @@ def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault):
     em = EmbeddingModel(ctx["blob"], max_batch=1024)
     if em.get_option("fuse_pair") != 1:
         pytest.skip("this device's dispatch order failed the probe at create: the paired kernel is not in use")
+    em.set_option("fuse_chain", chain)
     assert _rel(em.forward(x).cpu().numpy(), ref) < REL_TOL and em.get_option("pair_degraded") == 0
     em.set_option("pair_fault", fault)
     poisoned = em.forward(x)
@@ -273,6 +279,7 @@ def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault):
         assert torch.isfinite(out).all() and _rel(out.cpu().numpy(), ref) < REL_TOL
     # the Python wrapper retries by itself (with a warning) when it is the one that meets the error code
     em2 = EmbeddingModel(ctx["blob"], max_batch=1024)
+    em2.set_option("fuse_chain", chain)
     em2.set_option("pair_fault", fault)
     em2.forward(x)
     torch.cuda.synchronize()
