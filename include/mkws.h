@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKWS_ABI_VERSION 3
+#define MKWS_ABI_VERSION 4
 
 typedef enum mkws_status {
   MKWS_OK = 0,
@@ -287,6 +287,9 @@ int mkws_augment_batch(const float* d_bank0, const float* d_bank1, const float* 
 /* SpecAugment masking in place on d_spec [B, frames, channels]; d_masks int32 [B,8] =
  * {freq0 start, size, freq1 start, size, time0 start, size, time1 start, size}; size 0 = no mask. */
 int mkws_specaug_apply(float* d_spec, const int32_t* d_masks, int B, int frames, int channels, void* stream);
+/* The same with ANY number of masks per axis (the reference loops frequency_n / time_n times for whatever SpecAugParams says,
+ * input_data.py:317-362): d_masks int32 [B, 2*(n_freq + n_time)] = n_freq x {channel start, size} then n_time x {frame start, size}. */
+int mkws_specaug_apply_n(float* d_spec, const int32_t* d_masks, int n_freq, int n_time, int B, int frames, int channels, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training operators for `backprop_into_embedding=True` (multilingual_kws/embedding/transfer_learning.py:94-112).

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("MKWS_LIB") or os.path.join(_HERE, "lib", "libmkws_hip
 
 MKWS_OK = 0
 MKWS_ERR_EXCHANGE = -7
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MkwsError(RuntimeError):
@@ -58,6 +58,7 @@ SYMBOLS = [
     ("mkws_embed_forward_tap", _I, [_P, _P, _I, ctypes.c_char_p, _P, _SZ, _P]),
     ("mkws_augment_batch", _I, [_P, _P, _P, ctypes.c_int64, _P, _I, _I, _P, _P]),
     ("mkws_specaug_apply", _I, [_P, _P, _I, _I, _I, _P]),
+    ("mkws_specaug_apply_n", _I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     ("mkws_head_create", _I, [_I, _I, _I, _I, ctypes.POINTER(_P)]),
     ("mkws_head_destroy", None, [_P]),
     ("mkws_head_param_count", _I, [_P]),

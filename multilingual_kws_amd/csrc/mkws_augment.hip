@@ -81,6 +81,19 @@ __global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ spec, 
   }
 }
 
+// any number of masks per axis: masks [B][2*(NF+NT)] = NF x {channel start, size} then NT x {frame start, size}
+__global__ __launch_bounds__(256) void specaug_n_kernel(float* __restrict__ spec, const int32_t* __restrict__ masks, int NF, int NT, int F, int C) {
+  const int32_t* m = masks + (size_t)blockIdx.x * 2 * (NF + NT);
+  float* s = spec + (size_t)blockIdx.x * F * C;
+  for (int i = threadIdx.x; i < F * C; i += 256) {
+    const int f = i / C, c = i % C;
+    bool z = false;
+    for (int k = 0; k < NF; ++k) z |= (c >= m[2 * k] && c < m[2 * k] + m[2 * k + 1]);
+    for (int k = 0; k < NT; ++k) z |= (f >= m[2 * (NF + k)] && f < m[2 * (NF + k)] + m[2 * (NF + k) + 1]);
+    if (z) s[i] = 0.0f;
+  }
+}
+
 }  // namespace mkws
 
 using namespace mkws;
@@ -104,6 +117,15 @@ int mkws_specaug_apply(float* d_spec, const int32_t* d_masks, int B, int frames,
   if (B == 0) return MKWS_OK;
   if (!d_spec || !d_masks) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
   hipLaunchKernelGGL(specaug_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), d_spec, d_masks, frames, channels);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_specaug_apply_n(float* d_spec, const int32_t* d_masks, int n_freq, int n_time, int B, int frames, int channels, void* stream) {
+  if (B < 0 || frames <= 0 || channels <= 0 || n_freq < 0 || n_time < 0) return fail(MKWS_ERR_INVALID_ARG, "bad shape / mask counts");
+  if (B == 0 || n_freq + n_time == 0) return MKWS_OK;
+  if (!d_spec || !d_masks) return fail(MKWS_ERR_INVALID_ARG, "NULL buffer");
+  hipLaunchKernelGGL(specaug_n_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), d_spec, d_masks, n_freq, n_time, frames, channels);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

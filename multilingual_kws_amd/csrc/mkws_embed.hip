@@ -2314,11 +2314,7 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   f32x4 wq1[3][3];
   // (5x5: a thread holds 12 inputs + 12 outputs + 25 taps -- 196 registers; C1's ring is requested behind the depthwise loop there,
   // where waves that own one round of tasks wait for those that own two)
-#ifdef MKWS_CHAIN_WQ1_EARLY
-  constexpr bool kWq1Early = true;
-#else
-  constexpr bool kWq1Early = (KS == 3);
-#endif
+  constexpr bool kWq1Early = (KS == 3);                        // (requested in front of the 5x5 depthwise as well: measured, no difference)
   if (kWq1Early) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
   {
     const int Q = Cexp / 4;

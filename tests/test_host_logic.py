@@ -142,8 +142,9 @@ def test_unknown_files_bank_and_sample_check(tmp_path):
         input_data.load_unknown_files(tmp_path)
 
 
-def test_specaug_mask_table_and_its_two_slot_limit():
-    """Host draws for mkws_specaug_apply: [B,8] table inside the image, and no silent truncation of >2 masks per axis."""
+def test_specaug_mask_table_for_any_number_of_masks():
+    """Host draws for mkws_specaug_apply_n: [B, 2*(NF+NT)] table inside the image; the reference loops freq_n / time_n times for whatever
+    SpecAugParams says (input_data.py:317-362), so more than two masks per axis are drawn, not refused or truncated."""
     from multilingual_kws_amd.embedding import input_data
     ms = input_data.standard_microspeech_model_settings(3)
     ds = input_data.AudioDataset(ms, ["t"], None, [], spec_aug_params=input_data.SpecAugParams(percentage=100), seed=0)
@@ -155,10 +156,18 @@ def test_specaug_mask_table_and_its_two_slot_limit():
         assert tz.min() == 0 and tz.max() == 2 and ((ts + tz) <= 49 - 1).all()
     n_freq = (m[:, 1] > 0).astype(int) + (m[:, 3] > 0)
     assert abs((n_freq == 0).mean() - 1 / 3) < 0.05 and abs((n_freq == 2).mean() - 1 / 3) < 0.05   # freq_n ~ U{0,1,2}
-    for bad in (dict(frequency_n_range=3), dict(time_n_range=4)):
-        ds3 = input_data.AudioDataset(ms, ["t"], None, [], spec_aug_params=input_data.SpecAugParams(**bad), seed=0)
-        with pytest.raises(ValueError):
-            ds3._draw_specaug_masks(8)
+    ds3 = input_data.AudioDataset(ms, ["t"], None, [], spec_aug_params=input_data.SpecAugParams(percentage=100, frequency_n_range=3, time_n_range=5,
+                                                                                                  frequency_max_px=4, time_max_px=6), seed=1)
+    m3 = ds3._draw_specaug_masks(6000)
+    assert m3.shape == (6000, 2 * (3 + 5))
+    nf = (m3[:, 1:6:2] > 0).sum(1)
+    nt = (m3[:, 7::2] > 0).sum(1)
+    assert set(nf) == {0, 1, 2, 3} and set(nt) == {0, 1, 2, 3, 4, 5}                    # freq_n ~ U{0..3}, time_n ~ U{0..5}
+    assert all(abs((nf == k).mean() - 1 / 4) < 0.03 for k in range(4)) and all(abs((nt == k).mean() - 1 / 6) < 0.03 for k in range(6))
+    assert m3[:, 1:6:2].max() == 4 and m3[:, 7::2].max() == 6
+    assert ((m3[:, 0:6:2] + m3[:, 1:6:2]) <= 39).all() and ((m3[:, 6::2] + m3[:, 7::2]) <= 48).all()
+    # masks are used in slot order: slot k is on only if freq_n > k
+    assert ((m3[:, 3] > 0) <= (m3[:, 1] > 0)).all() and ((m3[:, 5] > 0) <= (m3[:, 3] > 0)).all()
 
 
 def test_shipped_bn_calibration_file_is_what_the_recipe_produces():

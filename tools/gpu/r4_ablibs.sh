@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export KFILTER=chain
 L=multilingual_kws_amd/lib
-bash tools/gpu/ablibs.sh - $L/libmkws_hip_localring.so $L/libmkws_hip_lrwq1.so $L/libmkws_hip_wq1.so - $L/libmkws_hip_localring.so $L/libmkws_hip_lrwq1.so $L/libmkws_hip_wq1.so
+bash tools/gpu/ablibs.sh - $L/libmkws_hip_wq1.so - $L/libmkws_hip_wq1.so - $L/libmkws_hip_wq1.so
