@@ -232,6 +232,9 @@ int mkws_head_param_count(const mkws_head* hd);
 float* mkws_head_params(mkws_head* hd);
 float* mkws_head_grads(mkws_head* hd);
 int mkws_head_grad_count(const mkws_head* hd);
+/* The handle's whole optimizer state is ONE contiguous range starting at mkws_head_params(): params | grads (+ 2 statistics) | Adam m |
+ * Adam v, each padded to the same length; this is the length of the range in floats (snapshot / restore around a warm-up step). */
+int mkws_head_state_floats(const mkws_head* hd);
 /* Uploads h_params (host) and zeroes the gradient and Adam state, ordered on `stream`; returns after the
  * stream has drained (h_params may be pageable). */
 int mkws_head_set_params(mkws_head* hd, const float* h_params, int n, void* stream);
@@ -302,10 +305,20 @@ int mkws_specaug_apply_n(float* d_spec, const int32_t* d_masks, int n_freq, int 
  * Cross-workgroup reductions are two-level and FIXED-ORDER (partial sums in a caller-provided scratch arena, folded in index
  * order by a second launch): no atomics, a step with the same inputs is bit-reproducible.
  * ---------------------------------------------------------------------------------------------- */
-/* Scratch arena (device memory, caller-owned) for those partial sums; per host thread, used by every mkws_op_* call of that
- * thread until changed, in stream order (ops on ONE stream share it safely; give concurrent streams separate threads / arenas).
- * 16 Mi floats cover every layer of the network at any batch (the largest user is the split reduction of mkws_op_gemm, which
- * splits only as far as the arena reaches).  Ops that need it fail with MKWS_ERR_INVALID_ARG when it is missing or too small. */
+/* State of the training operators = a CONTEXT: the scratch arena (device memory, caller-owned) for those partial sums and the queue of
+ * deferred second stages (mkws_op_fold_defer).  16 Mi floats cover every layer of the network at any batch (the largest user is the
+ * split reduction of mkws_op_gemm, which splits only as far as the arena reaches); ops that need the arena fail with
+ * MKWS_ERR_INVALID_ARG when it is missing or too small.  A context is used in stream order (ops on ONE stream share it safely; give
+ * concurrent streams separate contexts).
+ *   mkws_train_ctx_create / _destroy   a context handle owning nothing but its bookkeeping (the arena stays the caller's)
+ *   mkws_train_ctx_bind(ctx)           every mkws_op_* call of THIS host thread uses ctx until another bind; NULL = the thread's default
+ *                                      context.  Distinct contexts are independent: two trainers on one thread each bind their own before
+ *                                      their calls, a trainer handed to another thread binds there and finds its queue as it left it.
+ *   mkws_op_set_scratch                the thread's DEFAULT context (rounds 2-3 interface): sets its arena and binds it. */
+typedef struct mkws_train_ctx mkws_train_ctx;
+int mkws_train_ctx_create(float* d_scratch, size_t floats, mkws_train_ctx** out);
+void mkws_train_ctx_destroy(mkws_train_ctx* ctx);
+int mkws_train_ctx_bind(mkws_train_ctx* ctx);
 int mkws_op_set_scratch(float* d_scratch, size_t floats);
 /* C[M,N] (+)= op(A)[M,K] . op(B)[K,N] on the fp32 MFMA; op(A)(m,k) = transA ? A[k*lda+m] : A[m*lda+k], likewise B.
  * ksplit > 1 splits K over workgroups (slice sums go to the scratch arena, a second launch folds them in order into C);

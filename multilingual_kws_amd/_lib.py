@@ -64,6 +64,7 @@ SYMBOLS = [
     ("mkws_head_param_count", _I, [_P]),
     ("mkws_head_params", _P, [_P]),
     ("mkws_head_grads", _P, [_P]),
+    ("mkws_head_state_floats", _I, [_P]),
     ("mkws_head_grad_count", _I, [_P]),
     ("mkws_head_set_params", _I, [_P, _P, _I, _P]),
     ("mkws_head_get_params", _I, [_P, _P, _I, _P]),
@@ -74,6 +75,9 @@ SYMBOLS = [
     ("mkws_head_input_grad", _I, [_P, _P, _I, _P]),
     ("mkws_head_adam_step_dev", _I, [_P, _F, _F, _F, _F, _P, _F, _P]),
     # training operators (backprop_into_embedding)
+    ("mkws_train_ctx_create", _I, [_P, _SZ, ctypes.POINTER(_P)]),
+    ("mkws_train_ctx_destroy", None, [_P]),
+    ("mkws_train_ctx_bind", _I, [_P]),
     ("mkws_op_set_scratch", _I, [_P, _SZ]),
     ("mkws_op_fold_defer", _I, [_I, _P]),
     ("mkws_op_fold_flush", _I, [_P]),

@@ -490,6 +490,7 @@ int mkws_head_param_count(const mkws_head* hd) { return hd ? hd->nparams : fail(
 int mkws_head_grad_count(const mkws_head* hd) { return hd ? hd->nparams + 2 : fail(MKWS_ERR_INVALID_ARG, "head handle is NULL"); }
 float* mkws_head_params(mkws_head* hd) { return hd ? hd->params : nullptr; }
 float* mkws_head_grads(mkws_head* hd) { return hd ? hd->grads : nullptr; }
+int mkws_head_state_floats(const mkws_head* hd) { return hd ? (int)(4 * (hd->grads - hd->params)) : fail(MKWS_ERR_INVALID_ARG, "head handle is NULL"); }
 
 int mkws_head_set_params(mkws_head* hd, const float* h_params, int n, void* stream) {
   if (!hd || !h_params) return fail(MKWS_ERR_INVALID_ARG, "NULL argument");

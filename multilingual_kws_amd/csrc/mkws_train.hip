@@ -812,35 +812,45 @@ using namespace mkws;
 
 #define MKWS_REQ(cond, ...) do { if (!(cond)) return fail(MKWS_ERR_INVALID_ARG, __VA_ARGS__); } while (0)
 
+// Context of the training operators: the scratch arena of the fixed-order reductions and the queue of deferred second stages.  Every
+// host thread has a default context (mkws_op_set_scratch); a trainer that wants its state independent of the thread it happens to run
+// on -- two trainers on one thread, one trainer handed from thread to thread -- owns a context (mkws_train_ctx_create) and binds it
+// (mkws_train_ctx_bind) before its mkws_op_* calls.
+struct mkws_train_ctx {
+  float* scratch = nullptr;          // caller-owned device memory
+  size_t floats = 0;
+  size_t bump = 0;                   // floats held by queued folds: while folds are queued the arena is handed out from a bump pointer
+  int defer = 0;
+  mkws::FoldBatch fb;                // fb.n descriptors queued
+  int fold_blocks = 0;
+};
 namespace {
-// Scratch arena for the partial sums of the fixed-order reductions: caller-owned device memory, set per host thread.
-thread_local float* g_scratch = nullptr;
-thread_local size_t g_scratch_floats = 0;
-inline float* scratch(size_t floats) { return (g_scratch && floats <= g_scratch_floats) ? g_scratch : nullptr; }   // capacity check (base of the arena)
-// Deferred second stages (mkws_op_fold_defer): their partial sums stay in the arena until the flush, so the arena is handed out from a
-// bump pointer while folds are queued; every operator takes its scratch through scratch_at(), which flushes when the arena is full.
-thread_local size_t g_bump = 0;                       // floats held by queued folds
-thread_local int g_defer = 0;
-thread_local FoldBatch g_fb;                          // g_fb.n descriptors queued
-thread_local int g_fold_blocks = 0;
+thread_local mkws_train_ctx g_default_ctx;
+thread_local mkws_train_ctx* g_ctx = nullptr;
+inline mkws_train_ctx& ctx() { return g_ctx ? *g_ctx : g_default_ctx; }
+inline float* scratch(size_t floats) { mkws_train_ctx& c = ctx(); return (c.scratch && floats <= c.floats) ? c.scratch : nullptr; }   // capacity check (base of the arena)
 inline int fold_flush(hipStream_t s) {
-  if (g_fb.n > 0) hipLaunchKernelGGL(fold_batch_kernel, dim3(g_fold_blocks), dim3(256), 0, s, g_fb);
-  g_fb.n = 0; g_fold_blocks = 0; g_bump = 0;
+  mkws_train_ctx& c = ctx();
+  if (c.fb.n > 0) hipLaunchKernelGGL(fold_batch_kernel, dim3(c.fold_blocks), dim3(256), 0, s, c.fb);
+  c.fb.n = 0; c.fold_blocks = 0; c.bump = 0;
   return MKWS_OK;
 }
+// every operator takes its scratch through scratch_at(), which flushes the queued folds when the arena is full
 inline float* scratch_at(size_t floats, hipStream_t s) {
-  if (!g_scratch || floats > g_scratch_floats) return nullptr;
-  if (g_bump + floats > g_scratch_floats) fold_flush(s);
-  return g_scratch + g_bump;
+  mkws_train_ctx& c = ctx();
+  if (!c.scratch || floats > c.floats) return nullptr;
+  if (c.bump + floats > c.floats) fold_flush(s);
+  return c.scratch + c.bump;
 }
 // second stage out[(i / N) * ldc + i % N] (+)= scale * sum_z part[z][i], i < n: queued when deferral is on, launched otherwise (returns false)
 inline bool fold_defer(const float* part, float* out, int chunks, int n, int N, int ldc, float scale, int accumulate, hipStream_t s) {
-  if (!g_defer) return false;
-  if (g_fb.n == kMaxFolds) { fold_flush(s); return false; }          // (the caller's partials sit at the old bump position: fold them now)
-  FoldDesc& d = g_fb.d[g_fb.n++];
-  d.part = part; d.out = out; d.chunks = chunks; d.n = n; d.N = N; d.ldc = ldc; d.scale = scale; d.accumulate = accumulate; d.block0 = g_fold_blocks;
-  g_fold_blocks += (n + 255) / 256;
-  g_bump += ((size_t)chunks * n + 63) & ~(size_t)63;
+  mkws_train_ctx& c = ctx();
+  if (!c.defer) return false;
+  if (c.fb.n == kMaxFolds) { fold_flush(s); return false; }          // (the caller's partials sit at the old bump position: fold them now)
+  FoldDesc& d = c.fb.d[c.fb.n++];
+  d.part = part; d.out = out; d.chunks = chunks; d.n = n; d.N = N; d.ldc = ldc; d.scale = scale; d.accumulate = accumulate; d.block0 = c.fold_blocks;
+  c.fold_blocks += (n + 255) / 256;
+  c.bump += ((size_t)chunks * n + 63) & ~(size_t)63;
   return true;
 }
 inline int row_chunks(int M, int cap) { int c = (M + 127) / 128; if (c > cap) c = cap; if (c < 1) c = 1; return c; }
@@ -849,16 +859,41 @@ inline int row_chunks(int M, int cap) { int c = (M + 127) / 128; if (c > cap) c 
 extern "C" {
 
 int mkws_op_set_scratch(float* d_scratch, size_t floats) {
-  if (d_scratch != g_scratch || floats != g_scratch_floats) { g_fb.n = 0; g_fold_blocks = 0; g_bump = 0; }      // a new arena: nothing is queued in it
-  g_scratch = d_scratch;
-  g_scratch_floats = d_scratch ? floats : 0;
+  g_ctx = nullptr;                                                   // the thread's default context, and binds it
+  mkws_train_ctx& c = g_default_ctx;
+  if (d_scratch != c.scratch || floats != c.floats) { c.fb.n = 0; c.fold_blocks = 0; c.bump = 0; }      // a new arena: nothing is queued in it
+  c.scratch = d_scratch;
+  c.floats = d_scratch ? floats : 0;
+  return MKWS_OK;
+}
+
+int mkws_train_ctx_create(float* d_scratch, size_t floats, mkws_train_ctx** out) {
+  if (!out) return fail(MKWS_ERR_INVALID_ARG, "train_ctx_create: out is NULL");
+  *out = nullptr;
+  if (!d_scratch || floats == 0) return fail(MKWS_ERR_INVALID_ARG, "train_ctx_create: a context owns a scratch arena (device memory, > 0 floats)");
+  mkws_train_ctx* c = new (std::nothrow) mkws_train_ctx();
+  if (!c) return fail(MKWS_ERR_ALLOC, "train_ctx_create: out of host memory");
+  c->scratch = d_scratch; c->floats = floats;
+  *out = c;
+  return MKWS_OK;
+}
+
+void mkws_train_ctx_destroy(mkws_train_ctx* c) {
+  if (!c) return;
+  if (g_ctx == c) g_ctx = nullptr;                                   // (other threads must not have it bound: like any handle)
+  delete c;
+}
+
+int mkws_train_ctx_bind(mkws_train_ctx* c) {
+  g_ctx = c;                                                         // NULL = back to the thread's default context
   return MKWS_OK;
 }
 
 int mkws_op_fold_defer(int enable, void* stream) {
-  if (enable) { g_fb.n = 0; g_fold_blocks = 0; g_bump = 0; }      // a new pass: whatever an aborted one left queued is dropped, not folded
+  mkws_train_ctx& c = ctx();
+  if (enable) { c.fb.n = 0; c.fold_blocks = 0; c.bump = 0; }      // a new pass: whatever an aborted one left queued is dropped, not folded
   else fold_flush(static_cast<hipStream_t>(stream));
-  g_defer = enable ? 1 : 0;
+  c.defer = enable ? 1 : 0;
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

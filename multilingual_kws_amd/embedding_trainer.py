@@ -61,7 +61,19 @@ class EmbeddingTrainer:
         self._stream = None
         # partial sums of the fixed-order reductions (include/mkws.h: mkws_op_set_scratch); 16 Mi floats cover every layer
         self._scratch = torch.empty(16 << 20, dtype=torch.float32, device=self.device)
+        # the trainer's own operator context (arena + deferred-fold queue): independent of other trainers on this thread and of the
+        # thread it runs on; bound at the top of every public method (_bind_stream)
+        self._ctx = ctypes.c_void_p()
+        _lib.check(self.L.mkws_train_ctx_create(self._p(self._scratch), self._scratch.numel(), ctypes.byref(self._ctx)))
         self.d_step = torch.zeros(1, dtype=torch.int32, device=self.device)        # Adam step index for the graph-replayed step
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self.L.mkws_train_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
 
     # ---- plumbing -----------------------------------------------------------------------------------------------------
     def _s(self):
@@ -69,7 +81,7 @@ class EmbeddingTrainer:
 
     def _bind_stream(self):
         self._stream = _lib.current_stream_ptr()
-        _lib.check(self.L.mkws_op_set_scratch(self._p(self._scratch), self._scratch.numel()))     # per host thread: cheap, idempotent
+        _lib.check(self.L.mkws_train_ctx_bind(self._ctx))                                          # a thread-local pointer store
 
     @staticmethod
     def _p(t):
@@ -248,11 +260,21 @@ class EmbeddingTrainer:
         tape = self.tape
         if tape is None:
             raise RuntimeError("backward() needs a forward_train() first")
-        B = tape["B"]
         self._bind_stream()
         # second stages of the gradient reductions wait in a queue and run a batch at a time (mkws_op_fold_defer): nobody reads a weight
         # gradient before the all-reduce / the optimizer
         _lib.check(self.L.mkws_op_fold_defer(1, self._s()))
+        done = False
+        try:
+            self._backward_sweep(tape, d_emb, allreduce)
+            done = True
+        finally:
+            if not done:        # an operator raised mid-sweep: do not leave the context deferring (the queue is dropped by the next fold_defer(1))
+                self.L.mkws_op_fold_defer(0, self._s())
+
+    def _backward_sweep(self, tape, d_emb, allreduce):
+        torch = self.torch
+        B = tape["B"]
         # (no memset of the 52 MB gradient blob: every trainable tensor's gradient is WRITTEN by exactly one operator per step, and the slots
         #  of the non-trainable tensors -- moving statistics, normalisation constants -- are never touched after the zero-initialisation)
         self._pending = []
@@ -355,7 +377,7 @@ class TrainStepGraph:
             # warm-up on a side stream: fills the trainer's buffer pool for this batch size and every lazily created view, on state
             # that is restored afterwards (parameters, moving statistics, Adam moments, step counters)
             snap = [t.clone() for t in (trainer.params, trainer.m, trainer.v, trainer.d_step)]
-            hp = head.get_params()
+            hstate, hstep = head.state_view().clone(), head.step_t          # parameters AND Adam moments of the head (set_params would zero m / v)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -364,7 +386,8 @@ class TrainStepGraph:
             torch.cuda.synchronize(dev)
             for t, c in zip((trainer.params, trainer.m, trainer.v, trainer.d_step), snap):
                 t.copy_(c)
-            head.set_params(hp)
+            head.state_view().copy_(hstate)
+            head.step_t = hstep
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.stats = self._body()

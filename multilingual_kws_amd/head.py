@@ -73,6 +73,10 @@ class Head:
     def param_view(self):
         return self._alias(self.L.mkws_head_params(self.h), self.nparams)
 
+    def state_view(self):
+        """params | grads | Adam m | Adam v as ONE flat tensor aliasing the handle (snapshot / restore of the whole optimizer state)."""
+        return self._alias(self.L.mkws_head_params(self.h), _lib.check(self.L.mkws_head_state_floats(self.h)))
+
     def _alias(self, ptr, n):
         import torch
         key = (int(ptr), int(n))

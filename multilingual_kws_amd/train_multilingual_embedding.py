@@ -54,11 +54,21 @@ class LogitsLayer:
         self.W, self.b = self.params[:self.in_dim * self.n], self.params[self.in_dim * self.n:]
         self.dW, self.db = self.grads[:self.in_dim * self.n], self.grads[self.in_dim * self.n:]
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
-        # arena for the fixed-order reductions of the operators below (per host thread; the embedding trainer re-binds its own)
+        # the layer's own operator context (arena for the fixed-order reductions of the operators below; include/mkws.h, mkws_train_ctx)
         self._scratch = torch.empty(4 << 20, dtype=torch.float32, device=self.device)
+        self._ctx = ctypes.c_void_p()
+        _lib.check(self.L.mkws_train_ctx_create(self._p(self._scratch), self._scratch.numel(), ctypes.byref(self._ctx)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self.L.mkws_train_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
 
     def _bind(self):
-        _lib.check(self.L.mkws_op_set_scratch(self._p(self._scratch), self._scratch.numel()))
+        _lib.check(self.L.mkws_train_ctx_bind(self._ctx))
 
     @staticmethod
     def _p(t):
