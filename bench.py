@@ -223,7 +223,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, batch=1024):
     """HBM bytes per launch from the committed PMC passes (tools/pmc_to_json.py) -- only if they were collected on THIS
     build of the kernels (source hash match); a stale file yields null, never an old number."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -233,8 +233,8 @@ def measured_traffic(kernel):
         return None, "no profiles/pmc_traffic.json"
     if d.get("_source_hash") != source_hash():
         return None, f"profiles/pmc_traffic.json is from build {d.get('_source_hash')}, this is {source_hash()}"
-    e = d.get(kernel)
-    return (e.get("hbm_bytes_per_launch"), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same build") if e else (None, "kernel not in pmc_traffic.json")
+    e = d.get(kernel if batch == 1024 else f"{kernel}@{batch}")       # passes at 512 / 256 clips are stored as "<label>@<batch>"
+    return (e.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at {batch} clips, same build") if e else (None, "kernel not in pmc_traffic.json")
 
 
 def embed_roofline(em, spec, B, reps, arch, extra=None):
@@ -282,7 +282,7 @@ def _kernel_frac(v):
     return t_roof / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
 
 
-def roofline_of(per_kernel):
+def roofline_of(per_kernel, batch=1024):
     # "dominant" = most summed time per step; kernels within 5 % of the leader are a tie that timing noise would otherwise
     # decide (round 2: 0.156 / 0.154 / 0.150 ms), so among those the one FURTHEST from its roofline is reported
     top_ms = max(v["ms"] for v in per_kernel.values())
@@ -292,7 +292,7 @@ def roofline_of(per_kernel):
     avg_ms = dom["ms"] / dom["launches"]
     t_flops = dom["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
     t_bytes = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
-    traffic, traffic_src = measured_traffic(dom_name)
+    traffic, traffic_src = measured_traffic(dom_name, batch)
     if t_flops >= t_bytes:
         ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -468,7 +468,7 @@ def main():
                 # what the per-kernel table (frontend + embedding launches) does NOT cover: augmentation, SpecAugment, the head's
                 # loss / gradient / update kernels, collectives.  Round 2 found 290 us hiding here in the fine-tune config.
                 whole["other_ms"] = round(max(0.0, ms_per_step - fe_ms - emb_ms), 4)
-        roof, kernels = roofline_of(per_kernel)
+        roof, kernels = roofline_of(per_kernel, B)
         if cfg == "frontend":       # the whole step IS the one kernel
             roof["whole_step_frac"] = round(B * arch.FRONTEND_BYTES_PER_CLIP_F32 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         else:                       # algorithmic FLOPs of the step (embedding forward of every clip / window) / wall time of the step / MFMA peak

@@ -13,6 +13,10 @@ export TMPDIR=/tmp
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch -o f -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_fetch.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_write -o w -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_write.log 2>&1 )
+for BS in 512 256; do
+( cd /tmp && ONE_FWD_B=$BS timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch_$BS -o f -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_fetch_$BS.log 2>&1 )
+( cd /tmp && ONE_FWD_B=$BS timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_write_$BS -o w -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_write_$BS.log 2>&1 )
+done
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_mfma -o m -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_mfma.log 2>&1 )
 find $O -name "*.csv" | head -20
 python - <<'PY'

@@ -9,7 +9,7 @@ from multilingual_kws_amd.embedding_model import EmbeddingModel
 from multilingual_kws_amd.frontend import Frontend
 
 dev = torch.device("cuda:0")
-B = 1024
+B = int(os.environ.get("ONE_FWD_B", "1024"))      # 512 / 256: the handles of the fine-tune / streaming configs (other workgroup shapes)
 em = EmbeddingModel(weights.synthetic_blob(), max_batch=B)
 fe = Frontend(max_samples=16000)
 audio = torch.from_numpy(synth.clips_float32(B)).to(dev)

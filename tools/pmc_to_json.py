@@ -70,6 +70,17 @@ def main():
         fk = last_forward_mean(fetch[k]) if k in fetch else 0.0
         wk = last_forward_mean(write[k]) if k in write else 0.0
         out[k] = {"fetch_size_kib": round(fk, 1), "write_size_kib": round(wk, 1), "hbm_bytes_per_launch": int(round((2.0 * fk + wk) * 1024))}
+    # the handles of the fine-tune (512 clips) and streaming (256) configs launch other workgroup shapes and move other byte counts per
+    # launch: extra passes with ONE_FWD_B=512 / 256, stored as "<label>@<batch>" (bench.py looks a kernel up under its config's batch)
+    for bsz in (512, 256):
+        fd, wd = os.path.join(base, f"pmc_fetch_{bsz}"), os.path.join(base, f"pmc_write_{bsz}")
+        if not (os.path.isdir(fd) and os.path.isdir(wd)):
+            continue
+        f5, w5 = read_counters(fd)["FETCH_SIZE"], read_counters(wd)["WRITE_SIZE"]
+        for k in sorted(set(f5) | set(w5)):
+            fk = last_forward_mean(f5[k]) if k in f5 else 0.0
+            wk = last_forward_mean(w5[k]) if k in w5 else 0.0
+            out[f"{k}@{bsz}"] = {"fetch_size_kib": round(fk, 1), "write_size_kib": round(wk, 1), "hbm_bytes_per_launch": int(round((2.0 * fk + wk) * 1024))}
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     for k, v in sorted(((k, v) for k, v in out.items() if not k.startswith("_")), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch  {k}")
