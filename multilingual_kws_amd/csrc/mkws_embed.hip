@@ -4794,7 +4794,7 @@ int launch_back(hipStream_t s, const char* stage, const BlockPlan& b, const floa
   //                          HOWO CEXP NTP RS NTHR WPE
   if (b.ce == 96) return launch_back_inst<130, 96, 2, 8, 512, 4>(s, stage, a);   // 2a: 52 KB of LDS -> 3 workgroups per CU
   if (b.ce == 144) return launch_back_inst<130, 144, 2, 4, 512, 4>(s, stage, a);  // 2b: 80.5 KB -> 2 per CU
-  return launch_back_inst<35, 240, 3, 4, 512, 4>(s, stage, a);                    // 3b: 39 KB -> 4 per CU
+  return launch_back_inst<35, 240, 3, 4, 512, 4>(s, stage, a);                    // 3b: 39 KB -> 4 per CU by LDS; 91 VGPRs keep it at 2 (6 waves per SIMD spills 37 registers: tried in round 4)
 }
 
 void launch_se(hipStream_t s, const char* stage, const BlockPlan& b, const float* sums, float* part, float* gate, int B) {

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   f32x4 K = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
     K = *reinterpret_cast<const f32x4*>(Z + (size_t)r0 * C + c0);
+#pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
     for (int r = r0 + rl; r < r1; r += 16) {
       const f32x4 d = *reinterpret_cast<const f32x4*>(Z + (size_t)r * C + c0) - K;
       a1 += d;
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
   f32x4 inv, mu;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { inv[i] = s_sc[4 * ql + i]; mu[i] = s_sh[4 * ql + i]; }
+#pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
   for (int r = r0 + rl; r < r1; r += 16) {
     const f32x4 z = *reinterpret_cast<const f32x4*>(Z + (size_t)r * C + c0);
     f32x4 y;
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(256) void col_sum_partial_kernel(float* __restrict_
   float acc = 0.0f;
   if (c < C) {
     const float bc = MODE == 1 ? bias[c] : 0.0f;
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 4) {
       const size_t i = (size_t)r * C + c;
       float x = X[i];
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
     f32x4 inv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) inv[i] = rsqrtf(vv[i] + eps);
+#pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
     for (int r = r0 + rl; r < r1; r += 16) {
       const size_t o = (size_t)r * C + c0;
       const f32x4 z = *reinterpret_cast<const f32x4*>(Z + o);
@@ -453,6 +457,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   f32x4 inv, sa, sb;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { inv[i] = rsqrtf(vv[i] + eps); sa[i] = s_a[4 * ql + i] * invM; sb[i] = s_b[4 * ql + i] * invM; }
+#pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
   for (int r = r0 + rl; r < r1; r += 16) {
     const size_t o = (size_t)r * C + c0;
     const f32x4 z = *reinterpret_cast<const f32x4*>(Z + o);
@@ -537,43 +542,56 @@ __global__ __launch_bounds__(256) void dw_bwd_input_kernel(const float* __restri
 template <int KS>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ part /*[chunks][KS*KS*C]*/,
                                                             int B, int H, int Wd, int C, int s, int pt, int pl, int Ho, int Wo) {
-  __shared__ float red[16][16][4];
+  // thread = (channel quad ql of 16, position lane pl16 of 16); a workgroup owns 16 quads x one chunk of output positions.
+  // Round 4: the 25 tap sums used to leave the workgroup one tap at a time (2 barriers + a 16-deep serial sum each: 50 barriers for a
+  // 5x5 kernel, 42.7 us per call at 64 clips).  Now the four position lanes of a wave fold by two DPP-style shuffles, the four waves
+  // through LDS with ONE barrier, and the chunks are finer (launcher), so that the grid covers the chip.  Fixed order throughout.
+  __shared__ float red[4][KS * KS][16][4];
   const int ql = threadIdx.x & 15, pl16 = threadIdx.x >> 4;
   const int q = blockIdx.x * 16 + ql;
   const bool qok = q * 4 < C;
-  const int npos = qok ? B * Ho * Wo : 0;
-  const int per = (B * Ho * Wo + gridDim.y - 1) / gridDim.y;
+  const int npos = B * Ho * Wo;
+  const int per = (npos + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * per, p1 = (p0 + per < npos) ? p0 + per : npos;
   f32x4 acc[KS * KS];
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int p = p0 + pl16; p < p1; p += 16) {
-    const int ow = p % Wo, oh = (p / Wo) % Ho, b = p / (Wo * Ho);
-    const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + (size_t)p * C + 4 * q);
+  if (qok) {
+    for (int p = p0 + pl16; p < p1; p += 16) {
+      const int ow = p % Wo, oh = (p / Wo) % Ho, b = p / (Wo * Ho);
+      const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + (size_t)p * C + 4 * q);
 #pragma unroll
-    for (int ii = 0; ii < KS; ++ii) {
-      const int ih = oh * s - pt + ii;
-      if (ih < 0 || ih >= H) continue;
+      for (int ii = 0; ii < KS; ++ii) {
+        const int ih = oh * s - pt + ii;
+        if (ih < 0 || ih >= H) continue;
 #pragma unroll
-      for (int jj = 0; jj < KS; ++jj) {
-        const int iw = ow * s - pl + jj;
-        if (iw < 0 || iw >= Wd) continue;
-        acc[ii * KS + jj] += dz * *reinterpret_cast<const f32x4*>(X + (((size_t)b * H + ih) * Wd + iw) * C + 4 * q);
+        for (int jj = 0; jj < KS; ++jj) {
+          const int iw = ow * s - pl + jj;
+          if (iw < 0 || iw >= Wd) continue;
+          acc[ii * KS + jj] += dz * *reinterpret_cast<const f32x4*>(X + (((size_t)b * H + ih) * Wd + iw) * C + 4 * q);
+        }
       }
     }
   }
-  float* slab = part + (size_t)blockIdx.y * KS * KS * C;
+  // lanes ql, ql + 16, ql + 32, ql + 48 of a wave hold the same quad: (l0 + l1) + (l2 + l3), then the four waves in wave order
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t) {
-    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[pl16][ql][r] = acc[t][r];
-    __syncthreads();
-    if (pl16 < 4 && qok) {                              // lane r of the first four position lanes finishes component r
-      float v = red[0][ql][pl16];
-      for (int l = 1; l < 16; ++l) v += red[l][ql][pl16];
-      slab[(size_t)t * C + 4 * q + pl16] = v;
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[t][r];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      acc[t][r] = v;
     }
+    if (lane < 16) *reinterpret_cast<f32x4*>(&red[wave][t][ql][0]) = acc[t];
+  }
+  __syncthreads();
+  float* slab = part + (size_t)blockIdx.y * KS * KS * C;
+  for (int i = threadIdx.x; i < KS * KS * 64; i += 256) {
+    const int t = i >> 6, qq = (i >> 2) & 15, r = i & 3;
+    const int ch = (blockIdx.x * 16 + qq) * 4 + r;
+    if (ch < C) slab[(size_t)t * C + ch] = (red[0][t][qq][r] + red[1][t][qq][r]) + (red[2][t][qq][r] + red[3][t][qq][r]);
   }
 }
 
@@ -1039,10 +1057,15 @@ int mkws_op_dwconv_bwd(const float* X, const float* W, const float* dZ, float* d
   MKWS_REQ(X && W && dZ && dW && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_bwd: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dX) hipLaunchKernelGGL(dw_bwd_input_kernel, dim3(grid_for((size_t)B * H * Wd * (C / 4))), dim3(256), 0, st, dZ, W, dX, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
-  int chunks = (B * Ho * Wo + 127) / 128; if (chunks > 128) chunks = 128; if (chunks < 1) chunks = 1;
+  // chunks of output positions: 32 positions each (two per position lane) until the grid has ~512 workgroups, at most 256 chunks
+  const int xb = (C / 4 + 15) / 16;
+  int chunks = (B * Ho * Wo + 31) / 32;
+  const int cap = (512 + xb - 1) / xb < 256 ? (512 + xb - 1) / xb : 256;
+  if (chunks > cap) chunks = cap;
+  if (chunks < 1) chunks = 1;
   float* part = scratch_at((size_t)chunks * k * k * C, st);
   MKWS_REQ(part, "dwconv_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * k * k * C);
-  const dim3 grid((C / 4 + 15) / 16, chunks);
+  const dim3 grid(xb, chunks);
   if (k == 3) hipLaunchKernelGGL((dw_bwd_weight_kernel<3>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   else hipLaunchKernelGGL((dw_bwd_weight_kernel<5>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   if (!fold_defer(part, dW, chunks, k * k * C, k * k * C, k * k * C, 1.0f, 0, st))
