@@ -430,8 +430,13 @@ def test_bucketed_gradient_allreduce_over_rccl():
 
 def test_graph_replayed_training_step_equals_the_eager_step():
     """TrainStepGraph: forward + head loss + backward + both Adam updates of one `backprop_into_embedding` step as ONE hipGraph
-    replay.  Three steps with fresh inputs and drop-connect masks must leave exactly the parameters, moving statistics and head
-    the launch-by-launch path leaves (all reductions are fixed-order, the Adam step index is a device counter)."""
+    replay.  (a) Three replays with fresh inputs and drop-connect masks leave EXACTLY what the same launches issued one by one
+    leave (use_graph=False: same kernels, same buffers, device-side step counter) -- every reduction has a fixed order.  (b) Against
+    the host-driven eager step (EmbeddingTrainer / Head methods with host step counters) after ONE step: host pow vs device pow in lr_t
+    differ in the last bit, and Adam turns a last-bit difference of a noise-level gradient (betas in front of a batch-statistics BN
+    have an exactly-zero true gradient) into a full +-lr step, so a handful of parameters may sit lr apart; everything else agrees to
+    round-off.  (Comparing the two after several steps is not a test of the code: a ReLU of the dense stack that flips for one clip
+    under a 1e-7 perturbation changes a whole weight column's gradient -- seen in round 4 when a kernel's summation order changed.)"""
     from multilingual_kws_amd import weights
     from multilingual_kws_amd.embedding_trainer import EmbeddingTrainer, TrainStepGraph, drop_connect_rates
     from multilingual_kws_amd.head import Head
@@ -441,30 +446,33 @@ def test_graph_replayed_training_step_equals_the_eager_step():
     specs = [torch.from_numpy(rng.integers(0, 670, size=(B, 49, 40)).astype(np.float32) * np.float32(10 / 256)).cuda() for _ in range(3)]
     labels = [torch.from_numpy(rng.integers(0, 3, B).astype(np.int32)).cuda() for _ in range(3)]
     masks = [{n: rng.uniform(0, 1, B) >= r for n, r in drop_connect_rates().items()} for _ in range(3)]
-    tr_e, hd_e = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
-    stats_e = []
-    for x, y, mk in zip(specs, labels, masks):
-        emb = tr_e.forward_train(x, mk)
-        stats_e.append(hd_e.loss_grad(emb, y).clone())
-        tr_e.backward(hd_e.input_grad(B))
-        hd_e.adam_step(lr=lr)
-        tr_e.adam_step(lr=lr)
+    # (a) graph replay == the same launches one by one, bit for bit, over three steps
+    tr_l, hd_l = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    step_l = TrainStepGraph(tr_l, hd_l, B, lr, use_graph=False)
+    stats_l = [step_l.run(x, y, mk).clone() for x, y, mk in zip(specs, labels, masks)]
     tr_g, hd_g = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
     step = TrainStepGraph(tr_g, hd_g, B, lr)
-    assert step.graph is not None
+    assert step.graph is not None and step_l.graph is None
     assert np.array_equal(tr_g.blob(), blob) and int(tr_g.d_step.item()) == 0           # the capture warm-up left no trace
     for i, (x, y, mk) in enumerate(zip(specs, labels, masks)):
-        st = step.run(x, y, mk).clone()
-        assert torch.allclose(st, stats_e[i], rtol=1e-4, atol=1e-4), i
+        assert torch.equal(step.run(x, y, mk), stats_l[i]), i
     torch.cuda.synchronize()
-    assert int(tr_g.d_step.item()) == 3
-    pe, pg = tr_e.blob(), tr_g.blob()
-    # host pow vs device pow in lr_t differ in the last bit; Adam turns a last-bit difference of a noise-level gradient (betas in front
-    # of a batch-statistics BN have an exactly-zero true gradient) into a full +-lr step, so a handful of parameters may sit up to
-    # 3 steps x lr apart; everything else agrees to round-off
-    diff = np.abs(pe - pg)
-    assert diff.max() <= 3.5 * lr and (diff > 1e-6).mean() < 1e-3
-    assert np.abs(hd_e.get_params() - hd_g.get_params()).max() <= 3.5 * lr
+    assert int(tr_g.d_step.item()) == 3 == int(tr_l.d_step.item())
+    pg = tr_g.blob()
+    assert np.array_equal(pg, tr_l.blob()) and np.array_equal(hd_g.get_params(), hd_l.get_params())
+    # (b) one step of the host-driven eager path
+    tr_e, hd_e = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    emb = tr_e.forward_train(specs[0], masks[0])
+    st_e = hd_e.loss_grad(emb, labels[0]).clone()
+    tr_e.backward(hd_e.input_grad(B))
+    hd_e.adam_step(lr=lr)
+    tr_e.adam_step(lr=lr)
+    tr_1, hd_1 = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    st_1 = TrainStepGraph(tr_1, hd_1, B, lr).run(specs[0], labels[0], masks[0]).clone()
+    assert torch.allclose(st_1, st_e, rtol=1e-4, atol=1e-4)
+    diff = np.abs(tr_e.blob() - tr_1.blob())
+    assert diff.max() <= 1.5 * lr and (diff > 1e-6).mean() < 1e-3
+    assert np.abs(hd_e.get_params() - hd_1.get_params()).max() <= 1.5 * lr
     # and the graph path repeats itself bit for bit
     tr_h, hd_h = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
     step2 = TrainStepGraph(tr_h, hd_h, B, lr)

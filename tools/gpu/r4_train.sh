@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4_train; rm -rf $O; mkdir -p $O
+timeout 900 python -m pytest tests/test_train_gpu.py tests/test_train_embedding_gpu.py tests/test_hf_efficientnet_train_golden.py tests/test_pipeline_gpu.py -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log | cut -c1-200
