@@ -399,6 +399,9 @@ struct GemmArgs {
   int splitk;      // > 1: blockIdx.z owns a slice of the K chunks and writes raw sums to part[z][M][ldp]
   float* part; int ldp;
   const int* poison;   // optional device word: nonzero = an earlier kernel of this forward failed (mbconv_pair_kernel's exchange): store NaN
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbg_clk;   // timing build: [workgroup][2] = shader-clock cycles, 100 MHz ticks of wave 0
+#endif
 };
 
 template <int MT, int NT, bool GATE>
@@ -422,6 +425,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
   const int m0 = bx * (64 * MT) + wave * (16 * MT);
   const int nt0 = by * NT;
   if (m0 >= a.M) return;
+#ifdef MKWS_FRONT_TIMING
+  const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
 
   // Operand pointers are CLAMPED instead of predicated (rows past M re-read row M-1, tiles past NTtot
   // re-read the last tile; their results are never stored), so the K loop has no per-load branches.
@@ -551,6 +557,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
     }
     return;
   }
+#ifdef MKWS_FRONT_TIMING
+  if (a.dbg_clk && threadIdx.x == 0) { a.dbg_clk[2 * (blockIdx.x + gridDim.x * blockIdx.y)] = clock64() - dbg_c0; a.dbg_clk[2 * (blockIdx.x + gridDim.x * blockIdx.y) + 1] = wall_clock64() - dbg_w0; }
+#endif
   // epilogue: lane (g, c) holds rows m = m0 + mt*16 + c, channels n = 16*(nt0+nt) + 4g .. +3
   const bool poisoned = a.poison != nullptr && *a.poison != 0;       // uniform (scalar load)
 #pragma unroll
@@ -4139,11 +4148,27 @@ void launch_gemm(hipStream_t s, const SplitWs& sw, const char* stage, const Gemm
     else a.part = sw.p;
   }
   dim3 grid((M + 64 * MT - 1) / (64 * MT), (L.NTtot + NT - 1) / NT, a.splitk);
+#ifdef MKWS_FRONT_TIMING
+  static unsigned long long* d_gc = nullptr;
+  if (!d_gc) (void)hipMalloc(&d_gc, sizeof(unsigned long long) * 2 * 65536);
+  a.dbg_clk = (grid.x * grid.y <= 65536 && a.splitk == 1) ? d_gc : nullptr;
+#endif
   {
     ProfScope ps(stage, std::string("pw_gemm_kernel<") + std::to_string(MT) + "," + std::to_string(NT) + (gate ? ",true>" : ",false>"));
     if (MT == 2) { if (gate) launch_gemm_nt<2, true>(NT, grid, s, a); else launch_gemm_nt<2, false>(NT, grid, s, a); }
     else { if (gate) launch_gemm_nt<1, true>(NT, grid, s, a); else launch_gemm_nt<1, false>(NT, grid, s, a); }
   }
+#ifdef MKWS_FRONT_TIMING
+  if (a.dbg_clk) {
+    (void)hipStreamSynchronize(s);
+    const size_t nb = (size_t)grid.x * grid.y;
+    std::vector<unsigned long long> h(2 * nb);
+    (void)hipMemcpy(h.data(), d_gc, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost);
+    double mhz = 0, us = 0;
+    for (size_t i = 0; i < nb; ++i) { mhz += (double)h[2 * i] / ((double)h[2 * i + 1] / 100.0); us += (double)h[2 * i + 1] / 100.0; }
+    fprintf(stderr, "[gemm-timing] %s <%d,%d>: %zu workgroups, K loop of wave 0: %.2f us mean, shader clock %.0f MHz\n", stage, MT, NT, nb, us / nb, mhz / nb);
+  }
+#endif
   if (a.splitk > 1) {
     ProfScope ps(std::string(stage) + "#reduce", "splitk_reduce_kernel");
     const long total = (long)M * (L.N / 4);
