@@ -4139,7 +4139,8 @@ void launch_gemm(hipStream_t s, const SplitWs& sw, const char* stage, const Gemm
   if (pool4) tc.splitk = 1;                 // the fused average pool lives in the direct epilogue only
   if (const char* f = getenv("MKWS_GEMM_FORCE")) {       // experiment hook: "Mmax,MT,NT,SK" applies to layers with Mplan <= Mmax
     int mmax = 0, fmt = 0, fnt = 0, fsk = 0;
-    if (sscanf(f, "%d,%d,%d,%d", &mmax, &fmt, &fnt, &fsk) == 4 && Mplan <= mmax && fnt <= L.NTtot) tc = {fmt, fnt, fsk};
+    const int mmin = getenv("MKWS_GEMM_FORCE_MIN") ? atoi(getenv("MKWS_GEMM_FORCE_MIN")) : 0;
+    if (sscanf(f, "%d,%d,%d,%d", &mmax, &fmt, &fnt, &fsk) == 4 && Mplan <= mmax && Mplan >= mmin && fnt <= L.NTtot) tc = {fmt, fnt, fsk};
   }
   const int MT = tc.MT, NT = tc.NT;
   a.splitk = tc.splitk; a.part = nullptr; a.ldp = L.NTtot * 16;
