@@ -479,3 +479,44 @@ def test_graph_replayed_training_step_equals_the_eager_step():
     for x, y, mk in zip(specs, labels, masks):
         step2.run(x, y, mk)
     assert np.array_equal(tr_h.blob(), pg) and np.array_equal(hd_h.get_params(), hd_g.get_params())
+
+
+def test_two_trainers_interleaved_on_one_thread_do_not_share_operator_state():
+    """mkws_train_ctx (include/mkws.h): each EmbeddingTrainer owns its scratch arena and deferred-fold queue and binds them at the top of
+    every public method.  Two trainers whose forward / backward calls are INTERLEAVED on one host thread -- the second one's forward
+    runs while the first has a tape pending, its backward queues folds between the first's forward and backward -- must each produce
+    exactly the gradient they produce alone; so must a trainer whose backward runs on another host thread than its forward."""
+    import threading
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding_trainer import EmbeddingTrainer
+    blob = weights.synthetic_blob()
+    rng = np.random.default_rng(5)
+    xs = [torch.from_numpy(rng.integers(0, 670, size=(4, 49, 40)).astype(np.float32) * np.float32(10 / 256)).cuda() for _ in range(2)]
+    ds = [torch.from_numpy(rng.standard_normal((4, 1024)).astype(np.float32)).cuda() for _ in range(2)]
+
+    def alone(k):
+        tr = EmbeddingTrainer(blob)
+        tr.forward_train(xs[k], None)
+        tr.backward(ds[k])
+        return tr.grads.clone()
+    want = [alone(0), alone(1)]
+    a, b = EmbeddingTrainer(blob), EmbeddingTrainer(blob)
+    a.forward_train(xs[0], None)
+    b.forward_train(xs[1], None)
+    b.backward(ds[1])
+    a.backward(ds[0])
+    assert torch.equal(a.grads, want[0]) and torch.equal(b.grads, want[1])
+    c = EmbeddingTrainer(blob)
+    c.forward_train(xs[0], None)
+    err = []
+
+    def other_thread():
+        try:
+            with torch.cuda.device(0):
+                c.backward(ds[0])
+                torch.cuda.synchronize()
+        except Exception as e:      # pragma: no cover
+            err.append(e)
+    t = threading.Thread(target=other_thread)
+    t.start(); t.join()
+    assert not err and torch.equal(c.grads, want[0])
