@@ -257,6 +257,9 @@ def embed_roofline(em, spec, B, reps, arch, extra=None):
         elif stage.startswith("chain:"):
             # depth-fused launch: the algorithmic work of its blocks; bytes = chain input + output + every weight once (inner activations stay in LDS)
             names = stage[len("chain:"):].split(",")
+            top = names[-1] == "top"                                  # the top conv + global average pool as the paired chain's last phase
+            if top:
+                names = names[:-1]
             fl = sum(costs["block" + n + "_block"][0] for n in names)
             act = {n: (ci, co, s_) for n, ci, co, _, s_, _ in arch.BLOCKS}
             by = sum(costs["block" + n + "_block"][1] for n in names)
@@ -266,6 +269,9 @@ def embed_roofline(em, spec, B, reps, arch, extra=None):
                 by -= 4 * m * co * 2                                    # a_'s output store + b_'s input load
                 if act[b_][2] == 1 and act[b_][0] == act[b_][1]:
                     by -= 4 * m * co                                    # b_'s residual re-read
+            if top:     # + the top conv's flops and weights; the last block's output stays on chip, the pooled features go out instead
+                fl += costs["top"][0]
+                by += 4 * (320 * 1280 + B * 1280) - 4 * B * 4 * 320
             cost = (fl, by)
         elif kernel.startswith("mbconv_block") or kernel.startswith("mbconv_mid") or kernel.startswith("mbconv_pair"):
             cost = costs[stage + "_block"]

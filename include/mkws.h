@@ -167,10 +167,15 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "fuse_block" (default 2): blocks with 4x3 and 2x2 images (4b..7a) run expand -> depthwise -> SE -> project as
  *                 ONE kernel, 4 clips per workgroup, activations resident in LDS; 1 = only the 2x2 blocks
  *                 (6b..7a); 0 = the multi-kernel path everywhere.
- *   "fuse_chain" (default 1; needs "fuse_block" = 2): consecutive 4x3-image blocks (4b, 4c, 5a, 5b, 5c, 6a) run as ONE launch: a workgroup
+ *   "fuse_chain" (default 1; needs "fuse_block" = 2; 2 / 3 = only the first / second of the two chains): the stride-1 2x2-image blocks
+ *                 (6b, 6c, 6d, 7a) run as ONE paired launch (exchange 2 carries all projection tiles and both halves finish them), and
+ *                 consecutive 4x3-image blocks (4b, 4c, 5a, 5b, 5c, 6a) run as ONE launch: a workgroup
  *                 keeps its clips' activations in LDS from block to block (a block's projection writes the next block's MFMA operand
  *                 fragments), the residual rides in registers, the next block's weight ring is requested during the current block's
  *                 projection.  Bit-identical to one whole-block launch per block (0).  Not used by handles that plan the cluster kernel.
+ *   "fuse_top" (default 1; needs "fuse_chain" 1 or 3 and "fuse_gap"): the top conv + BN + swish + global average pool run as the LAST PHASE of
+ *                 the paired chain (both halves hold block 7a's output as fragments; they split the 80 output tiles, nothing is exchanged)
+ *                 instead of a launch of their own.  Bit-identical pooled features.
  *   "fuse_pair" (default 1 when the probe at create passed; needs "fuse_block"): the stride-1 2x2-image blocks (6b, 6c, 6d, 7a) run on
  *                 the PAIRED whole-block kernel: two workgroups on two CUs of one XCD share 8 clips and split the expanded channels,
  *                 so each CU streams half of the block's weights; two small in-kernel exchanges through L2.  0 = one workgroup per 4 clips.

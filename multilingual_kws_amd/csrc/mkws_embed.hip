@@ -3054,6 +3054,9 @@ struct PairChainArgs {
   float* xd;                  // [pairs][2][kPairXdAll][2][256]
   int* flags;                 // [pairs][kPairChainMax][2 exchanges][2 halves], zero between launches
   int* err_dev; int* err_host; int fault;
+  // top conv + BN + swish + global average pool as the chain's last phase (null = not fused): the halves split its n-tiles, no exchange
+  const float* top_Wp; const float* top_sc; const float* top_sh; int top_KC, top_NT;
+  float* gap;                 // [B, 16 * top_NT] pooled features
 };
 static constexpr int kPairXdAll = 20;
 
@@ -3371,6 +3374,55 @@ __device__ __forceinline__ void pair_chain_block(const BlockArgs& a, const Block
   if (nx) __syncthreads();
 }
 
+// Last phase of the paired chain when the top conv is fused into it: [16 MT rows x K] . [K x 16 top_NT] + BN + swish + 2x2 average pool.
+// Both halves hold block 7a's whole output as fragments in U; half h owns n-tiles [h * top_NT / 2, +top_NT / 2), wave w tiles w, w + 8, ...
+// (five of them: one stream_mfma over five accumulator tiles x MT row tiles), so nothing is exchanged.  Same operations in the same order
+// as pw_gemm_kernel<.., pool4>: chunk-ascending fp32 MFMA accumulation, acc * scale + shift, swish, (r0 + r1) + (r2 + r3) by two
+// xor-shuffles, * 0.25 -- bit-identical pooled features.  Why it pays: the stand-alone top conv has K = 320, 20 chunks per wave: ring fill
+// and epilogue are a third of its 38 us (0.55 of the MFMA roof); here its weights stream like another block's.
+template <int MT, int NWAVES>
+__device__ __forceinline__ void pair_top_phase(const PairChainArgs& pa, float* s_blk, int h, int pair) {
+  constexpr int G = 4 * MT, NTW = 5;
+  const int tid = opaque_((int)threadIdx.x), lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const unsigned loff = (unsigned)(g * 64 + c * 4);
+  const int b0 = pair * G;
+  const int NTh = pa.top_NT / 2;
+  const float* s_X = s_blk;
+  const WBuf w(pa.top_Wp, loff);
+  f32x4 wq[4][NTW];
+  f32x4 acc[NTW][MT];
+#pragma unroll
+  for (int q = 0; q < NTW; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto xload = [&](int j, int m) { return *reinterpret_cast<const f32x4*>(s_X + ((size_t)(j * MT + m) * 64 + lane) * 4); };
+  auto xmake = [](const f32x4& v) { return v; };
+  stream_mfma<NTW, 4, MT, false>(acc, wq, w, (size_t)pa.top_NT * 256, h * NTh + wave, NWAVES, (h + 1) * NTh, pa.top_KC, xload, xmake);
+#pragma unroll
+  for (int q = 0; q < NTW; ++q) {
+    const int i = wave + NWAVES * q;                            // tile of this half
+    const int n = (h * NTh + i) * 16 + 4 * g;
+    const bool tok = i < NTh;                                   // (uniform)
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(pa.top_sc + (tok ? n : 0)), sh = *reinterpret_cast<const f32x4*>(pa.top_sh + (tok ? n : 0));
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 y = acc[q][m] * sc + sh;                             // (one v_pk_fma, as in pw_gemm_kernel)
+      y = swish4_(y);
+      {
+        // the pooling adds must NOT contract with swish's final multiply (fma(v, t, shuffled) would skip a rounding that pw_gemm_kernel,
+        // whose activation sits behind a run-time switch, performs): 1-ulp differences in a fifth of the pooled features otherwise
+#pragma clang fp contract(off)
+        y.x += __shfl_xor(y.x, 1); y.y += __shfl_xor(y.y, 1); y.z += __shfl_xor(y.z, 1); y.w += __shfl_xor(y.w, 1);
+        y.x += __shfl_xor(y.x, 2); y.y += __shfl_xor(y.y, 2); y.z += __shfl_xor(y.z, 2); y.w += __shfl_xor(y.w, 2);
+      }
+      const int clip = b0 + m * 4 + (c >> 2);
+      if (tok && (c & 3) == 0 && clip < pa.B) *reinterpret_cast<f32x4*>(pa.gap + (size_t)clip * (16 * pa.top_NT) + n) = y * 0.25f;
+    }
+  }
+}
+
 template <int MT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_chain_kernel(PairChainArgs pa) {
   extern __shared__ __attribute__((aligned(16))) float s_blk[];
@@ -3418,9 +3470,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_pair_chain_kernel(PairChai
     const bool last = (i + 1 == pa.n);
     a.X = pa.X; a.Y = pa.Y; a.B = pa.B;
     const BlockArgs* nxp = last ? tab + i : tab + i + 1;
-    if (((pa.kinds >> i) & 1u) == 0) pair_chain_block<5, MT, NWAVES>(a, nxp, !last, i == 0, i, pa, s_blk, h, pair, xcc_expect, xcc, carry);
-    else pair_chain_block<3, MT, NWAVES>(a, nxp, !last, i == 0, i, pa, s_blk, h, pair, xcc_expect, xcc, carry);
+    // with the top conv fused the last block hands its whole output to BOTH halves as fragments, like an inner block
+    const bool hands_on = !last || pa.top_Wp != nullptr;
+    if (((pa.kinds >> i) & 1u) == 0) pair_chain_block<5, MT, NWAVES>(a, nxp, hands_on, i == 0, i, pa, s_blk, h, pair, xcc_expect, xcc, carry);
+    else pair_chain_block<3, MT, NWAVES>(a, nxp, hands_on, i == 0, i, pa, s_blk, h, pair, xcc_expect, xcc, carry);
   }
+  if (pa.top_Wp != nullptr) pair_top_phase<MT, NWAVES>(pa, s_blk, h, pair);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3962,6 +4017,7 @@ struct mkws_embed {
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   int fuse_chain = 1;              // depth-fused chains: 1 = blocks 4b..6a in ONE launch (mbconv_chain_kernel) and 6b..7a in ONE paired launch (mbconv_pair_chain_kernel); 2 / 3 = only the first / second; 0 = one launch per block
   mkws::BlockArgs* d_chain_tab = nullptr;   // device copy of every block's constants (BlockArgs without X / Y / dbg) for the chain kernels
+  int fuse_top = 1;                // top conv + pool as the last phase of the paired chain (needs fuse_chain 1 / 3 and fuse_gap)
   int fuse_pair = 1;               // stride-1 2x2 blocks on mbconv_pair_kernel: two workgroups share 8 clips and split the channels
   float* pair_xc1 = nullptr; float* pair_xd = nullptr; int* pair_flags = nullptr;   // exchange buffers of the paired kernel
   int* pair_err_dev = nullptr;     // sticky failure word of the paired kernel (device memory)
@@ -4608,7 +4664,7 @@ static bool pair_chain_link_ok(const BlockPlan& b, const BlockPlan& next) {
   if (b.project.NTtot > 2 * kBlockWaves) return false;                   // the residual carry holds two tiles per wave
   return b.spec.stride == 1 && next.spec.in_ch == b.spec.out_ch && next.expand.KC == b.project.NTtot;
 }
-int launch_pair_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const float* X, float* Y, int B) {
+int launch_pair_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const float* X, float* Y, int B, bool with_top) {
   PairChainArgs pa;
   const int n = i1 - i0 + 1, mt = em->pair_mt;
   if (!em->d_chain_tab || n > kPairChainMax) return fail(MKWS_ERR_UNSUPPORTED, "pair chain: no block table / too many blocks");
@@ -4622,6 +4678,14 @@ int launch_pair_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const
     const PairLds L = pair_lds(b.expand.KC, b.ce / 2, mt);
     pa.ldsU = std::max(pa.ldsU, L.U); pa.ldsE = std::max(pa.ldsE, L.E); pa.ldsZ = std::max(pa.ldsZ, L.Z);
     names += (k ? "," : "") + std::string(b.spec.name);
+  }
+  pa.top_Wp = nullptr; pa.top_sc = pa.top_sh = nullptr; pa.top_KC = pa.top_NT = 0; pa.gap = nullptr;
+  if (with_top) {
+    const GemmLayer& T = em->top;
+    if (T.NTtot != 2 * 5 * kBlockWaves || T.KC < 4 || T.KC != em->blocks[i1].project.NTtot) return fail(MKWS_ERR_UNSUPPORTED, "pair chain: top conv shape");
+    pa.top_Wp = T.Wp; pa.top_sc = T.scale; pa.top_sh = T.shift; pa.top_KC = T.KC; pa.top_NT = T.NTtot; pa.gap = em->gap;
+    pa.ldsU = std::max(pa.ldsU, T.KC * mt * 256);
+    names += ",top";
   }
   const size_t lds = ((size_t)pa.ldsU + pa.ldsE + pa.ldsZ) * sizeof(float);
   if (lds > 160 * 1024) return fail(MKWS_ERR_UNSUPPORTED, "pair chain: LDS carve %zu bytes", lds);
@@ -4908,6 +4972,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
   }
   float* cur = em->bufA;
   float* nxt = em->bufB;
+  bool top_done = false;
   for (int i = 0; i < kNumBlocks; ++i) {
     const BlockPlan& b = em->blocks[i];
     const std::string p = std::string("block") + b.spec.name;
@@ -4952,7 +5017,11 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
         while (e + 1 < kNumBlocks && e + 1 - i < kPairChainMax && !(stop && (std::string("block") + em->blocks[e].spec.name) == stop) &&
                pair_chain_member(em, em->blocks[e + 1]) && pair_chain_link_ok(em->blocks[e], em->blocks[e + 1]) && !inner_tap(e + 1)) ++e;
         const BlockPlan& bl = em->blocks[e];
-        if (int rc = launch_pair_chain(s, em, i, e, cur, nxt, B)) return rc;
+        // the top conv (+ BN + swish + global average pool) rides as the chain's last phase when nothing between here and the pooled
+        // features is tapped
+        const bool with_top = em->fuse_top && em->fuse_gap && (!stop || strcmp(stop, "gap") == 0 || strncmp(stop, "dense", 5) == 0) && e == kNumBlocks - 1 && em->topH * em->topW == 4;
+        if (int rc = launch_pair_chain(s, em, i, e, cur, nxt, B, with_top)) return rc;
+        top_done = with_top;
         if (hit(std::string("block") + bl.spec.name, nxt, (size_t)B * bl.Ho * bl.Wo * bl.spec.out_ch)) return MKWS_OK;
         float* t = cur; cur = nxt; nxt = t;
         i = e;
@@ -5009,14 +5078,16 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
   }
   const int HWt = em->topH * em->topW;
   const bool fuse_gap = em->fuse_gap && HWt == 4 && !(stop && strcmp(stop, "top") == 0);
-  if (fuse_gap) {
+  if (top_done) {
+    // (already computed by the paired chain's last phase)
+  } else if (fuse_gap) {
     // top conv + BN + swish + global average pool in one launch: the [B*4, 1280] tensor never reaches HBM
     launch_gemm(s, sw, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->gap, kTopCh, 1);
   } else {
     launch_gemm(s, sw, "top", em->top, cur, em->top.K, B * HWt, em->max_batch * HWt, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, kTopCh);
     if (hit("top", em->bufE, (size_t)B * HWt * kTopCh)) return MKWS_OK;
   }
-  if (!fuse_gap) {
+  if (!fuse_gap && !top_done) {
     const long total = (long)B * (kTopCh / 4);
     ProfScope ps("gap", "mean_hw_kernel");
     hipLaunchKernelGGL(mean_hw_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, em->bufE, em->gap, B, HWt, kTopCh);
@@ -5270,6 +5341,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
   if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
   if (strcmp(name, "fuse_chain") == 0) { em->fuse_chain = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_top") == 0) { em->fuse_top = value; return MKWS_OK; }
   if (strcmp(name, "fuse_cluster") == 0) {
     if (value && !em->cl_flags) return fail(MKWS_ERR_UNSUPPORTED, "fuse_cluster needs a handle of at most 64 clips (max_batch = %d)", em->max_batch);
     em->fuse_cluster = value; return MKWS_OK;
@@ -5302,6 +5374,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_back") == 0) return em->fuse_back;
   if (strcmp(name, "fuse_pair") == 0) return em->fuse_pair;
   if (strcmp(name, "fuse_chain") == 0) return em->fuse_chain;
+  if (strcmp(name, "fuse_top") == 0) return em->fuse_top;
   if (strcmp(name, "fuse_cluster") == 0) return em->fuse_cluster;
   if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
   if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;

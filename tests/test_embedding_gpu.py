@@ -94,6 +94,12 @@ def test_depth_fused_chain_is_bit_identical_to_the_single_block_kernels(ctx):
         got = {b: em.forward(x[:b]).clone() for b in (1024, 1023, 37, 9, 8, 7, 6, 5, 4, 3, 1)}
         taps = {n: em.tap(x[:9], n).clone() for n in ("block4b", "block4c", "block5a", "block5b", "block5c", "block6a", "block5b_dw", "block5c_gate", "block6a_dw",
                                                       "block6b", "block6c", "block6d", "block7a", "block6c_dw", "block7a_gate")}
+        gap = em.tap(x[:9], "gap").clone()                   # pooled features out of the paired chain's fused top-conv phase
+        em.set_option("fuse_top", 0)
+        assert torch.equal(em.tap(x[:9], "gap"), gap)          # (a tap runs the stand-alone top conv anyway; the forwards below compare the fused phase)
+        for b, e in got.items():
+            assert torch.equal(em.forward(x[:b]), e), ("fuse_top", b)
+        em.set_option("fuse_top", 1)
         for mode in (0, 2, 3):             # no chain / only the 4x3-image chain / only the paired 2x2-image chain
             em.set_option("fuse_chain", mode)
             for b, e in got.items():
@@ -110,6 +116,10 @@ def test_depth_fused_chain_is_bit_identical_to_the_single_block_kernels(ctx):
     try:
         got2 = {b: em2.forward(x[:b]).clone() for b in (512, 511, 37, 5, 4, 2, 1)}
         taps2 = {n: em2.tap(x[:9], n).clone() for n in ("block4c", "block5a", "block5c", "block6a", "block6b", "block6d", "block7a")}
+        em2.set_option("fuse_top", 0)
+        for b, e in got2.items():
+            assert torch.equal(em2.forward(x[:b]), e), ("fuse_top", b)
+        em2.set_option("fuse_top", 1)
         for mode in (0, 2, 3):
             em2.set_option("fuse_chain", mode)
             for b, e in got2.items():
