@@ -385,6 +385,19 @@ int mkws_op_pool_hw(const float* d_A, float* d_mean, int B, int HW, int C, void*
 int mkws_op_scale_channels(const float* d_A, const float* d_g, float* d_out, int B, int HW, int C, void* stream);
 /* backward of the excite multiply: dA = dOut * g,  dg[b,c] = sum_hw dOut * A */
 int mkws_op_se_bwd(const float* d_A, const float* d_g, const float* d_dOut, float* d_dA, float* d_dg, int B, int HW, int C, void* stream);
+/* The squeeze-excite branch of one MBConv block (Keras: GlobalAveragePooling2D -> Conv2D(se, swish) -> Conv2D(C, sigmoid) -> multiply) in two
+ * launches, one workgroup per (clip, 128-channel slab):  mean [B,C] = pool(A [B,HW,C]);  Yr [B,se] = mean Wr + br;  R = swish(Yr);
+ * G [B,C] = sigmoid(R We + be);  out = A * G.  Wr [C,se], We [se,C] are the Keras 1x1 kernels.  C % 4 == 0, C <= 1152, se <= 48.
+ * d_work: B * ceil(C / 128) * se floats of scratch (the per-slab partial sums; folded in slab order).  Same results as pool_hw + dense_fwd x 2 +
+ * scale_channels up to summation order. */
+int mkws_op_se_fwd(const float* d_A, const float* d_Wr, const float* d_br, const float* d_We, const float* d_be, float* d_mean, float* d_Yr, float* d_R, float* d_G,
+                   float* d_out, float* d_work, int B, int HW, int C, int se, void* stream);
+/* Its backward in three launches: given dOut = dLoss/d(out):  dA = dOut * G (the multiply's direct path; the squeeze's path comes back as dmean [B,C]
+ * = dLoss/d(mean), which mkws_op_bn_act_bwd_ex spreads over the pixels), and the gradients of the four parameter tensors (written, not accumulated;
+ * batch sums in row order).  dYg [B,C] / dYr [B,se] are outputs too (the pre-activation gradients); d_work as above. */
+int mkws_op_se_bwd_fused(const float* d_A, const float* d_G, const float* d_dOut, const float* d_mean, const float* d_Yr, const float* d_R, const float* d_Wr,
+                         const float* d_We, float* d_dA, float* d_dmean, float* d_dYg, float* d_dYr, float* d_dWr, float* d_dbr, float* d_dWe, float* d_dbe,
+                         float* d_work, int B, int HW, int C, int se, void* stream);
 /* X[b,hw,c] += v[b,c] * scale   (backward of a mean over HW) */
 int mkws_op_add_bcast(float* d_X, const float* d_v, float scale, int B, int HW, int C, void* stream);
 /* A = act(Z + bias);  backward: d_dA <- dA * act'(Z + bias) in place, d_dbias [N] <- its column sums */

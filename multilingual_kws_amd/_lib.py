@@ -100,6 +100,8 @@ SYMBOLS = [
     ("mkws_op_pool_hw", _I, [_P, _P, _I, _I, _I, _P]),
     ("mkws_op_scale_channels", _I, [_P, _P, _P, _I, _I, _I, _P]),
     ("mkws_op_se_bwd", _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    ("mkws_op_se_fwd", _I, [_P] * 11 + [_I, _I, _I, _I, _P]),
+    ("mkws_op_se_bwd_fused", _I, [_P] * 17 + [_I, _I, _I, _I, _P]),
     ("mkws_op_add_bcast", _I, [_P, _P, _F, _I, _I, _I, _P]),
     ("mkws_op_bias_act_fwd", _I, [_P, _P, _I, _P, _I, _I, _P]),
     ("mkws_op_bias_act_bwd", _I, [_P, _P, _I, _P, _P, _I, _I, _P]),

@@ -712,6 +712,215 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ A
     *reinterpret_cast<f32x4*>(dg + (size_t)b * C + 4 * q) = t;
   }
 }
+// ------------------------------------------------------------------------------------------------
+// The squeeze-excite branch of one block in two launches forward and three backward.  The operator-by-operator form above costs 4-5
+// launches forward (pool, two dense layers -- the first split over K with a fold --, excite multiply) and 7 backward per block; at batch
+// 64 every one of them is a few microseconds of work behind ~5 us of launch / drain latency.  Here a workgroup owns (clip, slab of 128
+// channels): it pools / gates / scales its slab of the clip's [HW, C] activation and multiplies it with its slab of the two tiny dense
+// layers (C x se, se <= 48); the sums over C cross slabs through a [B, slabs, se] scratch that the next launch folds in slab order.
+// (One workgroup per clip -- one launch per direction -- was built first: 51 us / 33 us per call, the clip's workgroup walks 2 x 220 KB
+// of weights alone, behind a CU's ~41 GB/s L2 stream.)  All sums keep a fixed order.
+constexpr int kSeMaxC = 1152, kSeMaxSe = 48, kSeSlab = 128;
+__device__ __forceinline__ float wave_sum_fixed(float v) {          // butterfly: the same order on every call
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// forward 1: mean = pool(A) for the slab; Zpart[b, slab, n] = sum_{c in slab} mean[c] Wr[c, n]
+__global__ __launch_bounds__(256) void se_fwd_pool_kernel(const float* __restrict__ A, const float* __restrict__ Wr /*[C,se]*/, float* __restrict__ mean,
+                                                          float* __restrict__ Zpart, int HW, int C, int se) {
+  __shared__ __attribute__((aligned(16))) float s_red[256 * 4];
+  __shared__ __attribute__((aligned(16))) float s_mean[kSeSlab];
+  __shared__ float s_part[16][64];
+  const int tid = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = gridDim.x;
+  const int c0 = slab * kSeSlab, SC = (C - c0 < kSeSlab) ? C - c0 : kSeSlab;
+  const int QS = SC >> 2, PL = 256 / QS;
+  const float* Ab = A + (size_t)b * HW * C + c0;
+  const int q = tid % QS, pl = tid / QS;
+  if (pl < PL) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int p = pl; p < HW; p += PL) s += *reinterpret_cast<const f32x4*>(Ab + (size_t)p * C + 4 * q);
+    *reinterpret_cast<f32x4*>(s_red + (size_t)(pl * QS + q) * 4) = s;
+  }
+  __syncthreads();
+  if (tid < QS) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(s_red + (size_t)tid * 4);
+    for (int l = 1; l < PL; ++l) t += *reinterpret_cast<const f32x4*>(s_red + (size_t)(l * QS + tid) * 4);
+    t = t * (1.0f / (float)HW);
+    *reinterpret_cast<f32x4*>(s_mean + 4 * tid) = t;
+    *reinterpret_cast<f32x4*>(mean + (size_t)b * C + c0 + 4 * tid) = t;
+  }
+  __syncthreads();
+  const int NL = (se <= 16) ? 16 : (se <= 32) ? 32 : 64, KL = 256 / NL;
+  const int n = tid % NL, kl = tid / NL;
+  float v = 0.0f;
+  if (n < se) {
+#pragma unroll 8
+    for (int c = kl; c < SC; c += KL) v += s_mean[c] * Wr[(size_t)(c0 + c) * se + n];
+  }
+  s_part[kl][n] = v;
+  __syncthreads();
+  if (tid < se) {
+    float t = s_part[0][tid];
+    for (int l = 1; l < KL; ++l) t += s_part[l][tid];
+    Zpart[((size_t)b * nslab + slab) * se + tid] = t;
+  }
+}
+// forward 2: Yr = sum_slab Zpart + br; R = swish(Yr); G = sigmoid(R We + be) for the slab; out = A * G
+__global__ __launch_bounds__(256) void se_fwd_gate_kernel(const float* __restrict__ A, const float* __restrict__ Zpart, const float* __restrict__ br,
+                                                          const float* __restrict__ We /*[se,C]*/, const float* __restrict__ be, float* __restrict__ Yr,
+                                                          float* __restrict__ R, float* __restrict__ G, float* __restrict__ out, int HW, int C, int se) {
+  __shared__ float s_R[kSeMaxSe];
+  __shared__ float s_half[2][kSeSlab];
+  __shared__ __attribute__((aligned(16))) float s_G[kSeSlab];
+  const int tid = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = gridDim.x;
+  const int c0 = slab * kSeSlab, SC = (C - c0 < kSeSlab) ? C - c0 : kSeSlab;
+  if (tid < se) {
+    float y = Zpart[(size_t)b * nslab * se + tid];
+    for (int l = 1; l < nslab; ++l) y += Zpart[((size_t)b * nslab + l) * se + tid];
+    y += br[tid];
+    const float r = act_fwd(y, TA_SWISH);
+    s_R[tid] = r;
+    if (slab == 0) { Yr[(size_t)b * se + tid] = y; R[(size_t)b * se + tid] = r; }
+  }
+  __syncthreads();
+  {
+    const int c = tid & (kSeSlab - 1), h = tid >> 7;
+    const int nh = (se + 1) / 2, n0 = h * nh, n1 = (n0 + nh < se) ? n0 + nh : se;
+    float z = 0.0f;
+    if (c < SC) {
+#pragma unroll 8
+      for (int n = n0; n < n1; ++n) z += s_R[n] * We[(size_t)n * C + c0 + c];
+    }
+    s_half[h][c] = z;
+  }
+  __syncthreads();
+  if (tid < SC) {
+    const float g = sigm(be[c0 + tid] + (s_half[0][tid] + s_half[1][tid]));
+    G[(size_t)b * C + c0 + tid] = g;
+    s_G[tid] = g;
+  }
+  __syncthreads();
+  const int QS = SC >> 2;
+  const float* Ab = A + (size_t)b * HW * C + c0;
+  float* ob = out + (size_t)b * HW * C + c0;
+#pragma unroll 4
+  for (int i = tid; i < HW * QS; i += 256) {
+    const int p = i / QS, q = i - p * QS;
+    *reinterpret_cast<f32x4*>(ob + (size_t)p * C + 4 * q) = *reinterpret_cast<const f32x4*>(Ab + (size_t)p * C + 4 * q) * *reinterpret_cast<const f32x4*>(s_G + 4 * q);
+  }
+}
+// backward 1: dA = dOut * G; dG = sum_hw dOut * A; dYg = dG * G (1 - G) for the slab; dRpart[b, slab, n] = sum_{c in slab} dYg[c] We[n, c]
+__global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restrict__ A, const float* __restrict__ G, const float* __restrict__ dOut,
+                                                          const float* __restrict__ We, float* __restrict__ dA, float* __restrict__ dYg,
+                                                          float* __restrict__ dRpart, int HW, int C, int se) {
+  __shared__ __attribute__((aligned(16))) float s_red[256 * 4];
+  __shared__ __attribute__((aligned(16))) float s_g[kSeSlab];
+  const int tid = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = gridDim.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = slab * kSeSlab, SC = (C - c0 < kSeSlab) ? C - c0 : kSeSlab;
+  const int QS = SC >> 2, PL = 256 / QS;
+  const float* Ab = A + (size_t)b * HW * C + c0;
+  const float* Db = dOut + (size_t)b * HW * C + c0;
+  float* dAb = dA + (size_t)b * HW * C + c0;
+  const float* Gb = G + (size_t)b * C + c0;
+  const int q = tid % QS, pl = tid / QS;
+  if (pl < PL) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(Gb + 4 * q);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int p = pl; p < HW; p += PL) {
+      const size_t o = (size_t)p * C + 4 * q;
+      const f32x4 d = *reinterpret_cast<const f32x4*>(Db + o);
+      s += d * *reinterpret_cast<const f32x4*>(Ab + o);
+      *reinterpret_cast<f32x4*>(dAb + o) = d * gv;
+    }
+    *reinterpret_cast<f32x4*>(s_red + (size_t)(pl * QS + q) * 4) = s;
+  }
+  __syncthreads();
+  if (tid < QS) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(s_red + (size_t)tid * 4);
+    for (int l = 1; l < PL; ++l) t += *reinterpret_cast<const f32x4*>(s_red + (size_t)(l * QS + tid) * 4);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(Gb + 4 * tid);
+    t = t * gv * ((f32x4){1.f, 1.f, 1.f, 1.f} - gv);
+    *reinterpret_cast<f32x4*>(s_g + 4 * tid) = t;
+    *reinterpret_cast<f32x4*>(dYg + (size_t)b * C + c0 + 4 * tid) = t;
+  }
+  __syncthreads();
+  const float g0 = (lane < SC) ? s_g[lane] : 0.0f, g1 = (lane + 64 < SC) ? s_g[lane + 64] : 0.0f;
+#pragma unroll 4
+  for (int n = wave; n < se; n += 4) {
+    const float* w = We + (size_t)n * C + c0;
+    float v = ((lane < SC) ? g0 * w[lane] : 0.0f) + ((lane + 64 < SC) ? g1 * w[lane + 64] : 0.0f);
+    v = wave_sum_fixed(v);
+    if (lane == 0) dRpart[((size_t)b * nslab + slab) * se + n] = v;
+  }
+}
+// backward 2: dYr = (sum_slab dRpart) * swish'(Yr); dmean[c] = sum_n dYr[n] Wr[c, n] for the slab
+__global__ __launch_bounds__(128) void se_bwd_squeeze_kernel(const float* __restrict__ dRpart, const float* __restrict__ Yr, const float* __restrict__ Wr,
+                                                             float* __restrict__ dYr, float* __restrict__ dmean, int C, int se) {
+  __shared__ float s_dr[kSeMaxSe];
+  const int tid = threadIdx.x, slab = blockIdx.x, b = blockIdx.y, nslab = gridDim.x;
+  const int c0 = slab * kSeSlab, SC = (C - c0 < kSeSlab) ? C - c0 : kSeSlab;
+  if (tid < se) {
+    float v = dRpart[(size_t)b * nslab * se + tid];
+    for (int l = 1; l < nslab; ++l) v += dRpart[((size_t)b * nslab + l) * se + tid];
+    v *= act_grad(Yr[(size_t)b * se + tid], TA_SWISH);
+    s_dr[tid] = v;
+    if (slab == 0) dYr[(size_t)b * se + tid] = v;
+  }
+  __syncthreads();
+  if (tid < SC) {
+    const float* w = Wr + (size_t)(c0 + tid) * se;
+    float v = 0.0f;
+#pragma unroll 8
+    for (int n = 0; n < se; ++n) v += s_dr[n] * w[n];
+    dmean[(size_t)b * C + c0 + tid] = v;
+  }
+}
+// backward, weights (sums over the batch, row order): dWe = R^T dYg, dbe = colsum(dYg), dWr = mean^T dYr, dbr = colsum(dYr).
+// grid (64-channel slabs, groups of 8 squeezed units); block = 64 channels x 4 unit lanes, two units per thread.
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ mean, const float* __restrict__ R, const float* __restrict__ dYg,
+                                                       const float* __restrict__ dYr, float* __restrict__ dWr, float* __restrict__ dbr, float* __restrict__ dWe,
+                                                       float* __restrict__ dbe, int B, int C, int se) {
+  __shared__ float s_R[64][8], s_d[64][8];
+  const int tid = threadIdx.x, cl = tid & 63, nl = tid >> 6;
+  const int c = blockIdx.x * 64 + cl, n0 = blockIdx.y * 8;
+  const bool okc = c < C;
+  float ae[2] = {0.f, 0.f}, ar[2] = {0.f, 0.f}, sbe = 0.0f, sbr = 0.0f;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int nb = (B - b0 < 64) ? B - b0 : 64;
+    __syncthreads();
+    for (int i = tid; i < 64 * 8; i += 256) {
+      const int r = i >> 3, j = i & 7;
+      const bool ok = r < nb && n0 + j < se;
+      s_R[r][j] = ok ? R[(size_t)(b0 + r) * se + n0 + j] : 0.0f;
+      s_d[r][j] = ok ? dYr[(size_t)(b0 + r) * se + n0 + j] : 0.0f;
+    }
+    __syncthreads();
+    if (okc)
+      for (int r = 0; r < nb; ++r) {
+        const float g = dYg[(size_t)(b0 + r) * C + c], m = mean[(size_t)(b0 + r) * C + c];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          ae[j] += s_R[r][nl * 2 + j] * g;
+          ar[j] += m * s_d[r][nl * 2 + j];
+        }
+        sbe += g;
+      }
+    if (blockIdx.x == 0 && tid < 8)
+      for (int r = 0; r < nb; ++r) sbr += s_d[r][tid];
+  }
+  if (okc) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + nl * 2 + j;
+      if (n < se) { dWe[(size_t)n * C + c] = ae[j]; dWr[(size_t)c * se + n] = ar[j]; }
+    }
+    if (blockIdx.y == 0 && nl == 0) dbe[c] = sbe;
+  }
+  if (blockIdx.x == 0 && tid < 8 && n0 + tid < se) dbr[n0 + tid] = sbr;
+}
 // X[b,hw,c] += v[b,c] * scale   (gradient of a mean over hw; also: broadcast add)
 __global__ __launch_bounds__(256) void add_bcast_kernel(float* __restrict__ X, const float* __restrict__ v, float scale, int B, int HW, int C) {
   const size_t total = (size_t)B * HW * C;
@@ -1110,6 +1319,34 @@ int mkws_op_scale_channels(const float* A, const float* g, float* out, int B, in
 int mkws_op_se_bwd(const float* A, const float* g, const float* dOut, float* dA, float* dg, int B, int HW, int C, void* stream) {
   MKWS_REQ(A && g && dOut && dA && dg && B > 0 && HW > 0 && C % 4 == 0, "se_bwd: bad arguments");
   hipLaunchKernelGGL(se_bwd_kernel, dim3((C / 4 + 63) / 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), A, g, dOut, dA, dg, B, HW, C);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_se_fwd(const float* A, const float* Wr, const float* br, const float* We, const float* be, float* mean, float* Yr, float* R, float* G, float* out,
+                   float* work, int B, int HW, int C, int se, void* stream) {
+  MKWS_REQ(A && Wr && br && We && be && mean && Yr && R && G && out && work, "se_fwd: NULL operand");
+  MKWS_REQ(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= kSeMaxC && se > 0 && se <= kSeMaxSe, "se_fwd: needs C %% 4 == 0, C <= %d, se <= %d (got C = %d, se = %d)",
+           kSeMaxC, kSeMaxSe, C, se);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((C + kSeSlab - 1) / kSeSlab, B);
+  hipLaunchKernelGGL(se_fwd_pool_kernel, grid, dim3(256), 0, s, A, Wr, mean, work, HW, C, se);
+  hipLaunchKernelGGL(se_fwd_gate_kernel, grid, dim3(256), 0, s, A, work, br, We, be, Yr, R, G, out, HW, C, se);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_se_bwd_fused(const float* A, const float* G, const float* dOut, const float* mean, const float* Yr, const float* R, const float* Wr, const float* We,
+                         float* dA, float* dmean, float* dYg, float* dYr, float* dWr, float* dbr, float* dWe, float* dbe, float* work, int B, int HW, int C, int se,
+                         void* stream) {
+  MKWS_REQ(A && G && dOut && mean && Yr && R && Wr && We && dA && dmean && dYg && dYr && dWr && dbr && dWe && dbe && work, "se_bwd_fused: NULL operand");
+  MKWS_REQ(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= kSeMaxC && se > 0 && se <= kSeMaxSe, "se_bwd_fused: needs C %% 4 == 0, C <= %d, se <= %d (got C = %d, se = %d)",
+           kSeMaxC, kSeMaxSe, C, se);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((C + kSeSlab - 1) / kSeSlab, B);
+  hipLaunchKernelGGL(se_bwd_gate_kernel, grid, dim3(256), 0, s, A, G, dOut, We, dA, dYg, work, HW, C, se);
+  hipLaunchKernelGGL(se_bwd_squeeze_kernel, grid, dim3(128), 0, s, work, Yr, Wr, dYr, dmean, C, se);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (se + 7) / 8), dim3(256), 0, s, mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C, se);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

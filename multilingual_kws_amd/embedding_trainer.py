@@ -215,13 +215,13 @@ class EmbeddingTrainer:
             Zd = self.new(Mout, ce)
             _lib.check(self.L.mkws_op_dwconv_fwd(self._p(Ae), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(Zd), B, H, W, ce, k, s, pt, pl, Ho, Wo, self._s()))
             Ad, rec["dw_bn"] = self._bn_fwd(Zd, Mout, ce, p + "_bn", ACT_SWISH)
-            mean = self.new(B, ce)
-            _lib.check(self.L.mkws_op_pool_hw(self._p(Ad), self._p(mean), B, Ho * Wo, ce, self._s()))
-            R, rec["se_reduce"] = self._fc_fwd(mean, B, ce, se, p + "_se_reduce", ACT_SWISH)
-            Gt, rec["se_expand"] = self._fc_fwd(R, B, se, ce, p + "_se_expand", ACT_SIGMOID)
-            As = self.new(Mout, ce)
-            _lib.check(self.L.mkws_op_scale_channels(self._p(Ad), self._p(Gt), self._p(As), B, Ho * Wo, ce, self._s()))
-            rec.update(Ad=Ad, Gt=Gt, As=As)
+            # the squeeze-excite branch (pool, two 1x1 convolutions, excite multiply): two launches, a workgroup per (clip, channel slab)
+            mean, Yr, R, Gt, As = self.new(B, ce), self.new(B, se), self.new(B, se), self.new(B, ce), self.new(Mout, ce)
+            work = self.new(B, (ce + 127) // 128 * se)
+            _lib.check(self.L.mkws_op_se_fwd(self._p(Ad), self._p(self.P(p + "_se_reduce/kernel")), self._p(self.P(p + "_se_reduce/bias")),
+                                             self._p(self.P(p + "_se_expand/kernel")), self._p(self.P(p + "_se_expand/bias")),
+                                             self._p(mean), self._p(Yr), self._p(R), self._p(Gt), self._p(As), self._p(work), B, Ho * Wo, ce, se, self._s()))
+            rec.update(Ad=Ad, Gt=Gt, As=As, se_mean=mean, se_Yr=Yr, se_R=R, se_work=work)
             Zp = self._conv_fwd(As, Mout, ce, cout, p + "_project_conv/kernel")
             rec["residual"] = (s == 1 and cin == cout)
             if rec["residual"]:
@@ -301,10 +301,14 @@ class EmbeddingTrainer:
             else:
                 dZp = self._bn_bwd(rec["project_bn"], d_out)
             dAs = self._conv_bwd(rec["As"], dZp, Mout, ce, cout, p + "_project_conv/kernel")
-            dAd, dG = self.new(Mout, ce), self.new(B, ce)
-            _lib.check(self.L.mkws_op_se_bwd(self._p(rec["Ad"]), self._p(rec["Gt"]), self._p(dAs), self._p(dAd), self._p(dG), B, Ho * Wo, ce, self._s()))
-            dR = self._fc_bwd(rec["se_expand"], dG)
-            dmean = self._fc_bwd(rec["se_reduce"], dR)
+            # squeeze-excite backward: two launches for dAd / dmean / the pre-activation gradients + one for the four parameter gradients
+            dAd, dmean, dYg, dYr = self.new(Mout, ce), self.new(B, ce), self.new(B, ce), self.new(B, se)
+            _lib.check(self.L.mkws_op_se_bwd_fused(self._p(rec["Ad"]), self._p(rec["Gt"]), self._p(dAs), self._p(rec["se_mean"]), self._p(rec["se_Yr"]),
+                                                   self._p(rec["se_R"]), self._p(self.P(p + "_se_reduce/kernel")), self._p(self.P(p + "_se_expand/kernel")),
+                                                   self._p(dAd), self._p(dmean), self._p(dYg), self._p(dYr),
+                                                   self._p(self.G(p + "_se_reduce/kernel")), self._p(self.G(p + "_se_reduce/bias")),
+                                                   self._p(self.G(p + "_se_expand/kernel")), self._p(self.G(p + "_se_expand/bias")),
+                                                   self._p(rec["se_work"]), B, Ho * Wo, ce, se, self._s()))
             dZd = self._bn_bwd(rec["dw_bn"], dAd, bcast=dmean, bscale=1.0 / (Ho * Wo), group=Ho * Wo)     # + the squeeze's gradient, spread over the pixels
             dAe = self.new(Min, ce)
             _lib.check(self.L.mkws_op_dwconv_bwd(self._p(rec["Ae"]), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(dZd), self._p(dAe),

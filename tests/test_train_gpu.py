@@ -283,6 +283,50 @@ def test_stem_se_and_elementwise_operators(ops):
     assert int(step.item()) == 3 and np.abs(P2.cpu().numpy() - P.cpu().numpy()).max() < 1e-7
 
 
+@pytest.mark.parametrize("B,HW,C,se", [(5, 500, 32, 8), (3, 130, 96, 4), (6, 35, 240, 10), (4, 12, 672, 28), (70, 4, 1152, 48)])
+def test_fused_squeeze_excite_forward_backward(ops, B, HW, C, se):
+    """mkws_op_se_fwd / mkws_op_se_bwd_fused (two launches forward, three backward) against float64 autograd of
+    pool -> dense(swish) -> dense(sigmoid) -> multiply; every stored intermediate and all six gradients."""
+    rng = np.random.default_rng(B * 1000 + C)
+    A = rng.standard_normal((B, HW, C)).astype(np.float32)
+    Wr, br = (rng.standard_normal((C, se)) / np.sqrt(C)).astype(np.float32), rng.standard_normal(se).astype(np.float32)
+    We, be = (rng.standard_normal((se, C)) / np.sqrt(se)).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    dO = rng.standard_normal((B, HW, C)).astype(np.float32)
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    a, wr, b_r, we, b_e = t64(A), t64(Wr), t64(br), t64(We), t64(be)
+    mean = a.mean(1)
+    mean.retain_grad()
+    yr = mean @ wr + b_r
+    r = yr * torch.sigmoid(yr)
+    g = torch.sigmoid(r @ we + b_e)
+    out = a * g[:, None]
+    (out * torch.tensor(dO, dtype=torch.float64)).sum().backward()
+    dA_, dWr, dbr, dWe, dbe, ddO = ops.t(A), ops.t(Wr), ops.t(br), ops.t(We), ops.t(be), ops.t(dO)
+    e = lambda *shape: torch.full(shape, float("nan"), device=ops.dev)
+    Mn, Yr, R, G, Out = e(B, C), e(B, se), e(B, se), e(B, C), e(B, HW, C)
+    work = e(B, (C + 127) // 128 * se)
+    ops.check(ops.L.mkws_op_se_fwd(ops.p(dA_), ops.p(dWr), ops.p(dbr), ops.p(dWe), ops.p(dbe), ops.p(Mn), ops.p(Yr), ops.p(R), ops.p(G), ops.p(Out),
+                                   ops.p(work), B, HW, C, se, ops.s()))
+    for got, ref, name in ((Mn, mean, "mean"), (Yr, yr, "Yr"), (R, r, "R"), (G, g, "G"), (Out, out, "out")):
+        assert _rel(got.cpu().numpy(), ref.detach().numpy()) < 2e-6, name
+    gA, gmean, gYg, gYr = e(B, HW, C), e(B, C), e(B, C), e(B, se)
+    gWr, gbr, gWe, gbe = e(C, se), e(se), e(se, C), e(C)
+    ops.check(ops.L.mkws_op_se_bwd_fused(ops.p(dA_), ops.p(G), ops.p(ddO), ops.p(Mn), ops.p(Yr), ops.p(R), ops.p(dWr), ops.p(dWe), ops.p(gA), ops.p(gmean),
+                                         ops.p(gYg), ops.p(gYr), ops.p(gWr), ops.p(gbr), ops.p(gWe), ops.p(gbe), ops.p(work), B, HW, C, se, ops.s()))
+    # dA is the multiply's direct path only; the squeeze's path (dmean / HW on every pixel) is added by the BatchNorm backward that follows
+    direct = dO.astype(np.float64) * g.detach().numpy()[:, None]
+    assert _rel(gA.cpu().numpy(), direct) < 2e-6
+    assert _rel(gmean.cpu().numpy(), mean.grad.numpy()) < 2e-5
+    assert _rel((gA.cpu().numpy().astype(np.float64) + gmean.cpu().numpy()[:, None] / HW), a.grad.numpy()) < 2e-5
+    for got, ref, name in ((gWr, wr.grad, "dWr"), (gbr, b_r.grad, "dbr"), (gWe, we.grad, "dWe"), (gbe, b_e.grad, "dbe")):
+        assert _rel(got.cpu().numpy(), ref.numpy()) < 2e-5, name
+    # fixed-order sums: a second call is bit-identical
+    gWr2, gbr2, gWe2, gbe2, gA2, gm2 = e(C, se), e(se), e(se, C), e(C), e(B, HW, C), e(B, C)
+    ops.check(ops.L.mkws_op_se_bwd_fused(ops.p(dA_), ops.p(G), ops.p(ddO), ops.p(Mn), ops.p(Yr), ops.p(R), ops.p(dWr), ops.p(dWe), ops.p(gA2), ops.p(gm2),
+                                         ops.p(gYg), ops.p(gYr), ops.p(gWr2), ops.p(gbr2), ops.p(gWe2), ops.p(gbe2), ops.p(work), B, HW, C, se, ops.s()))
+    assert torch.equal(gWr2, gWr) and torch.equal(gWe2, gWe) and torch.equal(gbr2, gbr) and torch.equal(gbe2, gbe) and torch.equal(gm2, gmean)
+
+
 def test_training_mode_gradients_match_the_oracle():
     """Every trainable tensor's gradient (d sum(emb . proj)) in training mode (batch statistics, drop-connect) against the
     float64 autograd oracle; tolerance 1e-3 of the tensor's largest gradient."""
