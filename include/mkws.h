@@ -330,6 +330,9 @@ int mkws_op_set_scratch(float* d_scratch, size_t floats);
  * ksplit = 0 picks the split from the shapes and the arena size (small grids with a long K: ~512 workgroups). */
 int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
                  int accumulate, int ksplit, void* stream);
+/* Stream ordering for a trainer that spreads its launches over two streams (weight gradients next to the input-gradient chain): everything queued
+ * on signalling_stream so far happens before whatever is queued on waiting_stream afterwards.  Events belong to the bound context.  Capturable. */
+int mkws_op_stream_wait(void* waiting_stream, void* signalling_stream);
 /* Deferred second stages.  With enable = 1 the fixed-order folds whose results only the optimizer (or a gradient all-reduce) reads -- the
  * split reduction of a weight-gradient GEMM (transA = 1), the bias gradient of mkws_op_bias_act_bwd, the weight gradients of
  * mkws_op_dwconv_bwd / mkws_op_stem_bwd_weight -- are QUEUED (their partial sums stay in the scratch arena, handed out from a bump pointer)
@@ -373,7 +376,7 @@ int mkws_op_bn_update_moving(float* d_moving_mean, float* d_moving_var, const fl
 /* Depthwise k x k conv (k = 3, 5; stride 1, 2) with explicit top / left padding (Keras "same" or correct_pad), raw output. */
 int mkws_op_dwconv_fwd(const float* d_X, const float* d_W, float* d_Z, int B, int H, int W, int C, int k, int stride, int pad_top, int pad_left, int Ho,
                        int Wo, void* stream);
-/* d_dX (may be NULL) <- input gradient, d_dW [k,k,C] <- weight gradient. */
+/* d_dX (may be NULL) <- input gradient, d_dW [k,k,C] (may be NULL; not both) <- weight gradient: two calls may split them over two streams. */
 int mkws_op_dwconv_bwd(const float* d_X, const float* d_W, const float* d_dZ, float* d_dX, float* d_dW, int B, int H, int W, int C, int k, int stride,
                        int pad_top, int pad_left, int Ho, int Wo, void* stream);
 /* Stem: Rescaling(1/255) + Normalization + ZeroPadding2D(((1,1),(0,1))) + Conv2D(32,3,s2,valid) on [B,49,40] -> raw [B,25,20,32]. */
@@ -398,6 +401,10 @@ int mkws_op_se_fwd(const float* d_A, const float* d_Wr, const float* d_br, const
 int mkws_op_se_bwd_fused(const float* d_A, const float* d_G, const float* d_dOut, const float* d_mean, const float* d_Yr, const float* d_R, const float* d_Wr,
                          const float* d_We, float* d_dA, float* d_dmean, float* d_dYg, float* d_dYr, float* d_dWr, float* d_dbr, float* d_dWe, float* d_dbe,
                          float* d_work, int B, int HW, int C, int se, void* stream);
+/* The parameter-gradient launch alone (mkws_op_se_bwd_fused with the four gradient pointers NULL skips it): nothing downstream waits for it, so a
+ * trainer may run it on a second stream next to the input-gradient chain. */
+int mkws_op_se_wgrad(const float* d_mean, const float* d_R, const float* d_dYg, const float* d_dYr, float* d_dWr, float* d_dbr, float* d_dWe, float* d_dbe, int B,
+                     int C, int se, void* stream);
 /* X[b,hw,c] += v[b,c] * scale   (backward of a mean over HW) */
 int mkws_op_add_bcast(float* d_X, const float* d_v, float scale, int B, int HW, int C, void* stream);
 /* A = act(Z + bias);  backward: d_dA <- dA * act'(Z + bias) in place, d_dbias [N] <- its column sums */

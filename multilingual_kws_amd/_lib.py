@@ -79,6 +79,7 @@ SYMBOLS = [
     ("mkws_train_ctx_destroy", None, [_P]),
     ("mkws_train_ctx_bind", _I, [_P]),
     ("mkws_op_set_scratch", _I, [_P, _SZ]),
+    ("mkws_op_stream_wait", _I, [_P, _P]),
     ("mkws_op_fold_defer", _I, [_I, _P]),
     ("mkws_op_fold_flush", _I, [_P]),
     ("mkws_op_bn_train_fwd", _I, [_P, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P]),
@@ -102,6 +103,7 @@ SYMBOLS = [
     ("mkws_op_se_bwd", _I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     ("mkws_op_se_fwd", _I, [_P] * 11 + [_I, _I, _I, _I, _P]),
     ("mkws_op_se_bwd_fused", _I, [_P] * 17 + [_I, _I, _I, _I, _P]),
+    ("mkws_op_se_wgrad", _I, [_P] * 8 + [_I, _I, _I, _P]),
     ("mkws_op_add_bcast", _I, [_P, _P, _F, _I, _I, _I, _P]),
     ("mkws_op_bias_act_fwd", _I, [_P, _P, _I, _P, _I, _I, _P]),
     ("mkws_op_bias_act_bwd", _I, [_P, _P, _I, _P, _P, _I, _I, _P]),

@@ -1050,6 +1050,8 @@ struct mkws_train_ctx {
   int defer = 0;
   mkws::FoldBatch fb;                // fb.n descriptors queued
   int fold_blocks = 0;
+  hipEvent_t ev[8] = {};             // mkws_op_stream_wait: created on first use, used round-robin
+  int evpos = 0;
 };
 namespace {
 thread_local mkws_train_ctx g_default_ctx;
@@ -1108,11 +1110,25 @@ int mkws_train_ctx_create(float* d_scratch, size_t floats, mkws_train_ctx** out)
 void mkws_train_ctx_destroy(mkws_train_ctx* c) {
   if (!c) return;
   if (g_ctx == c) g_ctx = nullptr;                                   // (other threads must not have it bound: like any handle)
+  for (hipEvent_t e : c->ev)
+    if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
 int mkws_train_ctx_bind(mkws_train_ctx* c) {
   g_ctx = c;                                                         // NULL = back to the thread's default context
+  return MKWS_OK;
+}
+
+int mkws_op_stream_wait(void* waiting_stream, void* signalling_stream) {
+  // everything queued on signalling_stream so far happens before whatever is queued on waiting_stream from here on (an event record + a
+  // stream wait; a wait refers to the record that preceded it, so the events are reused round-robin; capturable: fork / join of a hipGraph)
+  mkws_train_ctx& c = ctx();
+  hipEvent_t& e = c.ev[c.evpos];
+  c.evpos = (c.evpos + 1) % 8;
+  if (!e) MKWS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  MKWS_HIP(hipEventRecord(e, static_cast<hipStream_t>(signalling_stream)));
+  MKWS_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(waiting_stream), e, 0));
   return MKWS_OK;
 }
 
@@ -1263,9 +1279,13 @@ int mkws_op_dwconv_fwd(const float* X, const float* W, float* Z, int B, int H, i
 
 int mkws_op_dwconv_bwd(const float* X, const float* W, const float* dZ, float* dX, float* dW, int B, int H, int Wd, int C, int k, int s, int pt, int pl, int Ho,
                        int Wo, void* stream) {
-  MKWS_REQ(X && W && dZ && dW && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_bwd: bad arguments");
+  MKWS_REQ(X && W && dZ && (dW || dX) && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_bwd: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dX) hipLaunchKernelGGL(dw_bwd_input_kernel, dim3(grid_for((size_t)B * H * Wd * (C / 4))), dim3(256), 0, st, dZ, W, dX, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
+  if (!dW) {                                                         // input gradient only (the weight gradient is a second call, possibly on another stream)
+    MKWS_HIP(hipGetLastError());
+    return MKWS_OK;
+  }
   // chunks of output positions: 32 positions each (two per position lane) until the grid has ~512 workgroups, at most 256 chunks
   const int xb = (C / 4 + 15) / 16;
   int chunks = (B * Ho * Wo + 31) / 32;
@@ -1339,14 +1359,25 @@ int mkws_op_se_fwd(const float* A, const float* Wr, const float* br, const float
 int mkws_op_se_bwd_fused(const float* A, const float* G, const float* dOut, const float* mean, const float* Yr, const float* R, const float* Wr, const float* We,
                          float* dA, float* dmean, float* dYg, float* dYr, float* dWr, float* dbr, float* dWe, float* dbe, float* work, int B, int HW, int C, int se,
                          void* stream) {
-  MKWS_REQ(A && G && dOut && mean && Yr && R && Wr && We && dA && dmean && dYg && dYr && dWr && dbr && dWe && dbe && work, "se_bwd_fused: NULL operand");
+  MKWS_REQ(A && G && dOut && mean && Yr && R && Wr && We && dA && dmean && dYg && dYr && work, "se_bwd_fused: NULL operand");
+  MKWS_REQ((dWr && dbr && dWe && dbe) || (!dWr && !dbr && !dWe && !dbe), "se_bwd_fused: the four parameter gradients come together (all or none)");
   MKWS_REQ(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= kSeMaxC && se > 0 && se <= kSeMaxSe, "se_bwd_fused: needs C %% 4 == 0, C <= %d, se <= %d (got C = %d, se = %d)",
            kSeMaxC, kSeMaxSe, C, se);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((C + kSeSlab - 1) / kSeSlab, B);
   hipLaunchKernelGGL(se_bwd_gate_kernel, grid, dim3(256), 0, s, A, G, dOut, We, dA, dYg, work, HW, C, se);
   hipLaunchKernelGGL(se_bwd_squeeze_kernel, grid, dim3(128), 0, s, work, Yr, Wr, dYr, dmean, C, se);
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (se + 7) / 8), dim3(256), 0, s, mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C, se);
+  if (dWr) hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (se + 7) / 8), dim3(256), 0, s, mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C, se);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+int mkws_op_se_wgrad(const float* mean, const float* R, const float* dYg, const float* dYr, float* dWr, float* dbr, float* dWe, float* dbe, int B, int C, int se,
+                     void* stream) {
+  MKWS_REQ(mean && R && dYg && dYr && dWr && dbr && dWe && dbe, "se_wgrad: NULL operand");
+  MKWS_REQ(B > 0 && C > 0 && se > 0 && se <= kSeMaxSe, "se_wgrad: bad dimensions");
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (se + 7) / 8), dim3(256), 0, static_cast<hipStream_t>(stream), mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C,
+                     se);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

@@ -20,6 +20,7 @@ splits long reductions by itself; and `TrainStepGraph` captures forward + loss +
 Adam step index lives on the device), so a step is one replay instead of ~1000 ctypes round trips.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -66,12 +67,24 @@ class EmbeddingTrainer:
         self._ctx = ctypes.c_void_p()
         _lib.check(self.L.mkws_train_ctx_create(self._p(self._scratch), self._scratch.numel(), ctypes.byref(self._ctx)))
         self.d_step = torch.zeros(1, dtype=torch.int32, device=self.device)        # Adam step index for the graph-replayed step
+        # Weight gradients off the critical path: nothing in the backward sweep reads a dW before the optimizer (or the all-reduce), and at
+        # batch 64 the sweep is a chain of small launches that leaves most of the chip idle.  The weight-gradient launches (dW GEMMs,
+        # depthwise / squeeze-excite / stem weight gradients) go to a second stream with its own operator context (scratch arena + fold
+        # queue); the chain of input gradients stays on the caller's stream; the two join before the optimizer.  Capturable (fork / join).
+        self.overlap_wgrad = os.environ.get("MKWS_TRAIN_WGRAD_STREAM", "1") != "0"
+        self.wgrad_fork_every = max(1, int(os.environ.get("MKWS_TRAIN_WGRAD_FORK_EVERY", "1")))      # blocks of the sweep per fork
+        self._side = None
+        self._scratch_side = None
+        self._ctx_side = ctypes.c_void_p()
 
     def __del__(self):
         try:
             if getattr(self, "_ctx", None):
                 self.L.mkws_train_ctx_destroy(self._ctx)
                 self._ctx = None
+            if getattr(self, "_ctx_side", None):
+                self.L.mkws_train_ctx_destroy(self._ctx_side)
+                self._ctx_side = None
         except Exception:
             pass
 
@@ -82,6 +95,61 @@ class EmbeddingTrainer:
     def _bind_stream(self):
         self._stream = _lib.current_stream_ptr()
         _lib.check(self.L.mkws_train_ctx_bind(self._ctx))                                          # a thread-local pointer store
+
+    _STREAM = object()          # placeholder for "the stream this call is issued on" in a queued operator call
+
+    def _wgrad(self, op, *args):
+        """Queue one operator call -- weight-gradient launches only -- for the side stream.  args are evaluated now (pointers of this
+        block's buffers), except _STREAM.  _wgrad_go issues the queue: one fork per block of the sweep (or per `wgrad_fork_every` blocks)
+        instead of one per launch keeps the event traffic small."""
+        if not self.overlap_wgrad:
+            return _lib.check(op(*[self._s() if a is self._STREAM else a for a in args]))
+        self._wgrad_q.append((op, args))
+
+    def _wgrad_go(self, force=True):
+        """Issue the queued weight-gradient launches on the side stream, ordered after everything queued on the caller's stream so far."""
+        if not self._wgrad_q:
+            return
+        self._wgrad_skips += 1
+        if not force and self._wgrad_skips < self.wgrad_fork_every:
+            return
+        self._wgrad_skips = 0
+        q, self._wgrad_q = self._wgrad_q, []
+        self._on_side(lambda: [_lib.check(op(*[self._s() if a is self._STREAM else a for a in args])) for op, args in q])
+
+    def _on_side(self, fn):
+        torch = self.torch
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._scratch_side = torch.empty(16 << 20, dtype=torch.float32, device=self.device)
+            _lib.check(self.L.mkws_train_ctx_create(self._p(self._scratch_side), self._scratch_side.numel(), ctypes.byref(self._ctx_side)))
+            self._side_ptr = ctypes.c_void_p(self._side.cuda_stream)
+        _lib.check(self.L.mkws_op_stream_wait(self._side_ptr, self._stream))       # (a library call, not torch's wait_stream: TrainStepGraph's tape replays it)
+        _lib.check(self.L.mkws_train_ctx_bind(self._ctx_side))
+        if not self._side_open:             # first use in this sweep: a fresh fold queue
+            self._side_open = True
+            _lib.check(self.L.mkws_op_fold_defer(1, self._side_ptr))
+        main, self._stream = self._stream, self._side_ptr
+        try:
+            return fn()
+        finally:
+            self._stream = main
+            _lib.check(self.L.mkws_train_ctx_bind(self._ctx))
+
+    def _join_wgrad(self):
+        """Everything the side stream holds becomes final and visible to the caller's stream."""
+        self._wgrad_go()
+        if not getattr(self, "_side_open", False):
+            return
+        self._side_open = False
+        _lib.check(self.L.mkws_train_ctx_bind(self._ctx_side))
+        _lib.check(self.L.mkws_op_fold_defer(0, self._side_ptr))
+        _lib.check(self.L.mkws_train_ctx_bind(self._ctx))
+        _lib.check(self.L.mkws_op_stream_wait(self._stream, self._side_ptr))
+
+    _side_open = False
+    _wgrad_q = ()
+    _wgrad_skips = 0
 
     @staticmethod
     def _p(t):
@@ -155,7 +223,8 @@ class EmbeddingTrainer:
     def _conv_bwd(self, X, dZ, M, K, N, wname, need_dx=True, add_into=None):
         """dW = X^T dZ (the long reduction over the rows is split by the library), dX = dZ W^T (+ add_into, in place: the shortcut's
         gradient of a residual block joins in the GEMM epilogue instead of a separate launch)."""
-        self.gemm(X, dZ, self.G(wname), K, N, M, K, N, N, ta=1, tb=0, acc=0)     # every weight is used once per step: written, not accumulated
+        # every weight is used once per step: written, not accumulated (ksplit = 0: see gemm())
+        self._wgrad(self.L.mkws_op_gemm, self._p(X), self._p(dZ), self._p(self.G(wname)), K, N, M, K, N, N, 1, 0, 0, 0, self._STREAM)
         if not need_dx:
             return None
         if add_into is not None:
@@ -269,8 +338,13 @@ class EmbeddingTrainer:
             self._backward_sweep(tape, d_emb, allreduce)
             done = True
         finally:
-            if not done:        # an operator raised mid-sweep: do not leave the context deferring (the queue is dropped by the next fold_defer(1))
+            if not done:        # an operator raised mid-sweep: do not leave the contexts deferring (the queues are dropped by the next fold_defer(1))
+                self.L.mkws_train_ctx_bind(self._ctx)
                 self.L.mkws_op_fold_defer(0, self._s())
+                try:
+                    self._join_wgrad()
+                except Exception:
+                    self._side_open = False
 
     def _backward_sweep(self, tape, d_emb, allreduce):
         torch = self.torch
@@ -278,9 +352,18 @@ class EmbeddingTrainer:
         # (no memset of the 52 MB gradient blob: every trainable tensor's gradient is WRITTEN by exactly one operator per step, and the slots
         #  of the non-trainable tensors -- moving statistics, normalisation constants -- are never touched after the zero-initialisation)
         self._pending = []
-        d = d_emb.to(self.device, dtype=torch.float32).contiguous().clone()
+        self._wgrad_q = []
+        # a working copy in a pooled buffer (the sweep overwrites it in place); a library launch, so that the recorded step replays it
+        src = d_emb.to(self.device, dtype=torch.float32).contiguous()
+        d = self.new(B, src.shape[1])
+        ones = self._views.get(("ones", B))
+        if ones is None:
+            ones = self._views[("ones", B)] = torch.ones(B, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.mkws_op_row_scale_add(self._p(src), self._p(ones), None, self._p(d), B, src.shape[1], self._s()))
         d = self._fc_bwd(tape["dense_2"], d)
+        self._wgrad_go()
         d = self._fc_bwd(tape["dense_1"], d)
+        self._wgrad_go()
         if allreduce:      # dense_1 / dense_2 (25 M of the 52 MB) are final: their all-reduce runs under the rest of the sweep
             self._allreduce_range(self.tensors["dense_1/kernel"]["offset"], self.grads.shape[0])
         d = self._fc_bwd(tape["dense"], d)
@@ -288,6 +371,7 @@ class EmbeddingTrainer:
         dAt = self.new(B * HW, 1280)
         dZt = self._bn_bwd(tape["top_bn"], dAt, src=None, bcast=d, bscale=1.0 / HW, group=HW)       # the pooled gradient spread over the pixels on the fly
         d = self._conv_bwd(tape["top_in"], dZt, B * HW, 320, 1280, "top_conv/kernel")
+        self._wgrad_go()
         if allreduce:
             self._allreduce_range(self.tensors["top_conv/kernel"]["offset"], self.tensors["dense_1/kernel"]["offset"])
         for rec in reversed(tape["blocks"]):
@@ -305,14 +389,17 @@ class EmbeddingTrainer:
             dAd, dmean, dYg, dYr = self.new(Mout, ce), self.new(B, ce), self.new(B, ce), self.new(B, se)
             _lib.check(self.L.mkws_op_se_bwd_fused(self._p(rec["Ad"]), self._p(rec["Gt"]), self._p(dAs), self._p(rec["se_mean"]), self._p(rec["se_Yr"]),
                                                    self._p(rec["se_R"]), self._p(self.P(p + "_se_reduce/kernel")), self._p(self.P(p + "_se_expand/kernel")),
-                                                   self._p(dAd), self._p(dmean), self._p(dYg), self._p(dYr),
-                                                   self._p(self.G(p + "_se_reduce/kernel")), self._p(self.G(p + "_se_reduce/bias")),
-                                                   self._p(self.G(p + "_se_expand/kernel")), self._p(self.G(p + "_se_expand/bias")),
+                                                   self._p(dAd), self._p(dmean), self._p(dYg), self._p(dYr), None, None, None, None,
                                                    self._p(rec["se_work"]), B, Ho * Wo, ce, se, self._s()))
+            self._wgrad(self.L.mkws_op_se_wgrad, self._p(rec["se_mean"]), self._p(rec["se_R"]), self._p(dYg), self._p(dYr),
+                        self._p(self.G(p + "_se_reduce/kernel")), self._p(self.G(p + "_se_reduce/bias")),
+                        self._p(self.G(p + "_se_expand/kernel")), self._p(self.G(p + "_se_expand/bias")), B, ce, se, self._STREAM)
             dZd = self._bn_bwd(rec["dw_bn"], dAd, bcast=dmean, bscale=1.0 / (Ho * Wo), group=Ho * Wo)     # + the squeeze's gradient, spread over the pixels
             dAe = self.new(Min, ce)
+            self._wgrad(self.L.mkws_op_dwconv_bwd, self._p(rec["Ae"]), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(dZd), None,
+                        self._p(self.G(p + "_dwconv/depthwise_kernel")), B, H, W, ce, k, s, rec["pt"], rec["pl"], Ho, Wo, self._STREAM)
             _lib.check(self.L.mkws_op_dwconv_bwd(self._p(rec["Ae"]), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(dZd), self._p(dAe),
-                                                 self._p(self.G(p + "_dwconv/depthwise_kernel")), B, H, W, ce, k, s, rec["pt"], rec["pl"], Ho, Wo, self._s()))
+                                                 None, B, H, W, ce, k, s, rec["pt"], rec["pl"], Ho, Wo, self._s()))
             if "expand_bn" in rec:
                 dZe = self._bn_bwd(rec["expand_bn"], dAe)
                 d_in = self._conv_bwd(rec["inp"], dZe, Min, cin, ce, p + "_expand_conv/kernel", add_into=d_out if rec["residual"] else None)
@@ -321,9 +408,12 @@ class EmbeddingTrainer:
                 if rec["residual"]:
                     _lib.check(self.L.mkws_op_axpy(self._p(d_in), self._p(d_out), 1.0, d_in.numel(), self._s()))
             d = d_in
+            self._wgrad_go(force=False)
         dZ0 = self._bn_bwd(tape["stem_bn"], d)
-        _lib.check(self.L.mkws_op_stem_bwd_weight(self._p(tape["spec"]), self._p(dZ0), self.norm_mean, self.norm_std, self._p(self.G("stem_conv/kernel")), B, self._s()))
+        self._wgrad(self.L.mkws_op_stem_bwd_weight, self._p(tape["spec"]), self._p(dZ0), self.norm_mean, self.norm_std, self._p(self.G("stem_conv/kernel")), B,
+                    self._STREAM)
         _lib.check(self.L.mkws_op_fold_defer(0, self._s()))           # flush: every gradient is final from here on
+        self._join_wgrad()
         if allreduce:
             self._allreduce_range(0, self.tensors["top_conv/kernel"]["offset"])
             for h in self._pending:
@@ -333,7 +423,13 @@ class EmbeddingTrainer:
 
     def _allreduce_range(self, lo, hi):
         import torch.distributed as dist
-        _lib.check(self.L.mkws_op_fold_flush(self._s()))               # the range's gradients must be final before the collective reads them
+        self._wgrad_go()
+        if getattr(self, "_side_open", False):                         # the range's gradients must be final before the collective reads them
+            _lib.check(self.L.mkws_train_ctx_bind(self._ctx_side))
+            _lib.check(self.L.mkws_op_fold_flush(self._side_ptr))
+            _lib.check(self.L.mkws_train_ctx_bind(self._ctx))
+            _lib.check(self.L.mkws_op_stream_wait(self._stream, self._side_ptr))
+        _lib.check(self.L.mkws_op_fold_flush(self._s()))
         if dist.is_available() and dist.is_initialized():
             self._pending.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
@@ -360,51 +456,110 @@ def drop_connect_rates():
     return {name: DROP_CONNECT_RATE * bi / len(BLOCKS) for bi, (name, cin, cout, k, st, e) in enumerate(BLOCKS) if st == 1 and cin == cout}
 
 
+class _CallTape:
+    """Stand-in for the ctypes library object that logs every entry-point call (function, converted arguments) while passing it through."""
+
+    def __init__(self, lib, log):
+        self._lib, self._log = lib, log
+
+    def __getattr__(self, name):
+        f = getattr(self._lib, name)
+        log = self._log
+
+        def call(*args):
+            log.append((f, args))
+            return f(*args)
+        return call
+
+
 class TrainStepGraph:
     """One optimizer step of the `backprop_into_embedding=True` phase -- training-mode forward, head loss / gradient, backward through
-    the whole embedding, Keras Adam on the head and on the embedding -- captured ONCE in a hipGraph and replayed per step.
+    the whole embedding, Keras Adam on the head and on the embedding -- recorded ONCE and replayed per step.
 
     Everything a step consumes sits in static device buffers the caller refills (spectrograms, labels, the per-block drop-connect
-    scales); the Adam step index is a device counter (mkws_op_step_inc / *_adam*_dev), so the captured launches are valid for every
-    step.  Single process only: the data-parallel phase keeps the launch-by-launch path (its gradient all-reduce is host-driven)."""
+    scales); the Adam step index is a device counter (mkws_op_step_inc / *_adam*_dev), so the recorded launches are valid for every
+    step.  Three ways to run the step (`mode`):
+      "tape" (default)  the step's C-ABI calls (~560, with their converted arguments) are logged once and re-issued from a tight loop:
+                        no tensor bookkeeping, no argument conversion -- and the weight gradients keep their own stream (round 4: a
+                        hipGraph with the fork / join edges of that second stream replays SLOWER than the launch-by-launch step,
+                        4.6-4.8 ms against 3.9-4.1 ms at batch 64; profiles/r04_notes.md);
+      "hipgraph"        one hipGraph replay per step, single stream (use_graph=True);
+      "eager"           the plain host-driven step (use_graph=False).
+    All three issue the same launches with the same fixed-order sums: bit-identical parameters.
+    Single process only: the data-parallel phase keeps the launch-by-launch path (its gradient all-reduce is host-driven)."""
 
-    def __init__(self, trainer, head, batch, lr, use_graph=True):
+    def __init__(self, trainer, head, batch, lr, use_graph=None, mode=None):
         import torch
         self.tr, self.head, self.B, self.lr = trainer, head, int(batch), float(lr)
+        if mode is None:
+            mode = "tape" if use_graph is None else ("hipgraph" if use_graph else "eager")
+        if mode not in ("tape", "hipgraph", "eager"):
+            raise ValueError(f"mode {mode!r}: 'tape', 'hipgraph' or 'eager'")
+        self.mode = mode
         dev = trainer.device
         self.spec = torch.zeros((self.B, 49, 40), dtype=torch.float32, device=dev)
         self.labels = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.rates = drop_connect_rates()
         self.scales = {n: torch.ones(self.B, dtype=torch.float32, device=dev) for n in self.rates}
-        self.graph, self.stats = None, None
-        if use_graph:
-            # warm-up on a side stream: fills the trainer's buffer pool for this batch size and every lazily created view, on state
-            # that is restored afterwards (parameters, moving statistics, Adam moments, step counters)
-            snap = [t.clone() for t in (trainer.params, trainer.m, trainer.v, trainer.d_step)]
-            hstate, hstep = head.state_view().clone(), head.step_t          # parameters AND Adam moments of the head (set_params would zero m / v)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                self._body()
-            torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph, self.stats, self._tape, self._keep = None, None, None, []
+        if mode == "eager":
+            return
+        # warm-up: fills the trainer's buffer pool for this batch size and every lazily created view, on state that is restored
+        # afterwards (parameters, moving statistics, Adam moments, step counters)
+        snap = [t.clone() for t in (trainer.params, trainer.m, trainer.v, trainer.d_step)]
+        hstate, hstep = head.state_view().clone(), head.step_t          # parameters AND Adam moments of the head (set_params would zero m / v)
+
+        def restore():
             torch.cuda.synchronize(dev)
             for t, c in zip((trainer.params, trainer.m, trainer.v, trainer.d_step), snap):
                 t.copy_(c)
             head.state_view().copy_(hstate)
             head.step_t = hstep
+        if mode == "hipgraph":
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._body(overlap=False)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            restore()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.stats = self._body()
+                self.stats = self._body(overlap=False)
             self.graph = g
+            return
+        self._body()
+        self._record()
+        restore()
 
-    def _body(self):
+    def _record(self):
+        """Log one step's library calls on the current stream (the pool buffers, views and streams they name stay put from here on)."""
         tr, head = self.tr, self.head
-        emb = tr.forward_train(self.spec, keep_scales=self.scales)
-        stats = head.loss_grad(emb, self.labels)
-        tr.backward(head.input_grad(self.B))
-        _lib.check(tr.L.mkws_op_step_inc(tr._p(tr.d_step), _lib.current_stream_ptr()))
-        head.adam_step_dev(self.lr, tr.d_step)
-        tr.adam_step_dev(self.lr)
+        log = []
+        lib_t, lib_h = tr.L, head.L
+        tr.L, head.L = _CallTape(lib_t, log), _CallTape(lib_h, log)
+        try:
+            self.stats = self._body()
+        finally:
+            tr.L, head.L = lib_t, lib_h
+        self._tape = log
+        self._tape_stream = _lib.current_stream_ptr().value
+
+    def _body(self, overlap=None):
+        tr, head = self.tr, self.head
+        saved = tr.overlap_wgrad
+        if overlap is not None:
+            tr.overlap_wgrad = bool(overlap) and saved
+        try:
+            emb = tr.forward_train(self.spec, keep_scales=self.scales)
+            stats = head.loss_grad(emb, self.labels)
+            d_emb = head.input_grad(self.B)
+            self._keep = [emb, d_emb]           # the recorded step names these buffers
+            tr.backward(d_emb)
+            _lib.check(tr.L.mkws_op_step_inc(tr._p(tr.d_step), _lib.current_stream_ptr()))
+            head.adam_step_dev(self.lr, tr.d_step)
+            tr.adam_step_dev(self.lr)
+        finally:
+            tr.overlap_wgrad = saved
         return stats
 
     def run(self, spec, labels, drop_masks=None):
@@ -423,5 +578,14 @@ class TrainStepGraph:
                 self.scales[n].fill_(1.0)
         if self.graph is not None:
             self.graph.replay()
+            return self.stats
+        if self._tape is not None:
+            if _lib.current_stream_ptr().value != self._tape_stream:      # the caller moved to another stream: the tape names the old one
+                self._record()                                            # (recording runs the step: this one is done)
+                return self.stats
+            for f, a in self._tape:
+                rc = f(*a)
+                if rc is not None and rc < 0:
+                    _lib.check(rc)
             return self.stats
         return self._body()

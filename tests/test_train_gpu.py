@@ -473,9 +473,10 @@ def test_bucketed_gradient_allreduce_over_rccl():
 
 
 def test_graph_replayed_training_step_equals_the_eager_step():
-    """TrainStepGraph: forward + head loss + backward + both Adam updates of one `backprop_into_embedding` step as ONE hipGraph
-    replay.  (a) Three replays with fresh inputs and drop-connect masks leave EXACTLY what the same launches issued one by one
-    leave (use_graph=False: same kernels, same buffers, device-side step counter) -- every reduction has a fixed order.  (b) Against
+    """TrainStepGraph: forward + head loss + backward + both Adam updates of one `backprop_into_embedding` step recorded once and
+    replayed (the call tape by default, one hipGraph on request).  (a) Three replays with fresh inputs and drop-connect masks leave
+    EXACTLY what the same launches issued one by one leave (use_graph=False: same kernels, same buffers, device-side step counter;
+    one stream or two) -- every reduction has a fixed order.  (b) Against
     the host-driven eager step (EmbeddingTrainer / Head methods with host step counters) after ONE step: host pow vs device pow in lr_t
     differ in the last bit, and Adam turns a last-bit difference of a noise-level gradient (betas in front of a batch-statistics BN
     have an exactly-zero true gradient) into a full +-lr step, so a handful of parameters may sit lr apart; everything else agrees to
@@ -496,7 +497,7 @@ def test_graph_replayed_training_step_equals_the_eager_step():
     stats_l = [step_l.run(x, y, mk).clone() for x, y, mk in zip(specs, labels, masks)]
     tr_g, hd_g = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
     step = TrainStepGraph(tr_g, hd_g, B, lr)
-    assert step.graph is not None and step_l.graph is None
+    assert step._tape and step.graph is None and step_l.graph is None and step_l._tape is None        # default: the recorded call tape
     assert np.array_equal(tr_g.blob(), blob) and int(tr_g.d_step.item()) == 0           # the capture warm-up left no trace
     for i, (x, y, mk) in enumerate(zip(specs, labels, masks)):
         assert torch.equal(step.run(x, y, mk), stats_l[i]), i
@@ -523,6 +524,20 @@ def test_graph_replayed_training_step_equals_the_eager_step():
     for x, y, mk in zip(specs, labels, masks):
         step2.run(x, y, mk)
     assert np.array_equal(tr_h.blob(), pg) and np.array_equal(hd_h.get_params(), hd_g.get_params())
+    # the default is the recorded call tape (two streams); the single-stream hipGraph form of the step walks the same trajectory bit for bit
+    tr_c, hd_c = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    step3 = TrainStepGraph(tr_c, hd_c, B, lr, use_graph=True)
+    assert step2.mode == "tape" and step3.mode == "hipgraph" and step_l.mode == "eager"
+    for x, y, mk in zip(specs, labels, masks):
+        step3.run(x, y, mk)
+    assert np.array_equal(tr_c.blob(), pg) and np.array_equal(hd_c.get_params(), hd_g.get_params())
+    # and so does a trainer that keeps its weight gradients on the caller's stream
+    tr_s, hd_s = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+    tr_s.overlap_wgrad = False
+    step4 = TrainStepGraph(tr_s, hd_s, B, lr, use_graph=False)
+    for x, y, mk in zip(specs, labels, masks):
+        step4.run(x, y, mk)
+    assert np.array_equal(tr_s.blob(), pg) and np.array_equal(hd_s.get_params(), hd_g.get_params())
 
 
 def test_two_trainers_interleaved_on_one_thread_do_not_share_operator_state():

@@ -41,13 +41,14 @@ for B in (int(a) for a in (sys.argv[1:] or ["64", "512"])):
     print(f"B={B}: launch by launch {dt * 1e3:.2f} ms/step = {B / dt:.0f} clips/s (training-mode forward alone {df * 1e3:.2f} ms); loss {hd.loss_grad(tr.forward_train(spec), labels).tolist()[0] / B:.4f}")
     if os.environ.get("MKWS_TRAIN_BENCH_NO_GRAPH"):
         continue
-    g = TrainStepGraph(tr, hd, B, 1e-4)
-    for _ in range(3):
-        g.run(spec, labels)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        g.run(spec, labels)
-    torch.cuda.synchronize()
-    dg = (time.perf_counter() - t0) / n
-    print(f"B={B}: one hipGraph replay per step {dg * 1e3:.2f} ms/step = {B / dg:.0f} clips/s; loss {g.stats.tolist()[0] / B:.4f}", flush=True)
+    for mode, what in (("tape", "recorded call tape, two streams"), ("hipgraph", "one hipGraph replay per step, one stream")):
+        g = TrainStepGraph(tr, hd, B, 1e-4, mode=mode)
+        for _ in range(3):
+            g.run(spec, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g.run(spec, labels)
+        torch.cuda.synchronize()
+        dg = (time.perf_counter() - t0) / n
+        print(f"B={B}: {what} {dg * 1e3:.2f} ms/step = {B / dg:.0f} clips/s ({len(g._tape) if g._tape else 0} library calls); loss {g.stats.tolist()[0] / B:.4f}", flush=True)
