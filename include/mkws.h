@@ -335,7 +335,7 @@ int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, i
 int mkws_op_stream_wait(void* waiting_stream, void* signalling_stream);
 /* Deferred second stages.  With enable = 1 the fixed-order folds whose results only the optimizer (or a gradient all-reduce) reads -- the
  * split reduction of a weight-gradient GEMM (transA = 1), the bias gradient of mkws_op_bias_act_bwd, the weight gradients of
- * mkws_op_dwconv_bwd / mkws_op_stem_bwd_weight -- are QUEUED (their partial sums stay in the scratch arena, handed out from a bump pointer)
+ * mkws_op_dwconv_bwd / mkws_op_stem_bwd_weight / mkws_op_se_wgrad (batches above 64 rows) -- are QUEUED (their partial sums stay in the scratch arena, handed out from a bump pointer)
  * and run as ONE launch at mkws_op_fold_flush, at enable = 0, or when the queue (24 entries) or the arena is full.  Same sums in the same
  * order: bit-identical results, ~90 launches fewer per training step.  Until the flush those outputs are not final.  Per host thread, like
  * the scratch arena; capturable. */
@@ -402,7 +402,8 @@ int mkws_op_se_bwd_fused(const float* d_A, const float* d_G, const float* d_dOut
                          const float* d_We, float* d_dA, float* d_dmean, float* d_dYg, float* d_dYr, float* d_dWr, float* d_dbr, float* d_dWe, float* d_dbe,
                          float* d_work, int B, int HW, int C, int se, void* stream);
 /* The parameter-gradient launch alone (mkws_op_se_bwd_fused with the four gradient pointers NULL skips it): nothing downstream waits for it, so a
- * trainer may run it on a second stream next to the input-gradient chain. */
+ * trainer may run it on a second stream next to the input-gradient chain.  Batches above 64 rows are summed in chunks of 64 rows whose partial
+ * sums (context scratch arena) are folded in chunk order -- deferrable like the other weight-gradient folds (mkws_op_fold_defer). */
 int mkws_op_se_wgrad(const float* d_mean, const float* d_R, const float* d_dYg, const float* d_dYr, float* d_dWr, float* d_dbr, float* d_dWe, float* d_dbe, int B,
                      int C, int se, void* stream);
 /* X[b,hw,c] += v[b,c] * scale   (backward of a mean over HW) */

@@ -24,7 +24,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 enum TrainAct { TA_NONE = 0, TA_SWISH = 1, TA_RELU = 2, TA_SELU = 3, TA_SIGMOID = 4 };
 constexpr float kSeluScale = 1.0507009873554805f, kSeluAlpha = 1.6732632423543772f;
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1 / (1 + 2^(-x log2 e)) on the hardware exp2 / reciprocal (1 ulp each), the formulation of the inference kernels (mkws_embed.hip sigmoidf_).
+// Round 4: with expf() and an IEEE division the BatchNorm launches of a 512-clip step were bound by this function, not by memory.
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float act_fwd(float y, int act) {
   switch (act) {
     case TA_SWISH: return y * sigm(y);
@@ -882,14 +884,18 @@ __global__ __launch_bounds__(128) void se_bwd_squeeze_kernel(const float* __rest
 // grid (64-channel slabs, groups of 8 squeezed units); block = 64 channels x 4 unit lanes, two units per thread.
 __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ mean, const float* __restrict__ R, const float* __restrict__ dYg,
                                                        const float* __restrict__ dYr, float* __restrict__ dWr, float* __restrict__ dbr, float* __restrict__ dWe,
-                                                       float* __restrict__ dbe, int B, int C, int se) {
+                                                       float* __restrict__ dbe, int B, int C, int se, int rows_per_chunk) {
+  // blockIdx.z = chunk of batch rows.  One chunk: the outputs are the gradients themselves; several: every output pointer is the base of a
+  // [chunks][n] array of partial sums that a fixed-order fold adds up (host: se_wgrad_launch).
   __shared__ float s_R[64][8], s_d[64][8];
   const int tid = threadIdx.x, cl = tid & 63, nl = tid >> 6;
   const int c = blockIdx.x * 64 + cl, n0 = blockIdx.y * 8;
   const bool okc = c < C;
+  const int rb = blockIdx.z * rows_per_chunk, re = (rb + rows_per_chunk < B) ? rb + rows_per_chunk : B;
+  dWe += (size_t)blockIdx.z * se * C; dWr += (size_t)blockIdx.z * se * C; dbe += (size_t)blockIdx.z * C; dbr += (size_t)blockIdx.z * se;
   float ae[2] = {0.f, 0.f}, ar[2] = {0.f, 0.f}, sbe = 0.0f, sbr = 0.0f;
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    const int nb = (B - b0 < 64) ? B - b0 : 64;
+  for (int b0 = rb; b0 < re; b0 += 64) {
+    const int nb = (re - b0 < 64) ? re - b0 : 64;
     __syncthreads();
     for (int i = tid; i < 64 * 8; i += 256) {
       const int r = i >> 3, j = i & 7;
@@ -898,7 +904,8 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
       s_d[r][j] = ok ? dYr[(size_t)(b0 + r) * se + n0 + j] : 0.0f;
     }
     __syncthreads();
-    if (okc)
+    if (okc) {
+#pragma unroll 8      // eight rows' loads in flight (the adds keep their order)
       for (int r = 0; r < nb; ++r) {
         const float g = dYg[(size_t)(b0 + r) * C + c], m = mean[(size_t)(b0 + r) * C + c];
 #pragma unroll
@@ -908,6 +915,7 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
         }
         sbe += g;
       }
+    }
     if (blockIdx.x == 0 && tid < 8)
       for (int r = 0; r < nb; ++r) sbr += s_d[r][tid];
   }
@@ -1343,6 +1351,31 @@ int mkws_op_se_bwd(const float* A, const float* g, const float* dOut, float* dA,
   return MKWS_OK;
 }
 
+// the squeeze-excite parameter gradients: batch rows in chunks of 64 over blockIdx.z; with more than one chunk the kernel writes partial
+// sums to the scratch arena and four fixed-order folds (deferred with the others when deferral is on) produce the gradients
+static int se_wgrad_launch(const float* mean, const float* R, const float* dYg, const float* dYr, float* dWr, float* dbr, float* dWe, float* dbe, int B, int C, int se,
+                           hipStream_t s) {
+  const int chunks = (B + 63) / 64;
+  const dim3 grid((C + 63) / 64, (se + 7) / 8, chunks);
+  if (chunks == 1) {
+    hipLaunchKernelGGL(se_wgrad_kernel, grid, dim3(256), 0, s, mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C, se, 64);
+    return MKWS_OK;
+  }
+  auto r64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  const size_t nW = (size_t)se * C, sW = r64(chunks * nW), sbe = r64((size_t)chunks * C), sbr = r64((size_t)chunks * se);
+  mkws_train_ctx& c = ctx();
+  if (c.defer && c.fb.n + 4 > kMaxFolds) fold_flush(s);              // all four folds join the queue together (or none)
+  float* base = scratch_at(2 * sW + sbe + sbr, s);
+  MKWS_REQ(base, "se_wgrad: needs %zu floats of scratch (mkws_op_set_scratch)", 2 * sW + sbe + sbr);
+  float* pWr = base; float* pWe = pWr + sW; float* pbe = pWe + sW; float* pbr = pbe + sbe;
+  hipLaunchKernelGGL(se_wgrad_kernel, grid, dim3(256), 0, s, mean, R, dYg, dYr, pWr, pbr, pWe, pbe, B, C, se, 64);
+  struct { float* part; float* out; int n; } f[4] = {{pWr, dWr, (int)nW}, {pWe, dWe, (int)nW}, {pbe, dbe, C}, {pbr, dbr, se}};
+  for (auto& d : f)
+    if (!fold_defer(d.part, d.out, chunks, d.n, d.n, d.n, 1.0f, 0, s))
+      hipLaunchKernelGGL(fold_partials_kernel, dim3((d.n + 255) / 256), dim3(256), 0, s, d.part, chunks, d.n, d.out, 1.0f, 0);
+  return MKWS_OK;
+}
+
 int mkws_op_se_fwd(const float* A, const float* Wr, const float* br, const float* We, const float* be, float* mean, float* Yr, float* R, float* G, float* out,
                    float* work, int B, int HW, int C, int se, void* stream) {
   MKWS_REQ(A && Wr && br && We && be && mean && Yr && R && G && out && work, "se_fwd: NULL operand");
@@ -1367,7 +1400,8 @@ int mkws_op_se_bwd_fused(const float* A, const float* G, const float* dOut, cons
   const dim3 grid((C + kSeSlab - 1) / kSeSlab, B);
   hipLaunchKernelGGL(se_bwd_gate_kernel, grid, dim3(256), 0, s, A, G, dOut, We, dA, dYg, work, HW, C, se);
   hipLaunchKernelGGL(se_bwd_squeeze_kernel, grid, dim3(128), 0, s, work, Yr, Wr, dYr, dmean, C, se);
-  if (dWr) hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (se + 7) / 8), dim3(256), 0, s, mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C, se);
+  if (dWr)
+    if (int rc = se_wgrad_launch(mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C, se, s)) return rc;
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -1376,8 +1410,7 @@ int mkws_op_se_wgrad(const float* mean, const float* R, const float* dYg, const 
                      void* stream) {
   MKWS_REQ(mean && R && dYg && dYr && dWr && dbr && dWe && dbe, "se_wgrad: NULL operand");
   MKWS_REQ(B > 0 && C > 0 && se > 0 && se <= kSeMaxSe, "se_wgrad: bad dimensions");
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (se + 7) / 8), dim3(256), 0, static_cast<hipStream_t>(stream), mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C,
-                     se);
+  if (int rc = se_wgrad_launch(mean, R, dYg, dYr, dWr, dbr, dWe, dbe, B, C, se, static_cast<hipStream_t>(stream))) return rc;
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
