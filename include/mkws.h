@@ -373,6 +373,18 @@ int mkws_op_bn_act_bwd_ex(const float* d_Z, const float* d_mean, const float* d_
                           float* d_dbeta, int M, int C, void* stream);
 /* moving = momentum * moving + (1 - momentum) * batch; the variance enters Bessel-corrected (M/(M-1)) as in Keras' fused BN. */
 int mkws_op_bn_update_moving(float* d_moving_mean, float* d_moving_var, const float* d_mean, const float* d_var, float momentum, int M, int C, void* stream);
+/* 1x1 convolution Z [M,N] = X [M,K] W [K,N] followed by training-mode BatchNorm (+ activation, + residual branch) -- mkws_op_gemm +
+ * mkws_op_bn_train_fwd_res as ONE operator, so that the GEMM's epilogue can leave the BatchNorm's chunk statistics (one chunk per 64-row tile)
+ * when it is unsplit and has at most 160 row tiles: two launches instead of three and one pass less over Z.  Same arguments and results
+ * (statistics up to summation order) as the two calls; Z keeps the raw convolution output for the backward pass. */
+int mkws_op_conv_bn_fwd(const float* d_X, const float* d_W, float* d_Z, int M, int N, int K, const float* d_gamma, const float* d_beta, float eps, int act,
+                        float momentum, float* d_moving_mean, float* d_moving_var, float* d_mean, float* d_var, float* d_A, const float* d_res,
+                        const float* d_row_scale, int group, void* stream);
+/* The same for the depthwise convolution (mkws_op_dwconv_fwd + mkws_op_bn_train_fwd): up to 256 chunks of 128 output rows the convolution launch
+ * leaves the chunk statistics itself. */
+int mkws_op_dwconv_bn_fwd(const float* d_X, const float* d_W, float* d_Z, int B, int H, int W, int C, int k, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                          const float* d_gamma, const float* d_beta, float eps, int act, float momentum, float* d_moving_mean, float* d_moving_var, float* d_mean,
+                          float* d_var, float* d_A, void* stream);
 /* Depthwise k x k conv (k = 3, 5; stride 1, 2) with explicit top / left padding (Keras "same" or correct_pad), raw output. */
 int mkws_op_dwconv_fwd(const float* d_X, const float* d_W, float* d_Z, int B, int H, int W, int C, int k, int stride, int pad_top, int pad_left, int Ho,
                        int Wo, void* stream);

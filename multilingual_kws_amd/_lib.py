@@ -95,6 +95,8 @@ SYMBOLS = [
     ("mkws_op_bn_act_bwd_ex", _I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _P]),
     ("mkws_op_bn_update_moving", _I, [_P, _P, _P, _P, _F, _I, _I, _P]),
     ("mkws_op_dwconv_fwd", _I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    ("mkws_op_conv_bn_fwd", _I, [_P, _P, _P, _I, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    ("mkws_op_dwconv_bn_fwd", _I, [_P, _P, _P] + [_I] * 10 + [_P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P]),
     ("mkws_op_dwconv_bwd", _I, [_P, _P, _P, _P, _P] + [_I] * 10 + [_P]),
     ("mkws_op_stem_fwd", _I, [_P, _P, _F, _F, _P, _I, _P]),
     ("mkws_op_stem_bwd_weight", _I, [_P, _P, _F, _F, _P, _I, _P]),

@@ -55,7 +55,7 @@ __device__ __forceinline__ float act_grad(float y, int act) {
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
                                                          int K, int lda, int ldb, int ldc, int accumulate, int ksplit, float* __restrict__ part,
-                                                         const float* __restrict__ bias, int act, float* __restrict__ Act) {
+                                                         const float* __restrict__ bias, int act, float* __restrict__ Act, float* __restrict__ stats) {
   // Two LDS stages; the next K step's operands travel global -> registers while the current step's MFMAs run (round 2 loaded,
   // synchronised and multiplied one K step at a time: a full memory latency per 16 columns of K, 44-61 us per call at batch 64).
   __shared__ float As[2][64][17];
@@ -119,6 +119,52 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
     if (more) stash(st ^ 1);
     __syncthreads();
     st ^= 1;
+  }
+  if (stats) {
+    // BatchNorm chunk statistics of this 64-row tile in the epilogue (unsplit GEMMs in front of a training-mode BN: the separate statistics
+    // launch and its pass over Z go away): per column the mean of the tile's valid rows and the sum of squared deviations from it, two
+    // passes over the accumulators.  Order: rows of a lane, the four lane groups by butterfly, the two row halves (waves) in order.
+    __shared__ float s_cs[2][64], s_cq[2][64];
+    const int nrows = (M - m0 < 64) ? M - m0 : 64;
+    float mu[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (wm * 32 + i * 16 + 4 * (lane >> 4) + r < nrows) t += acc[i][j][r];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      if ((lane >> 4) == 0) s_cs[wm][wn * 32 + j * 16 + (lane & 15)] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn * 32 + j * 16 + (lane & 15);
+      mu[j] = (s_cs[0][col] + s_cs[1][col]) / (float)nrows;
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (wm * 32 + i * 16 + 4 * (lane >> 4) + r < nrows) { const float d = acc[i][j][r] - mu[j]; q += d * d; }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if ((lane >> 4) == 0) s_cq[wm][col] = q;
+    }
+    __syncthreads();
+    if (wm == 0 && (lane >> 4) == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn * 32 + j * 16 + (lane & 15), n = n0 + col;
+        if (n < N) {
+          stats[((size_t)blockIdx.y * 2 + 0) * N + n] = mu[j];
+          stats[((size_t)blockIdx.y * 2 + 1) * N + n] = s_cq[0][col] + s_cq[1][col];
+        }
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -227,8 +273,8 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 
 // Chan's parallel-variance fold of the chunk statistics [k0, k1) of one channel, in chunk order -> (count, mean, M2)
 __device__ __forceinline__ void bn_fold_range(const float* __restrict__ part, int chunks, int M, int C, int c, int k0, int k1, float* n_out, float* mean_out,
-                                              float* m2_out) {
-  const int per = (M + chunks - 1) / chunks;
+                                              float* m2_out, int stat_rows) {
+  const int per = stat_rows > 0 ? stat_rows : (M + chunks - 1) / chunks;      // rows per chunk: the producer's tiling (GEMM tiles of 64, depthwise chunks of 128), or even shares
   float n = 0.0f, mu = 0.0f, m2 = 0.0f;
   for (int k = k0; k < k1; ++k) {
     const int r0 = k * per, r1 = (r0 + per < M) ? r0 + per : M;
@@ -245,12 +291,13 @@ __device__ __forceinline__ void bn_fold_range(const float* __restrict__ part, in
 // The statistics of the 64 channels of slab `slab`, by all 256 threads of a workgroup: thread group q = tid / 64 folds the q-th
 // quarter of the chunks, then lane group 0 combines the four results in order.  The grouping is a function of `chunks` only, so
 // every workgroup (and bn_stats_finalize_kernel) produces the same bits.  Results in s_mean / s_var [64]; needs a barrier after.
-__device__ __forceinline__ void bn_fold_slab(const float* __restrict__ part, int chunks, int M, int C, int slab, float (*s_q)[64][3], float* s_mean, float* s_var) {
+__device__ __forceinline__ void bn_fold_slab(const float* __restrict__ part, int chunks, int M, int C, int slab, float (*s_q)[64][3], float* s_mean, float* s_var,
+                                             int stat_rows = 0) {
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int c = slab * 64 + cl;
   const int per4 = (chunks + 3) / 4;
   float n = 0.0f, mu = 0.0f, m2 = 0.0f;
-  if (c < C) bn_fold_range(part, chunks, M, C, c, q * per4, (q + 1) * per4 < chunks ? (q + 1) * per4 : chunks, &n, &mu, &m2);
+  if (c < C) bn_fold_range(part, chunks, M, C, c, q * per4, (q + 1) * per4 < chunks ? (q + 1) * per4 : chunks, &n, &mu, &m2, stat_rows);
   s_q[q][cl][0] = n; s_q[q][cl][1] = mu; s_q[q][cl][2] = m2;
   __syncthreads();
   if (q == 0) {
@@ -291,10 +338,10 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ part, int chunks, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int act, float momentum, float* __restrict__ mmean,
                                                            float* __restrict__ mvar, float* __restrict__ mean, float* __restrict__ var, float* __restrict__ A, int M,
-                                                           int C, const float* __restrict__ res, const float* __restrict__ row_scale, int group) {
+                                                           int C, const float* __restrict__ res, const float* __restrict__ row_scale, int group, int stat_rows) {
   __shared__ float s_q[4][64][3], s_sh[64], s_var[64], s_sc[64];
   const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  bn_fold_slab(part, chunks, M, C, blockIdx.x, s_q, s_sh, s_var);          // s_sh = mean
+  bn_fold_slab(part, chunks, M, C, blockIdx.x, s_q, s_sh, s_var, stat_rows);          // s_sh = mean
   __syncthreads();
   if (threadIdx.x < 64) {
     const int c = blockIdx.x * 64 + threadIdx.x;
@@ -506,6 +553,73 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ X
       }
     }
     *reinterpret_cast<f32x4*>(Z + i * 4) = acc;
+  }
+}
+
+// The same convolution with the BatchNorm chunk statistics of its output (rows = output positions) in the same launch: grid (64-channel
+// slabs, chunks of 128 rows), block = 16 channel quads x 16 row lanes, eight rows per thread kept in registers for the second pass
+// (mean of the chunk, then squared deviations from it; lanes fold in lane order).  part[chunk][2][C] as bn_stats_partial_kernel writes it.
+__global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Z,
+                                                           float* __restrict__ part, int B, int H, int Wd, int C, int k, int s, int pt, int pl, int Ho, int Wo) {
+  __shared__ float s1[16][16][4];
+  const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + 4 * ql;
+  const int M = B * Ho * Wo;
+  const int r0 = blockIdx.y * 128, r1 = (r0 + 128 < M) ? r0 + 128 : M;
+  const int n = r1 - r0;
+  const bool ok = c0 < C;
+  f32x4 z[8];
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = r0 + rl + 16 * t;
+    z[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ok && r < r1) {
+      int p = r;
+      const int ow = p % Wo; p /= Wo;
+      const int oh = p % Ho;
+      const int b = p / Ho;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ii = 0; ii < k; ++ii) {
+        const int ih = oh * s - pt + ii;
+        if (ih < 0 || ih >= H) continue;
+        for (int jj = 0; jj < k; ++jj) {
+          const int iw = ow * s - pl + jj;
+          if (iw < 0 || iw >= Wd) continue;
+          acc += *reinterpret_cast<const f32x4*>(X + (((size_t)b * H + ih) * Wd + iw) * C + c0) * *reinterpret_cast<const f32x4*>(W + (size_t)(ii * k + jj) * C + c0);
+        }
+      }
+      *reinterpret_cast<f32x4*>(Z + (size_t)r * C + c0) = acc;
+      z[t] = acc;
+      a1 += acc;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s1[rl][ql][i] = a1[i];
+  __syncthreads();
+  f32x4 mu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t1 = s1[0][ql][i];
+    for (int l = 1; l < 16; ++l) t1 += s1[l][ql][i];
+    mu[i] = t1 / (float)n;
+  }
+  __syncthreads();
+  f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    if (r0 + rl + 16 * t < r1) { const f32x4 d = z[t] - mu; a2 += d * d; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s1[rl][ql][i] = a2[i];
+  __syncthreads();
+  if (rl == 0 && ok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t2 = s1[0][ql][i];
+      for (int l = 1; l < 16; ++l) t2 += s1[l][ql][i];
+      part[((size_t)blockIdx.y * 2 + 0) * C + c0 + i] = mu[i];
+      part[((size_t)blockIdx.y * 2 + 1) * C + c0 + i] = t2;
+    }
   }
 }
 
@@ -850,7 +964,6 @@ __global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restric
   }
   __syncthreads();
   const float g0 = (lane < SC) ? s_g[lane] : 0.0f, g1 = (lane + 64 < SC) ? s_g[lane + 64] : 0.0f;
-#pragma unroll 4
   for (int n = wave; n < se; n += 4) {
     const float* w = We + (size_t)n * C + c0;
     float v = ((lane < SC) ? g0 * w[lane] : 0.0f) + ((lane + 64 < SC) ? g1 * w[lane + 64] : 0.0f);
@@ -1090,6 +1203,8 @@ inline bool fold_defer(const float* part, float* out, int chunks, int n, int N, 
   c.bump += ((size_t)chunks * n + 63) & ~(size_t)63;
   return true;
 }
+constexpr int kBnMaxChunks = 256;          // chunk statistics one BatchNorm launch folds per channel (a producer with more chunks keeps the separate statistics launch)
+constexpr int kBnMaxGemmTiles = 160;       // the same for GEMM row tiles (64 rows each: more, smaller chunks than the statistics kernel would make)
 inline int row_chunks(int M, int cap) { int c = (M + 127) / 128; if (c > cap) c = cap; if (c < 1) c = 1; return c; }
 }  // namespace
 
@@ -1156,7 +1271,7 @@ int mkws_op_fold_flush(void* stream) {
 }
 
 static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
-                     const float* bias, int act, float* Act, hipStream_t s) {
+                     const float* bias, int act, float* Act, hipStream_t s, float* stats = nullptr, bool* stats_done = nullptr) {
   MKWS_REQ(A && B && C, "gemm: NULL operand");
   MKWS_REQ(M > 0 && N > 0 && K > 0 && ksplit >= 0, "gemm: bad dimensions");
   const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
@@ -1177,8 +1292,11 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
     MKWS_REQ(part, "gemm: ksplit = %d needs %zu floats of scratch (mkws_op_set_scratch)", ksplit, (size_t)ksplit * M * N);
   }
   const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
+  // chunk statistics ride in the epilogue of an unsplit NN GEMM whose row tiles are few enough for the BatchNorm launch to fold
+  float* st = (stats && ksplit == 1 && !transA && !transB && !accumulate && (M + 63) / 64 <= kBnMaxGemmTiles) ? stats : nullptr;
+  if (stats_done) *stats_done = st != nullptr;
 #define MKWS_TG(TA_, TB_) hipLaunchKernelGGL((train_gemm_kernel<TA_, TB_>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part, bias, act, \
-                                             ksplit > 1 ? nullptr : Act)
+                                             ksplit > 1 ? nullptr : Act, st)
   if (!transA && !transB) MKWS_TG(false, false);
   else if (!transA) MKWS_TG(false, true);
   else if (!transB) MKWS_TG(true, false);
@@ -1233,7 +1351,28 @@ int mkws_op_bn_train_fwd_res(const float* Z, int M, int C, const float* gamma, c
   MKWS_REQ(part, "bn_train_fwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, Z, part, M, C);
   hipLaunchKernelGGL(bn_train_fwd_kernel, dim3((C + 63) / 64, row_chunks(M, 256)), dim3(256), 0, s, Z, part, chunks, gamma, beta, eps, act, momentum, moving_mean,
-                     moving_var, mean, var, A, M, C, res, row_scale, group);
+                     moving_var, mean, var, A, M, C, res, row_scale, group, 0);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+// 1x1 convolution (NN GEMM) + training-mode BatchNorm (+ activation, + residual branch) as ONE operator: when the GEMM is unsplit and has
+// at most kBnMaxGemmTiles row tiles, its epilogue leaves the BatchNorm chunk statistics (one chunk = one 64-row tile) and the BatchNorm is a
+// single launch; otherwise the three-launch sequence of mkws_op_gemm + mkws_op_bn_train_fwd_res.
+int mkws_op_conv_bn_fwd(const float* X, const float* W, float* Z, int M, int N, int K, const float* gamma, const float* beta, float eps, int act, float momentum,
+                        float* moving_mean, float* moving_var, float* mean, float* var, float* A, const float* res, const float* row_scale, int group,
+                        void* stream) {
+  MKWS_REQ(X && W && Z && gamma && beta && moving_mean && moving_var && mean && var && A && M > 0 && N > 0 && K > 0, "conv_bn_fwd: bad arguments");
+  MKWS_REQ(group > 0 && (res || !row_scale), "conv_bn_fwd: row_scale needs a residual input and a positive group");
+  MKWS_REQ(N % 4 == 0, "conv_bn_fwd: N must be a multiple of 4");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int tiles = (M + 63) / 64;
+  float* part = (tiles <= kBnMaxGemmTiles) ? scratch_at((size_t)tiles * 2 * N, s) : nullptr;
+  bool fused = false;
+  if (int rc = gemm_impl(X, W, Z, M, N, K, K, N, N, 0, 0, 0, 0, nullptr, 0, nullptr, s, part, &fused)) return rc;
+  if (!fused) return mkws_op_bn_train_fwd_res(Z, M, N, gamma, beta, eps, act, momentum, moving_mean, moving_var, mean, var, A, res, row_scale, group, stream);
+  hipLaunchKernelGGL(bn_train_fwd_kernel, dim3((N + 63) / 64, row_chunks(M, 256)), dim3(256), 0, s, Z, part, tiles, gamma, beta, eps, act, momentum, moving_mean,
+                     moving_var, mean, var, A, M, N, res, row_scale, group, 64);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -1281,6 +1420,28 @@ int mkws_op_bn_update_moving(float* moving_mean, float* moving_var, const float*
 int mkws_op_dwconv_fwd(const float* X, const float* W, float* Z, int B, int H, int Wd, int C, int k, int s, int pt, int pl, int Ho, int Wo, void* stream) {
   MKWS_REQ(X && W && Z && B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_fwd: bad arguments");
   hipLaunchKernelGGL(dw_fwd_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), X, W, Z, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
+  MKWS_HIP(hipGetLastError());
+  return MKWS_OK;
+}
+
+// Depthwise convolution + training-mode BatchNorm + activation as ONE operator: up to kBnMaxChunks chunks of 128 output rows the convolution
+// launch leaves the chunk statistics itself (two launches in all), above that the three-launch sequence.
+int mkws_op_dwconv_bn_fwd(const float* X, const float* W, float* Z, int B, int H, int Wd, int C, int k, int s, int pt, int pl, int Ho, int Wo, const float* gamma,
+                          const float* beta, float eps, int act, float momentum, float* moving_mean, float* moving_var, float* mean, float* var, float* A,
+                          void* stream) {
+  MKWS_REQ(X && W && Z && gamma && beta && moving_mean && moving_var && mean && var && A, "dwconv_bn_fwd: NULL operand");
+  MKWS_REQ(B > 0 && C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2), "dwconv_bn_fwd: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int M = B * Ho * Wo, chunks = (M + 127) / 128;
+  if (chunks > kBnMaxChunks) {
+    if (int rc = mkws_op_dwconv_fwd(X, W, Z, B, H, Wd, C, k, s, pt, pl, Ho, Wo, stream)) return rc;
+    return mkws_op_bn_train_fwd_res(Z, M, C, gamma, beta, eps, act, momentum, moving_mean, moving_var, mean, var, A, nullptr, nullptr, 1, stream);
+  }
+  float* part = scratch_at((size_t)chunks * 2 * C, st);
+  MKWS_REQ(part, "dwconv_bn_fwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
+  hipLaunchKernelGGL(dw_fwd_stats_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, X, W, Z, part, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
+  hipLaunchKernelGGL(bn_train_fwd_kernel, dim3((C + 63) / 64, row_chunks(M, 256)), dim3(256), 0, st, Z, part, chunks, gamma, beta, eps, act, momentum, moving_mean,
+                     moving_var, mean, var, A, M, C, nullptr, nullptr, 1, 128);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

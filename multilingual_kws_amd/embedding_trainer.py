@@ -215,6 +215,16 @@ class EmbeddingTrainer:
                                                 self._p(self.G(prefix + "/gamma")), self._p(self.G(prefix + "/beta")), M, C, self._s()))
         return dA
 
+    def _conv_bn_fwd(self, X, M, K, N, wname, prefix, act, res=None, row_scale=None, group=1):
+        """1x1 convolution + training-mode BN (+ activation / residual branch) as one operator: the GEMM's epilogue leaves the BN's chunk
+        statistics whenever it can (mkws_op_conv_bn_fwd).  Returns (A, BN tape record) like _bn_fwd."""
+        Z, mean, var, A = self.new(M, N), self.new(N), self.new(N), self.new(M, N)
+        _lib.check(self.L.mkws_op_conv_bn_fwd(self._p(X), self._p(self.P(wname)), self._p(Z), M, N, K, self._p(self.P(prefix + "/gamma")),
+                                              self._p(self.P(prefix + "/beta")), BN_EPS, act, BN_MOMENTUM, self._p(self.P(prefix + "/moving_mean")),
+                                              self._p(self.P(prefix + "/moving_variance")), self._p(mean), self._p(var), self._p(A),
+                                              self._p(res) if res is not None else None, self._p(row_scale) if row_scale is not None else None, group, self._s()))
+        return A, (Z, mean, var, M, N, prefix, act)
+
     def _conv_fwd(self, X, M, K, N, wname):
         Z = self.new(M, N)
         self.gemm(X, self.P(wname), Z, M, N, K, K, N, N)
@@ -271,8 +281,7 @@ class EmbeddingTrainer:
             rec = {"name": name, "inp": x, "H": H, "W": W, "cin": cin, "cout": cout, "k": k, "s": s, "ce": ce, "se": se}
             Min = B * H * W
             if e != 1:
-                Ze = self._conv_fwd(x, Min, cin, ce, p + "_expand_conv/kernel")
-                Ae, rec["expand_bn"] = self._bn_fwd(Ze, Min, ce, p + "_expand_bn", ACT_SWISH)
+                Ae, rec["expand_bn"] = self._conv_bn_fwd(x, Min, cin, ce, p + "_expand_conv/kernel", p + "_expand_bn", ACT_SWISH)
             else:
                 Ae = x
             if s == 2:
@@ -281,9 +290,13 @@ class EmbeddingTrainer:
                 Ho, Wo, pt, pl = H, W, k // 2, k // 2
             rec.update(Ho=Ho, Wo=Wo, pt=pt, pl=pl, Ae=Ae)
             Mout = B * Ho * Wo
-            Zd = self.new(Mout, ce)
-            _lib.check(self.L.mkws_op_dwconv_fwd(self._p(Ae), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(Zd), B, H, W, ce, k, s, pt, pl, Ho, Wo, self._s()))
-            Ad, rec["dw_bn"] = self._bn_fwd(Zd, Mout, ce, p + "_bn", ACT_SWISH)
+            # depthwise conv + BN + swish: the conv launch leaves the BN chunk statistics (mkws_op_dwconv_bn_fwd)
+            Zd, dmean_, dvar_, Ad = self.new(Mout, ce), self.new(ce), self.new(ce), self.new(Mout, ce)
+            _lib.check(self.L.mkws_op_dwconv_bn_fwd(self._p(Ae), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(Zd), B, H, W, ce, k, s, pt, pl, Ho, Wo,
+                                                    self._p(self.P(p + "_bn/gamma")), self._p(self.P(p + "_bn/beta")), BN_EPS, ACT_SWISH, BN_MOMENTUM,
+                                                    self._p(self.P(p + "_bn/moving_mean")), self._p(self.P(p + "_bn/moving_variance")), self._p(dmean_), self._p(dvar_),
+                                                    self._p(Ad), self._s()))
+            rec["dw_bn"] = (Zd, dmean_, dvar_, Mout, ce, p + "_bn", ACT_SWISH)
             # the squeeze-excite branch (pool, two 1x1 convolutions, excite multiply): two launches, a workgroup per (clip, channel slab)
             mean, Yr, R, Gt, As = self.new(B, ce), self.new(B, se), self.new(B, se), self.new(B, ce), self.new(Mout, ce)
             work = self.new(B, (ce + 127) // 128 * se)
@@ -291,7 +304,6 @@ class EmbeddingTrainer:
                                              self._p(self.P(p + "_se_expand/kernel")), self._p(self.P(p + "_se_expand/bias")),
                                              self._p(mean), self._p(Yr), self._p(R), self._p(Gt), self._p(As), self._p(work), B, Ho * Wo, ce, se, self._s()))
             rec.update(Ad=Ad, Gt=Gt, As=As, se_mean=mean, se_Yr=Yr, se_R=R, se_work=work)
-            Zp = self._conv_fwd(As, Mout, ce, cout, p + "_project_conv/kernel")
             rec["residual"] = (s == 1 and cin == cout)
             if rec["residual"]:
                 scale = self._views.get(("ones", B))
@@ -304,15 +316,15 @@ class EmbeddingTrainer:
                     scale = torch.as_tensor(np.asarray(drop_masks[name]), device=self.device).to(torch.float32) / (1.0 - rate)
                 rec["keep_scale"] = scale.contiguous()
                 # out = keep * BN(project) + shortcut, inside the BN launch
-                x, rec["project_bn"] = self._bn_fwd(Zp, Mout, cout, p + "_project_bn", ACT_NONE, res=x, row_scale=rec["keep_scale"], group=Ho * Wo)
+                x, rec["project_bn"] = self._conv_bn_fwd(As, Mout, ce, cout, p + "_project_conv/kernel", p + "_project_bn", ACT_NONE, res=x,
+                                                         row_scale=rec["keep_scale"], group=Ho * Wo)
             else:
-                x, rec["project_bn"] = self._bn_fwd(Zp, Mout, cout, p + "_project_bn", ACT_NONE)
+                x, rec["project_bn"] = self._conv_bn_fwd(As, Mout, ce, cout, p + "_project_conv/kernel", p + "_project_bn", ACT_NONE)
             tape["blocks"].append(rec)
             H, W = Ho, Wo
         HW = H * W
         tape["top_in"], tape["HW"] = x, HW
-        Zt = self._conv_fwd(x, B * HW, 320, 1280, "top_conv/kernel")
-        At, tape["top_bn"] = self._bn_fwd(Zt, B * HW, 1280, "top_bn", ACT_SWISH)
+        At, tape["top_bn"] = self._conv_bn_fwd(x, B * HW, 320, 1280, "top_conv/kernel", "top_bn", ACT_SWISH)
         gap = self.new(B, 1280)
         _lib.check(self.L.mkws_op_pool_hw(self._p(At), self._p(gap), B, HW, 1280, self._s()))
         a, tape["dense"] = self._fc_fwd(gap, B, 1280, 2048, "dense", ACT_RELU)

@@ -283,6 +283,71 @@ def test_stem_se_and_elementwise_operators(ops):
     assert int(step.item()) == 3 and np.abs(P2.cpu().numpy() - P.cpu().numpy()).max() < 1e-7
 
 
+@pytest.mark.parametrize("M,K,N,act,res", [(768, 80, 480, 1, False), (2240, 144, 40, 0, True), (100, 16, 96, 1, False), (256, 1152, 320, 0, False),
+                                           (12800, 16, 96, 1, False)])
+def test_conv_batchnorm_as_one_operator(ops, M, K, N, act, res):
+    """mkws_op_conv_bn_fwd == mkws_op_gemm + mkws_op_bn_train_fwd_res.  Unsplit GEMMs with <= 160 row tiles leave the BN chunk statistics
+    in their epilogue (other chunking than the statistics kernel: statistics to round-off, not to the bit); split GEMMs (K = 1152) and
+    large M (200 row tiles) take the sequence itself: bit-identical."""
+    rng = np.random.default_rng(M + N)
+    X, W = ops.t(rng.standard_normal((M, K))), ops.t(rng.standard_normal((K, N)) / np.sqrt(K))
+    g, b = ops.t(rng.uniform(0.5, 1.5, N)), ops.t(rng.standard_normal(N) * 0.1)
+    group = 4
+    R = ops.t(rng.standard_normal((M, N))) if res else None
+    rs = ops.t(rng.uniform(0, 1.3, M // group)) if res else None
+    e = lambda *shape: torch.full(shape, float("nan"), device=ops.dev)
+    out = []
+    for fused in (False, True):
+        mm, mv = ops.t(np.zeros(N)), ops.t(np.ones(N))
+        Z, mean, var, A = e(M, N), e(N), e(N), e(M, N)
+        if fused:
+            ops.check(ops.L.mkws_op_conv_bn_fwd(ops.p(X), ops.p(W), ops.p(Z), M, N, K, ops.p(g), ops.p(b), 1e-3, act, 0.99, ops.p(mm), ops.p(mv), ops.p(mean),
+                                                ops.p(var), ops.p(A), ops.p(R), ops.p(rs), group, ops.s()))
+        else:
+            ops.check(ops.L.mkws_op_gemm(ops.p(X), ops.p(W), ops.p(Z), M, N, K, K, N, N, 0, 0, 0, 0, ops.s()))
+            ops.check(ops.L.mkws_op_bn_train_fwd_res(ops.p(Z), M, N, ops.p(g), ops.p(b), 1e-3, act, 0.99, ops.p(mm), ops.p(mv), ops.p(mean), ops.p(var), ops.p(A),
+                                                     ops.p(R), ops.p(rs), group, ops.s()))
+        out.append([t.cpu().numpy() for t in (Z, mean, var, A, mm, mv)])
+    (Z0, m0, v0, A0, mm0, mv0), (Z1, m1, v1, A1, mm1, mv1) = out
+    assert np.array_equal(Z0, Z1)
+    if K >= 512 or M > 160 * 64:
+        assert all(np.array_equal(a, b_) for a, b_ in zip(out[0], out[1]))
+    z64 = Z0.astype(np.float64)
+    assert np.abs(m1 - z64.mean(0)).max() < 1e-5 and _rel(v1, z64.var(0)) < 1e-5
+    assert _rel(m1, m0) < 1e-5 and _rel(v1, v0) < 1e-5 and _rel(A1, A0) < 1e-4 and _rel(mm1, mm0) < 1e-5 and _rel(mv1, mv0) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,C,k,s", [(3, 25, 20, 96, 3, 2), (5, 7, 5, 240, 5, 1), (70, 2, 2, 1152, 3, 1), (9, 13, 10, 144, 5, 2)])
+def test_depthwise_batchnorm_as_one_operator(ops, B, H, W, C, k, s):
+    """mkws_op_dwconv_bn_fwd == mkws_op_dwconv_fwd + mkws_op_bn_train_fwd: same convolution bits, statistics to round-off."""
+    rng = np.random.default_rng(B + C)
+    if s == 2:
+        pt, pl = k // 2 - (1 - H % 2), k // 2 - (1 - W % 2)
+        Ho, Wo = (H + pt + k // 2 - k) // 2 + 1, (W + pl + k // 2 - k) // 2 + 1
+    else:
+        pt, pl, Ho, Wo = k // 2, k // 2, H, W
+    M = B * Ho * Wo
+    X, Wd = ops.t(rng.standard_normal((B, H, W, C))), ops.t(rng.standard_normal((k, k, C)) / k)
+    g, b = ops.t(rng.uniform(0.5, 1.5, C)), ops.t(rng.standard_normal(C) * 0.1)
+    e = lambda *shape: torch.full(shape, float("nan"), device=ops.dev)
+    out = []
+    for fused in (False, True):
+        mm, mv = ops.t(np.zeros(C)), ops.t(np.ones(C))
+        Z, mean, var, A = e(M, C), e(C), e(C), e(M, C)
+        if fused:
+            ops.check(ops.L.mkws_op_dwconv_bn_fwd(ops.p(X), ops.p(Wd), ops.p(Z), B, H, W, C, k, s, pt, pl, Ho, Wo, ops.p(g), ops.p(b), 1e-3, 1, 0.99, ops.p(mm),
+                                                  ops.p(mv), ops.p(mean), ops.p(var), ops.p(A), ops.s()))
+        else:
+            ops.check(ops.L.mkws_op_dwconv_fwd(ops.p(X), ops.p(Wd), ops.p(Z), B, H, W, C, k, s, pt, pl, Ho, Wo, ops.s()))
+            ops.check(ops.L.mkws_op_bn_train_fwd(ops.p(Z), M, C, ops.p(g), ops.p(b), 1e-3, 1, 0.99, ops.p(mm), ops.p(mv), ops.p(mean), ops.p(var), ops.p(A), ops.s()))
+        out.append([t.cpu().numpy() for t in (Z, mean, var, A, mm, mv)])
+    (Z0, m0, v0, A0, mm0, mv0), (Z1, m1, v1, A1, mm1, mv1) = out
+    assert np.array_equal(Z0, Z1)
+    z64 = Z0.astype(np.float64)
+    assert np.abs(m1 - z64.mean(0)).max() < 1e-5 and _rel(v1, z64.var(0)) < 1e-5
+    assert _rel(A1, A0) < 1e-4 and _rel(mm1, mm0) < 1e-5 and _rel(mv1, mv0) < 1e-5
+
+
 @pytest.mark.parametrize("B,HW,C,se", [(5, 500, 32, 8), (3, 130, 96, 4), (6, 35, 240, 10), (4, 12, 672, 28), (70, 4, 1152, 48)])
 def test_fused_squeeze_excite_forward_backward(ops, B, HW, C, se):
     """mkws_op_se_fwd / mkws_op_se_bwd_fused (two launches forward, three backward) against float64 autograd of
