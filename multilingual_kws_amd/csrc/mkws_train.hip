@@ -559,8 +559,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ X
 // The same convolution with the BatchNorm chunk statistics of its output (rows = output positions) in the same launch: grid (64-channel
 // slabs, chunks of 128 rows), block = 16 channel quads x 16 row lanes, eight rows per thread kept in registers for the second pass
 // (mean of the chunk, then squared deviations from it; lanes fold in lane order).  part[chunk][2][C] as bn_stats_partial_kernel writes it.
+template <int KS>
 __global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Z,
-                                                           float* __restrict__ part, int B, int H, int Wd, int C, int k, int s, int pt, int pl, int Ho, int Wo) {
+                                                           float* __restrict__ part, int B, int H, int Wd, int C, int s, int pt, int pl, int Ho, int Wo) {
   __shared__ float s1[16][16][4];
   const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c0 = blockIdx.x * 64 + 4 * ql;
@@ -568,27 +569,40 @@ __global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const float* __restri
   const int r0 = blockIdx.y * 128, r1 = (r0 + 128 < M) ? r0 + 128 : M;
   const int n = r1 - r0;
   const bool ok = c0 < C;
+  const int cc = ok ? c0 : 0;
+  // the taps of this thread's channel quad stay in registers; a row's KS*KS input loads are issued together (clamped addresses, the
+  // padding taps multiply by zero), so a thread pays one memory latency per row, not one per tap
+  f32x4 wv[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) wv[t] = *reinterpret_cast<const f32x4*>(W + (size_t)t * C + cc);
   f32x4 z[8];
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 2
   for (int t = 0; t < 8; ++t) {
     const int r = r0 + rl + 16 * t;
-    z[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ok && r < r1) {
-      int p = r;
-      const int ow = p % Wo; p /= Wo;
-      const int oh = p % Ho;
-      const int b = p / Ho;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int ii = 0; ii < k; ++ii) {
-        const int ih = oh * s - pt + ii;
-        if (ih < 0 || ih >= H) continue;
-        for (int jj = 0; jj < k; ++jj) {
-          const int iw = ow * s - pl + jj;
-          if (iw < 0 || iw >= Wd) continue;
-          acc += *reinterpret_cast<const f32x4*>(X + (((size_t)b * H + ih) * Wd + iw) * C + c0) * *reinterpret_cast<const f32x4*>(W + (size_t)(ii * k + jj) * C + c0);
-        }
+    const bool live = ok && r < r1;
+    int p = live ? r : r0;
+    const int ow = p % Wo; p /= Wo;
+    const int oh = p % Ho;
+    const int b = p / Ho;
+    const float* xb = X + (size_t)b * H * Wd * C + cc;
+    f32x4 xv[KS * KS];
+    float m[KS * KS];
+#pragma unroll
+    for (int ii = 0; ii < KS; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < KS; ++jj) {
+        const int ih = oh * s - pt + ii, iw = ow * s - pl + jj;
+        const bool in = ih >= 0 && ih < H && iw >= 0 && iw < Wd;
+        const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= Wd ? Wd - 1 : iw);
+        xv[ii * KS + jj] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ihc * Wd + iwc) * C);
+        m[ii * KS + jj] = in ? 1.0f : 0.0f;
       }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KS * KS; ++q) acc += xv[q] * (wv[q] * m[q]);      // same products in the same order as dw_fwd_kernel (skipped taps add +0)
+    z[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (live) {
       *reinterpret_cast<f32x4*>(Z + (size_t)r * C + c0) = acc;
       z[t] = acc;
       a1 += acc;
@@ -1439,7 +1453,8 @@ int mkws_op_dwconv_bn_fwd(const float* X, const float* W, float* Z, int B, int H
   }
   float* part = scratch_at((size_t)chunks * 2 * C, st);
   MKWS_REQ(part, "dwconv_bn_fwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
-  hipLaunchKernelGGL(dw_fwd_stats_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, X, W, Z, part, B, H, Wd, C, k, s, pt, pl, Ho, Wo);
+  if (k == 3) hipLaunchKernelGGL((dw_fwd_stats_kernel<3>), dim3((C + 63) / 64, chunks), dim3(256), 0, st, X, W, Z, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
+  else hipLaunchKernelGGL((dw_fwd_stats_kernel<5>), dim3((C + 63) / 64, chunks), dim3(256), 0, st, X, W, Z, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   hipLaunchKernelGGL(bn_train_fwd_kernel, dim3((C + 63) / 64, row_chunks(M, 256)), dim3(256), 0, st, Z, part, chunks, gamma, beta, eps, act, momentum, moving_mean,
                      moving_var, mean, var, A, M, C, nullptr, nullptr, 1, 128);
   MKWS_HIP(hipGetLastError());

@@ -73,6 +73,11 @@ class EmbeddingTrainer:
         # queue); the chain of input gradients stays on the caller's stream; the two join before the optimizer.  Capturable (fork / join).
         self.overlap_wgrad = os.environ.get("MKWS_TRAIN_WGRAD_STREAM", "1") != "0"
         self.wgrad_fork_every = max(1, int(os.environ.get("MKWS_TRAIN_WGRAD_FORK_EVERY", "1")))      # blocks of the sweep per fork
+        # BatchNorm chunk statistics inside the producing launch: bit 0 = 1x1 convolutions (GEMM epilogue), bit 1 = 3x3 depthwise, bit 2 = 5x5
+        # depthwise.  Same-call A/B (tools/gpu/r4_train6.sh, ms per step at batch 64 / 512): 0: 3.73-3.76 / 7.92, 1: 3.71-3.72 / 7.91,
+        # 3: 3.72 / 7.90, 7: 3.76-3.77 / 7.98 -- 32 launches fewer per forward pass for 1 % of the step; the 5x5 depthwise loses (a thread of
+        # the fused kernel owns eight rows x 25 taps)
+        self.fuse_bn_stats = int(os.environ.get("MKWS_TRAIN_FUSE_BN_STATS", "3"))
         self._side = None
         self._scratch_side = None
         self._ctx_side = ctypes.c_void_p()
@@ -218,6 +223,8 @@ class EmbeddingTrainer:
     def _conv_bn_fwd(self, X, M, K, N, wname, prefix, act, res=None, row_scale=None, group=1):
         """1x1 convolution + training-mode BN (+ activation / residual branch) as one operator: the GEMM's epilogue leaves the BN's chunk
         statistics whenever it can (mkws_op_conv_bn_fwd).  Returns (A, BN tape record) like _bn_fwd."""
+        if not self.fuse_bn_stats & 1:
+            return self._bn_fwd(self._conv_fwd(X, M, K, N, wname), M, N, prefix, act, res=res, row_scale=row_scale, group=group)
         Z, mean, var, A = self.new(M, N), self.new(N), self.new(N), self.new(M, N)
         _lib.check(self.L.mkws_op_conv_bn_fwd(self._p(X), self._p(self.P(wname)), self._p(Z), M, N, K, self._p(self.P(prefix + "/gamma")),
                                               self._p(self.P(prefix + "/beta")), BN_EPS, act, BN_MOMENTUM, self._p(self.P(prefix + "/moving_mean")),
@@ -291,12 +298,18 @@ class EmbeddingTrainer:
             rec.update(Ho=Ho, Wo=Wo, pt=pt, pl=pl, Ae=Ae)
             Mout = B * Ho * Wo
             # depthwise conv + BN + swish: the conv launch leaves the BN chunk statistics (mkws_op_dwconv_bn_fwd)
-            Zd, dmean_, dvar_, Ad = self.new(Mout, ce), self.new(ce), self.new(ce), self.new(Mout, ce)
-            _lib.check(self.L.mkws_op_dwconv_bn_fwd(self._p(Ae), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(Zd), B, H, W, ce, k, s, pt, pl, Ho, Wo,
-                                                    self._p(self.P(p + "_bn/gamma")), self._p(self.P(p + "_bn/beta")), BN_EPS, ACT_SWISH, BN_MOMENTUM,
-                                                    self._p(self.P(p + "_bn/moving_mean")), self._p(self.P(p + "_bn/moving_variance")), self._p(dmean_), self._p(dvar_),
-                                                    self._p(Ad), self._s()))
-            rec["dw_bn"] = (Zd, dmean_, dvar_, Mout, ce, p + "_bn", ACT_SWISH)
+            if self.fuse_bn_stats & (2 if k == 3 else 4):
+                Zd, dmean_, dvar_, Ad = self.new(Mout, ce), self.new(ce), self.new(ce), self.new(Mout, ce)
+                _lib.check(self.L.mkws_op_dwconv_bn_fwd(self._p(Ae), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(Zd), B, H, W, ce, k, s, pt, pl, Ho, Wo,
+                                                        self._p(self.P(p + "_bn/gamma")), self._p(self.P(p + "_bn/beta")), BN_EPS, ACT_SWISH, BN_MOMENTUM,
+                                                        self._p(self.P(p + "_bn/moving_mean")), self._p(self.P(p + "_bn/moving_variance")), self._p(dmean_),
+                                                        self._p(dvar_), self._p(Ad), self._s()))
+                rec["dw_bn"] = (Zd, dmean_, dvar_, Mout, ce, p + "_bn", ACT_SWISH)
+            else:
+                Zd = self.new(Mout, ce)
+                _lib.check(self.L.mkws_op_dwconv_fwd(self._p(Ae), self._p(self.P(p + "_dwconv/depthwise_kernel")), self._p(Zd), B, H, W, ce, k, s, pt, pl, Ho, Wo,
+                                                     self._s()))
+                Ad, rec["dw_bn"] = self._bn_fwd(Zd, Mout, ce, p + "_bn", ACT_SWISH)
             # the squeeze-excite branch (pool, two 1x1 convolutions, excite multiply): two launches, a workgroup per (clip, channel slab)
             mean, Yr, R, Gt, As = self.new(B, ce), self.new(B, se), self.new(B, se), self.new(B, ce), self.new(Mout, ce)
             work = self.new(B, (ce + 127) // 128 * se)
