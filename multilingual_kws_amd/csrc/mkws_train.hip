@@ -520,6 +520,80 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// Both backward steps in ONE launch for layers with few rows (M <= kBnSmallRows: the 4x3 and 2x2 image layers of a 64-clip step, 33 of
+// the 49 BatchNorms; at 2 048-2 304 rows it measured ~17 us SLOWER per layer than the two launches): a workgroup owns 8 channels (two
+// quads) of ALL rows -- 128 row lanes stride the rows --, so the column sums it needs never leave it: pass 1 writes dY and sums, a workgroup barrier, pass 2 re-reads its own dY (L2) and writes dZ.  At this size
+// the two-launch form is two launch / drain latencies around ~3 us of work each.  Sums: the rows of a lane in row order, the 32 row
+// lanes of a wave by butterfly, the four waves in order -- fixed.
+constexpr int kBnSmallRows = 1024;
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+                                                           float* __restrict__ dA, int M, int C, const float* __restrict__ src,
+                                                           const float* __restrict__ row_scale, const float* __restrict__ bcast, float bscale, int group,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s_w[4][2][8];
+  const int tid = threadIdx.x, ql = tid & 1, rl = tid >> 1, wave = tid >> 6;
+  const int c0 = blockIdx.x * 8 + 4 * ql;
+  const bool ok = c0 < C;
+  const int cc = ok ? c0 : 0;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cc), vv = *reinterpret_cast<const f32x4*>(var + cc);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cc), b = *reinterpret_cast<const f32x4*>(beta + cc);
+  f32x4 inv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) inv[i] = rsqrtf(vv[i] + eps);
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+#pragma unroll 6
+    for (int r = rl; r < M; r += 128) {
+      const size_t o = (size_t)r * C + c0;
+      const f32x4 z = *reinterpret_cast<const f32x4*>(Z + o);
+      f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      if (src) d = *reinterpret_cast<const f32x4*>(src + o);
+      if (row_scale) { const float ks = row_scale[r / group]; d = d * ks; }
+      if (bcast) { const f32x4 bv = *reinterpret_cast<const f32x4*>(bcast + (size_t)(r / group) * C + c0); d = d + bv * bscale; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (z[i] - mu[i]) * inv[i];
+        d[i] *= act_grad(g[i] * xh + b[i], act);
+        a1[i] += d[i];
+        a2[i] += d[i] * xh;
+      }
+      *reinterpret_cast<f32x4*>(dA + o) = d;
+    }
+  }
+#pragma unroll
+  for (int m = 2; m < 64; m <<= 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a1[i] += __shfl_xor(a1[i], m); a2[i] += __shfl_xor(a2[i], m); }
+  if ((tid & 63) < 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_w[wave][ql][i] = a1[i]; s_w[wave][ql][4 + i] = a2[i]; }
+  }
+  __syncthreads();
+  f32x4 sa, sb;
+  const float invM = 1.0f / (float)M;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t1 = ((s_w[0][ql][i] + s_w[1][ql][i]) + s_w[2][ql][i]) + s_w[3][ql][i];
+    const float t2 = ((s_w[0][ql][4 + i] + s_w[1][ql][4 + i]) + s_w[2][ql][4 + i]) + s_w[3][ql][4 + i];
+    if (rl == 0 && ok) { dbeta[c0 + i] = t1; dgamma[c0 + i] = t2; }
+    sa[i] = t1 * invM; sb[i] = t2 * invM;
+  }
+  if (!ok) return;
+#pragma unroll 6
+  for (int r = rl; r < M; r += 128) {
+    const size_t o = (size_t)r * C + c0;
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + o);
+    f32x4 d = *reinterpret_cast<const f32x4*>(dA + o);        // this thread's own dY of pass 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (z[i] - mu[i]) * inv[i];
+      d[i] = g[i] * inv[i] * (d[i] - sa[i] - xh * sb[i]);
+    }
+    *reinterpret_cast<f32x4*>(dA + o) = d;
+  }
+}
+
 // moving = momentum * moving + (1 - momentum) * batch  (variance: Bessel-corrected, Keras' fused BN)
 __global__ void bn_moving_kernel(float* __restrict__ mmean, float* __restrict__ mvar, const float* __restrict__ mean, const float* __restrict__ var,
                                  float momentum, float bessel, int C) {
@@ -1219,6 +1293,7 @@ inline bool fold_defer(const float* part, float* out, int chunks, int n, int N, 
 }
 constexpr int kBnMaxChunks = 256;          // chunk statistics one BatchNorm launch folds per channel (a producer with more chunks keeps the separate statistics launch)
 constexpr int kBnMaxGemmTiles = 160;       // the same for GEMM row tiles (64 rows each: more, smaller chunks than the statistics kernel would make)
+const bool g_bn_small = [] { const char* e = getenv("MKWS_TRAIN_BN_SMALL"); return !(e && e[0] == '0'); }();      // A/B switch of bn_small_bwd_kernel
 inline int row_chunks(int M, int cap) { int c = (M + 127) / 128; if (c > cap) c = cap; if (c < 1) c = 1; return c; }
 }  // namespace
 
@@ -1413,6 +1488,12 @@ int mkws_op_bn_act_bwd_ex(const float* Z, const float* mean, const float* var, c
   MKWS_REQ(Z && mean && var && gamma && beta && dA && dgamma && dbeta && M > 0 && C > 0, "bn_act_bwd: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
   MKWS_REQ(C % 4 == 0, "bn_act_bwd: C must be a multiple of 4");
+  if (M <= kBnSmallRows && g_bn_small) {                            // few rows: both steps in one launch, a workgroup per 8 channels
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3((C + 7) / 8), dim3(256), 0, s, Z, mean, var, gamma, beta, eps, act, dA, M, C, src, row_scale, bcast, bscale, group,
+                       dgamma, dbeta);
+    MKWS_HIP(hipGetLastError());
+    return MKWS_OK;
+  }
   const int chunks = row_chunks(M, 128);
   float* part = scratch_at((size_t)chunks * 2 * C, s);
   MKWS_REQ(part, "bn_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * 2 * C);
