@@ -463,8 +463,11 @@ def main():
     if rank == 0:
         fe.forward(audio, out=spec)
         fe_ms = event_ms(lambda: fe.forward(audio, out=spec), args.profile_reps)
-        fe_entry = {"frontend_clip_kernel<float,4>": {"ms": fe_ms, "launches": 1, "flops": 0.0,
-                                                     "bytes": float(B * arch.FRONTEND_BYTES_PER_CLIP_F32)}}
+        fw = int(os.environ.get("MKWS_FRONTEND_WAVES", "0"))          # waves per clip (mkws_frontend.hip clip_waves: 4 unless the experiment knob is set)
+        fw = fw if fw in (5, 8, 10) else 4
+        fe_name = f"frontend_clip_kernel_w8<float,8>" if fw == 8 else f"frontend_clip_kernel<float,{fw}>"
+        fe_entry = {fe_name: {"ms": fe_ms, "launches": 1, "flops": 0.0,
+                                                         "bytes": float(B * arch.FRONTEND_BYTES_PER_CLIP_F32)}}
         whole = {"frontend_ms": round(fe_ms, 4)}
         if cfg == "frontend":
             per_kernel = fe_entry

@@ -40,6 +40,8 @@ struct FrontendParams {
   const int16_t* pcan_lut;      // [128]
   const uint16_t* log_lut;      // [132]
   int ncoef;
+  int fast48;                   // every channel's filterbank weights are >= 0 and add up to <= 2^16: mel sums < 2^48, 16-bit multiplies suffice
+  int lane_off, nm;             // out_coef[lane_off + lane * nm + j], j < nm (nm % 4 == 0): lane `lane`'s tap list, zero padded to the longest
   int window_size, window_step, num_channels;
   int smoothing_bits, enable_pcan, enable_log, scale_shift, snr_shift, correction_bits;
   uint32_t even_smoothing, odd_smoothing, min_signal_remaining;
@@ -127,6 +129,34 @@ __device__ __forceinline__ uint32_t sqrt64_round(uint64_t x) {
   const uint64_t sat = ((x >> 32) == 0) ? 0xFFFFull : 0xFFFFFFFFull;
   if (rem > r && r != sat) ++r;
   return (uint32_t)r;
+}
+
+// The same rounded root for x < 2^48 (the mel sums of every configuration whose channel weights add up to <= 2^16: host-checked,
+// FrontendParams::fast48) without 64-bit or double arithmetic.  r0 = trunc(sqrtf(float(x))) is within 4 of the integer root (2^-24 from
+// each of the two conversions / the fma, 1 ulp from v_sqrt_f32, root < 2^24), so d = x - r0^2 fits an int32 and its LOW words suffice;
+// k = floor(d / (2 r0)) is the correction up to one (exact for roots < 4096, where sqrtf is exact; the k^2 term is < 0.01 above), fixed by
+// one exact step on t(k) = k (2 r0 + k) <= d < t(k + 1).  Checked against the integer definition on 7e5 values incl. every boundary
+// class with r0 forced off by -4..+4 (profiles/r04_notes.md section 7).
+__device__ __forceinline__ uint32_t sqrt48_round(uint64_t x) {
+  const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+  const float xf = __builtin_fmaf((float)hi, 4294967296.0f, (float)lo);
+  int r0 = (int)__builtin_amdgcn_sqrtf(xf);
+  r0 = min(max(r0, 1), 0xFFFFFF);
+  const int d = (int)(lo - __umul24((uint32_t)r0, (uint32_t)r0));
+  const int two = 2 * r0;
+  int k = (int)__builtin_floorf((float)d * __builtin_amdgcn_rcpf((float)two));
+  int t = k * (two + k);
+  {
+    const int up = t + two + 2 * k + 1, dn = t - (two + 2 * k - 1);
+    const bool dec = t > d, inc = !dec && up <= d;
+    t = dec ? dn : (inc ? up : t);
+    k = dec ? k - 1 : (inc ? k + 1 : k);
+  }
+  uint32_t r = (uint32_t)(r0 + k);
+  const uint32_t rem = (uint32_t)(d - t);
+  const uint32_t sat = (hi == 0) ? 0xFFFFu : 0xFFFFFFFFu;
+  if (rem > r && r != sat) ++r;
+  return x == 0 ? 0u : r;
 }
 
 // pcan_gain_control.c WideDynamicFunction
@@ -264,6 +294,7 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
     wave_lds_sync();
   }
   // ---- real-FFT post-pass (kiss_fftr) + energy, bins k and 256-k for k = lane+1, lane+65 ----
+  uint32_t ebig = 0;                                      // bit 31: some energy of this frame is exactly 2^31 (the value upstream sign-extends)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int k = lane + 1 + 64 * h;
@@ -277,15 +308,47 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
     const int ar = ((int)f1.x + (int)tw.x) >> 1, ai = ((int)f1.y + (int)tw.y) >> 1;
     const int br = ((int)f1.x - (int)tw.x) >> 1, bi = ((int)tw.y - (int)f1.y) >> 1;
     // FilterbankConvertFftComplexToEnergy: uint32 r*r + i*i (can reach exactly 2^31)
-    if (k != 128) ebuf[k] = (uint32_t)(ar * ar) + (uint32_t)(ai * ai);
-    ebuf[256 - k] = (uint32_t)(br * br) + (uint32_t)(bi * bi);   // k == 128: the second write wins upstream
+    const uint32_t e1 = (uint32_t)(ar * ar) + (uint32_t)(ai * ai), e2 = (uint32_t)(br * br) + (uint32_t)(bi * bi);
+    if (k != 128) ebuf[k] = e1;
+    ebuf[256 - k] = e2;   // k == 128: the second write wins upstream
+    ebig |= e1 | e2;
   }
   wave_lds_sync();
   // ---- mel filterbank (uint64 sums) + rounded sqrt ----
   // Lane c < C owns channel c; the tap lists of the longest channels are split in two and the lanes >= C take the second
   // halves (the loop runs max-length iterations for the whole wave: 14 instead of 28 for the 40-channel configuration).
   // uint64 sums wrap mod 2^64, so the split is exact.
-  {
+  // Round 4: when no energy of the frame is 2^31 (wave-uniform test; the sign-extension quirk cannot fire) and the weights allow it
+  // (fast48), the sums run on FULL-RATE 16-bit multiply-adds -- coef * e = coef * e.lo16 + (coef * e.hi16 << 16), two uint32 accumulators
+  // per lane (<= 14 taps x 2^12 x 2^16 < 2^32) -- instead of quarter-rate v_mad_i64_i32, and the root on sqrt48_round.  Same integers.
+  // Every lane walks the SAME number of taps (its list is zero padded to the longest, p.nm): a uniform loop of four taps per trip,
+  // 6 LDS reads and 8 multiply-adds, no per-lane bounds (the energies read past a short list -- possibly past this wave's buffer, still
+  // inside the workgroup's LDS -- meet zero coefficients).
+  const bool fast = p.fast48 && __builtin_amdgcn_ballot_w64((ebig >> 31) != 0) == 0;
+  if (fast) {
+    uint32_t alo = 0, ahi = 0;
+    const uint32_t* eb = ebuf + L.fb_start;
+    const uint32_t* lc = reinterpret_cast<const uint32_t*>(s_coef + p.lane_off + lane * p.nm);
+    for (int j0 = 0; j0 < p.nm; j0 += 4) {
+      const uint32_t c01 = lc[j0 >> 1], c23 = lc[(j0 >> 1) + 1];
+      const uint32_t e0 = eb[j0], e1 = eb[j0 + 1], e2 = eb[j0 + 2], e3 = eb[j0 + 3];
+      asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(alo) : "v"(e0), "v"(c01));
+      asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(ahi) : "v"(e0), "v"(c01));
+      asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[0,1,0,0]" : "+v"(alo) : "v"(e1), "v"(c01));
+      asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,1,0,0]" : "+v"(ahi) : "v"(e1), "v"(c01));
+      asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(alo) : "v"(e2), "v"(c23));
+      asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(ahi) : "v"(e2), "v"(c23));
+      asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[0,1,0,0]" : "+v"(alo) : "v"(e3), "v"(c23));
+      asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,1,0,0]" : "+v"(ahi) : "v"(e3), "v"(c23));
+    }
+    uint64_t acc = (uint64_t)alo + ((uint64_t)ahi << 16);
+    if (L.fb_ch >= 0) { fftbuf[2 * L.fb_ch] = (uint32_t)acc; fftbuf[2 * L.fb_ch + 1] = (uint32_t)(acc >> 32); }   // helper: FFT state is dead
+    wave_lds_sync();
+    if (lane < p.num_channels) {
+      if (L.fb_helped) acc += (uint64_t)fftbuf[2 * lane] | ((uint64_t)fftbuf[2 * lane + 1] << 32);
+      sig_out[lane] = sqrt48_round(acc) >> shift;
+    }
+  } else {
     uint64_t acc = 0;
     for (int j = 0; j < L.fb_len; ++j) {
       // upstream multiplies (uint64_t)(int32 energy): sign-extends the one value 2^31
@@ -362,9 +425,8 @@ __device__ __forceinline__ uint32_t finish_element(const FrontendParams& p, uint
 // Fused kernel: one workgroup per clip.
 // dynamic LDS: [NWAVES][512] u32 (fft+energy) | sig [F*C] u32 | est [F*C] u32 | coef i16 | pcan i16[128] | log u16[132]
 template <typename T, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void frontend_clip_kernel(FrontendParams p, const T* __restrict__ audio,
-                                                                      int n_samples, int num_frames, int aligned,
-                                                                      float* __restrict__ spec, uint16_t* __restrict__ raw) {
+__device__ __forceinline__ void clip_body(const FrontendParams& p, const T* __restrict__ audio, int n_samples, int num_frames, int aligned,
+                                          float* __restrict__ spec, uint16_t* __restrict__ raw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int C = p.num_channels;
   const int FC = num_frames * C;
@@ -420,6 +482,21 @@ __global__ __launch_bounds__(NWAVES * 64) void frontend_clip_kernel(FrontendPara
     if (spec) spec[clip * FC + i] = (float)v * scale;
     if (raw) raw[clip * FC + i] = (uint16_t)v;
   }
+}
+
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void frontend_clip_kernel(FrontendParams p, const T* __restrict__ audio, int n_samples, int num_frames, int aligned,
+                                                                      float* __restrict__ spec, uint16_t* __restrict__ raw) {
+  clip_body<T, NWAVES>(p, audio, n_samples, num_frames, aligned, spec, raw);
+}
+// The same body compiled for EIGHT waves per SIMD (64 VGPRs: hipcc keeps ~20 loop-invariant lane constants in scratch and reloads them
+// once per frame -- 20 L1 hits against a ~10 000-cycle frame), so that four clips with eight waves each share a CU.
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void frontend_clip_kernel_w8(FrontendParams p, const T* __restrict__ audio,
+                                                                                                                 int n_samples, int num_frames, int aligned,
+                                                                                                                 float* __restrict__ spec,
+                                                                                                                 uint16_t* __restrict__ raw) {
+  clip_body<T, NWAVES>(p, audio, n_samples, num_frames, aligned, spec, raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -570,7 +647,26 @@ int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_fro
   (void)hipGetDevice(&fe->device);
   // pack one device blob
   const int C = cfg->num_channels;
-  const size_t ncoef = t.out_coef.size();
+  // device coefficient array = the compact lists (padded to a multiple of 8) + the per-LANE lists zero padded to the longest one (nm),
+  // which the 16-bit filterbank path walks with a uniform trip count; both are staged into LDS together
+  const size_t ncoef_compact = (t.out_coef.size() + 7) & ~size_t(7);
+  int lane_len[64], lane_src[64];
+  for (int l = 0; l < 64; ++l) { lane_len[l] = 0; lane_src[l] = 0; }
+  {
+    for (int c = 0; c < C; ++c) { lane_len[c] = t.out_len[c]; lane_src[c] = t.out_off[c]; }
+    std::vector<int> order(C);
+    for (int c = 0; c < C; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t.out_len[a] > t.out_len[b]; });
+    for (int k = 0, l = C; k < C && l < 64; ++k, ++l) {          // the same split as the task table below
+      const int c = order[k], len = t.out_len[c];
+      if (len < 2) break;
+      const int first = (len + 1) / 2;
+      lane_len[c] = first; lane_len[l] = len - first; lane_src[l] = t.out_off[c] + first;
+    }
+  }
+  int nm = 4;
+  for (int l = 0; l < 64; ++l) nm = std::max(nm, (lane_len[l] + 3) & ~3);
+  const size_t ncoef = ncoef_compact + (size_t)64 * nm;
   auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
   size_t o_win = 0, o_tw = al(o_win + 512 * 2), o_stw = al(o_tw + 256 * 4), o_os = al(o_stw + 128 * 4), o_ol = al(o_os + 64 * 2),
          o_oo = al(o_ol + 64 * 2), o_tc = al(o_oo + 64 * 2), o_th = al(o_tc + 64 * 2), o_oc = al(o_th + 64 * 2), o_pc = al(o_oc + (ncoef + 8) * 2), o_lg = al(o_pc + 128 * 2), total = al(o_lg + 132 * 2);
@@ -601,7 +697,12 @@ int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_fro
       tc[l] = static_cast<int16_t>(c); th[c] = 1;
     }
   }
-  memcpy(h.data() + o_oc, t.out_coef.data(), ncoef * 2);
+  memcpy(h.data() + o_oc, t.out_coef.data(), t.out_coef.size() * 2);
+  {
+    int16_t* lt = reinterpret_cast<int16_t*>(h.data() + o_oc) + ncoef_compact;
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < lane_len[l]; ++j) lt[(size_t)l * nm + j] = t.out_coef[lane_src[l] + j];
+  }
   memcpy(h.data() + o_pc, t.pcan_lut.data(), t.pcan_lut.size() * 2);
   memcpy(h.data() + o_lg, t.log_lut.data(), t.log_lut.size() * 2);
   if (hipMalloc(&fe->d_blob, total) != hipSuccess) { delete fe; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) failed", total); }
@@ -622,6 +723,18 @@ int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_fro
   p.pcan_lut = reinterpret_cast<int16_t*>(d + o_pc);
   p.log_lut = reinterpret_cast<uint16_t*>(d + o_lg);
   p.ncoef = (int)ncoef;
+  {
+    // fast48: all weights non-negative and every channel's list (both lane halves together) adds up to <= 2^16, so that a mel sum of
+    // energies < 2^31 stays below 2^47 and a lane's 16-bit partial sums below 2^32
+    bool ok48 = true;
+    for (int c = 0; c < C && ok48; ++c) {
+      long sum = 0;
+      for (int j = 0; j < t.out_len[c]; ++j) { const int w = t.out_coef[t.out_off[c] + j]; if (w < 0) ok48 = false; sum += w; }
+      if (sum > 65536) ok48 = false;
+    }
+    p.fast48 = (ok48 && nm <= 32) ? 1 : 0;
+    p.lane_off = (int)ncoef_compact; p.nm = nm;
+  }
   p.window_size = t.window_size; p.window_step = t.window_step; p.num_channels = C;
   p.smoothing_bits = cfg->smoothing_bits; p.enable_pcan = cfg->enable_pcan ? 1 : 0; p.enable_log = cfg->enable_log ? 1 : 0;
   p.scale_shift = cfg->scale_shift; p.snr_shift = t.snr_shift; p.correction_bits = t.correction_bits;
@@ -643,11 +756,20 @@ void mkws_frontend_destroy(mkws_frontend* fe) {
 
 namespace {
 
-constexpr int kClipWaves = 4;
+// Waves per clip: four.  A clip's frames are independent until the scan and one wave works on one frame, so more waves per clip look like
+// free parallelism -- measured in round 4 (tools/gpu/r4_fe.sh, 1024 clips, same call): 60.0 us with four waves per clip; 66.4 with five
+// (90 VGPRs allow five per SIMD, but a 5-wave workgroup does not spread evenly over four SIMDs); 70.6 with eight at eight waves per SIMD
+// (frontend_clip_kernel_w8: 64 VGPRs, 20 scratch reloads per frame); 83.8 with ten.  MKWS_FRONTEND_WAVES=5 / 8 / 10 keeps the experiment
+// runnable; results do not depend on it.
+int clip_waves(int B) {
+  (void)B;
+  static const int forced = [] { const char* e = getenv("MKWS_FRONTEND_WAVES"); return e ? atoi(e) : 0; }();
+  return (forced == 5 || forced == 8 || forced == 10) ? forced : 4;
+}
 
-size_t clip_lds_bytes(const mkws_frontend* fe, int frames) {
+size_t clip_lds_bytes(const mkws_frontend* fe, int frames, int waves) {
   const size_t FC = (size_t)frames * fe->prm.num_channels;
-  return kClipWaves * 512 * 4 + 2 * FC * 4 + ((fe->prm.ncoef + 7) & ~7) * 2 + 128 * 2 + 132 * 2 + 16;
+  return (size_t)waves * 512 * 4 + 2 * FC * 4 + ((fe->prm.ncoef + 7) & ~7) * 2 + 128 * 2 + 132 * 2 + 16;
 }
 
 template <typename T>
@@ -659,13 +781,22 @@ int frontend_forward_impl(mkws_frontend* fe, const T* d_audio, int B, int n_samp
   if (B == 0 || frames == 0) return MKWS_OK;   // empty input -> empty output, like the op
   if (!d_spec && !d_raw) return fail(MKWS_ERR_INVALID_ARG, "both outputs are NULL");
   if (!d_audio) return fail(MKWS_ERR_INVALID_ARG, "d_audio is NULL");
-  const size_t lds = clip_lds_bytes(fe, frames);
+  int waves = clip_waves(B);
+  if (clip_lds_bytes(fe, frames, waves) > 64 * 1024) waves = 4;
+  const size_t lds = clip_lds_bytes(fe, frames, waves);
   if (lds > 64 * 1024)
     return fail(MKWS_ERR_UNSUPPORTED, "%d frames per clip need %zu B of LDS; use mkws_frontend_stream_f32 for long audio", frames, lds);
   const int aligned = ((n_samples % 2) == 0 && (fe->prm.window_step % 2) == 0 && (fe->prm.window_size % 2) == 0 &&
                        (reinterpret_cast<uintptr_t>(d_audio) % (2 * sizeof(T))) == 0) ? 1 : 0;
-  hipLaunchKernelGGL((frontend_clip_kernel<T, kClipWaves>), dim3(B), dim3(kClipWaves * 64), lds, static_cast<hipStream_t>(stream),
-                     fe->prm, d_audio, n_samples, frames, aligned, d_spec, d_raw);
+#define MKWS_FE_CLIP(W_) hipLaunchKernelGGL((frontend_clip_kernel<T, W_>), dim3(B), dim3(W_ * 64), lds, static_cast<hipStream_t>(stream), fe->prm, d_audio, n_samples, \
+                                            frames, aligned, d_spec, d_raw)
+  if (waves == 10) MKWS_FE_CLIP(10);
+  else if (waves == 8)
+    hipLaunchKernelGGL((frontend_clip_kernel_w8<T, 8>), dim3(B), dim3(8 * 64), lds, static_cast<hipStream_t>(stream), fe->prm, d_audio, n_samples, frames, aligned,
+                       d_spec, d_raw);
+  else if (waves == 5) MKWS_FE_CLIP(5);
+  else MKWS_FE_CLIP(4);
+#undef MKWS_FE_CLIP
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

@@ -31,8 +31,6 @@ def label(name):
     base, targs = m.group(1), (m.group(2) or "").replace(" ", "")
     if base == "se_expand_kernel":
         targs = targs.replace(",false", "")
-    if base == "frontend_clip_kernel":
-        targs = "<float,4>" if "float" in targs else targs
     if base == "mbconv_mid_kernel":       # device template <KS,S,KCT,HT,WT,CEXP,CC,NTP,G,SEG,NTHR,WPE> -> profile label <KS,S,HT,WT,CEXP,CC,G,NTHR>
         a = targs.strip("<>").split(",")
         targs = "<" + ",".join(a[i] for i in (0, 1, 3, 4, 5, 6, 8, 10)) + ">"
