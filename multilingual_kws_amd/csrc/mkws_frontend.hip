@@ -41,7 +41,7 @@ struct FrontendParams {
   const uint16_t* log_lut;      // [132]
   int ncoef;
   int fast48;                   // every channel's filterbank weights are >= 0 and add up to <= 2^16: mel sums < 2^48, 16-bit multiplies suffice
-  int lane_off, nm;             // out_coef[lane_off + lane * nm + j], j < nm (nm % 4 == 0): lane `lane`'s tap list, zero padded to the longest
+  int lane_off, nm;             // out_coef[lane_off + ((j >> 1) * 64 + lane) * 2 + (j & 1)], j < nm (nm % 4 == 0): lane `lane`'s tap list, zero padded to the longest
   int window_size, window_step, num_channels;
   int smoothing_bits, enable_pcan, enable_log, scale_shift, snr_shift, correction_bits;
   uint32_t even_smoothing, odd_smoothing, min_signal_remaining;
@@ -198,7 +198,14 @@ struct LaneConst {
   // mel filterbank task of this lane: bins [fb_start, +fb_len) with coefficients from fb_off; lanes < C own channel = lane,
   // lanes >= C may help the channel fb_ch (second half of a long tap list); fb_helped: a helper adds to this lane's channel
   int fb_start, fb_len, fb_off, fb_ch, fb_helped;
+  // LDS word index of every FFT-state access of this lane, SWIZZLED: z[i] lives at word i ^ ((i >> 3) & 31).  In the natural layout the
+  // exchanges of stage B (stride-16 groups of four) and C (stride-64 groups of sixteen) put 8 / 4 lanes on one bank (8 / 4 passes per
+  // 64-lane access instead of 2); with this XOR every access pattern of the transform -- stage A's 4 lane + q, B, C, D's lane + 64 q and the
+  // post-pass's k / 256 - k -- is two lanes per bank (searched over XOR / padding families, tools/fft_lds_swizzle.py).  The indices do not
+  // change from frame to frame: 20 registers of the 128 a wave may hold at four waves per SIMD.
+  int ia[4], ib[4], ic[4], id[4], ip[4];
 };
+__device__ __forceinline__ int fft_swz(int i) { return i ^ ((i >> 3) & 31); }
 
 __device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lane, LaneConst& L) {
   const int d0 = lane & 3, d1 = (lane >> 2) & 3, d2 = (lane >> 4) & 3;
@@ -228,6 +235,14 @@ __device__ __forceinline__ void init_lane_const(const FrontendParams& p, int lan
   L.st2 = mktw(unpack(p.stw[lane + 64]));
   L.fb_start = p.out_start[lane]; L.fb_len = p.out_len[lane]; L.fb_off = p.out_off[lane];
   L.fb_ch = p.task_ch[lane]; L.fb_helped = p.task_helped[lane];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    L.ia[q] = fft_swz(4 * lane + q);
+    L.ib[q] = fft_swz((lane >> 2) * 16 + (lane & 3) + 4 * q);
+    L.ic[q] = fft_swz((lane >> 4) * 64 + (lane & 15) + 16 * q);
+    L.id[q] = fft_swz(lane + 64 * q);
+  }
+  L.ip[0] = fft_swz(lane + 1); L.ip[1] = fft_swz(255 - lane); L.ip[2] = fft_swz(lane + 65); L.ip[3] = fft_swz(191 - lane);
 }
 
 // window.c + fft.c + kiss_fftr + filterbank.c for ONE frame by ONE wave.
@@ -262,35 +277,33 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
   s16x2 F0 = W[0] << sh2, F1 = W[1] << sh2, F2 = W[2] << sh2, F3 = W[3] << sh2;
   const tw2 one = mktw(cpx{32767, 0});
   bfly4(F0, F1, F2, F3, one, one, one);
-  fftbuf[4 * lane + 0] = bits2(F0);
-  fftbuf[4 * lane + 1] = bits2(F1);
-  fftbuf[4 * lane + 2] = bits2(F2);
-  fftbuf[4 * lane + 3] = bits2(F3);
+  fftbuf[L.ia[0]] = bits2(F0);
+  fftbuf[L.ia[1]] = bits2(F1);
+  fftbuf[L.ia[2]] = bits2(F2);
+  fftbuf[L.ia[3]] = bits2(F3);
   wave_lds_sync();
   // ---- stage B (m = 4) ----
   {
-    const int base = (lane >> 2) * 16 + (lane & 3);
-    F0 = from2(fftbuf[base]); F1 = from2(fftbuf[base + 4]); F2 = from2(fftbuf[base + 8]); F3 = from2(fftbuf[base + 12]);
+    F0 = from2(fftbuf[L.ib[0]]); F1 = from2(fftbuf[L.ib[1]]); F2 = from2(fftbuf[L.ib[2]]); F3 = from2(fftbuf[L.ib[3]]);
     bfly4(F0, F1, F2, F3, L.twB[0], L.twB[1], L.twB[2]);
-    fftbuf[base] = bits2(F0); fftbuf[base + 4] = bits2(F1);
-    fftbuf[base + 8] = bits2(F2); fftbuf[base + 12] = bits2(F3);
+    fftbuf[L.ib[0]] = bits2(F0); fftbuf[L.ib[1]] = bits2(F1);
+    fftbuf[L.ib[2]] = bits2(F2); fftbuf[L.ib[3]] = bits2(F3);
     wave_lds_sync();
   }
   // ---- stage C (m = 16) ----
   {
-    const int base = (lane >> 4) * 64 + (lane & 15);
-    F0 = from2(fftbuf[base]); F1 = from2(fftbuf[base + 16]); F2 = from2(fftbuf[base + 32]); F3 = from2(fftbuf[base + 48]);
+    F0 = from2(fftbuf[L.ic[0]]); F1 = from2(fftbuf[L.ic[1]]); F2 = from2(fftbuf[L.ic[2]]); F3 = from2(fftbuf[L.ic[3]]);
     bfly4(F0, F1, F2, F3, L.twC[0], L.twC[1], L.twC[2]);
-    fftbuf[base] = bits2(F0); fftbuf[base + 16] = bits2(F1);
-    fftbuf[base + 32] = bits2(F2); fftbuf[base + 48] = bits2(F3);
+    fftbuf[L.ic[0]] = bits2(F0); fftbuf[L.ic[1]] = bits2(F1);
+    fftbuf[L.ic[2]] = bits2(F2); fftbuf[L.ic[3]] = bits2(F3);
     wave_lds_sync();
   }
   // ---- stage D (m = 64) ----
   {
-    F0 = from2(fftbuf[lane]); F1 = from2(fftbuf[lane + 64]); F2 = from2(fftbuf[lane + 128]); F3 = from2(fftbuf[lane + 192]);
+    F0 = from2(fftbuf[L.id[0]]); F1 = from2(fftbuf[L.id[1]]); F2 = from2(fftbuf[L.id[2]]); F3 = from2(fftbuf[L.id[3]]);
     bfly4(F0, F1, F2, F3, L.twD[0], L.twD[1], L.twD[2]);
-    fftbuf[lane] = bits2(F0); fftbuf[lane + 64] = bits2(F1);
-    fftbuf[lane + 128] = bits2(F2); fftbuf[lane + 192] = bits2(F3);
+    fftbuf[L.id[0]] = bits2(F0); fftbuf[L.id[1]] = bits2(F1);
+    fftbuf[L.id[2]] = bits2(F2); fftbuf[L.id[3]] = bits2(F3);
     wave_lds_sync();
   }
   // ---- real-FFT post-pass (kiss_fftr) + energy, bins k and 256-k for k = lane+1, lane+65 ----
@@ -299,8 +312,8 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
   for (int h = 0; h < 2; ++h) {
     const int k = lane + 1 + 64 * h;
     const tw2 st = h ? L.st2 : L.st1;
-    const s16x2 t = from2(fftbuf[256 - k]);
-    const s16x2 fpk = fixdiv_pk(from2(fftbuf[k]), 16383);
+    const s16x2 t = from2(fftbuf[L.ip[2 * h + 1]]);                  // z[256 - k]
+    const s16x2 fpk = fixdiv_pk(from2(fftbuf[L.ip[2 * h]]), 16383);   // z[k]
     const s16x2 fpnk = fixdiv_pk(mk2(t.x, -(int)t.y), 16383);
     const s16x2 f1 = fpk + fpnk, f2 = fpk - fpnk;
     const s16x2 tw = cmul_pk(f2, st);
@@ -328,9 +341,9 @@ __device__ __forceinline__ void frame_to_sig(const FrontendParams& p, const Lane
   if (fast) {
     uint32_t alo = 0, ahi = 0;
     const uint32_t* eb = ebuf + L.fb_start;
-    const uint32_t* lc = reinterpret_cast<const uint32_t*>(s_coef + p.lane_off + lane * p.nm);
+    const uint32_t* lc = reinterpret_cast<const uint32_t*>(s_coef + p.lane_off) + lane;      // coefficient PAIR m of lane l at word m * 64 + l: conflict-free
     for (int j0 = 0; j0 < p.nm; j0 += 4) {
-      const uint32_t c01 = lc[j0 >> 1], c23 = lc[(j0 >> 1) + 1];
+      const uint32_t c01 = lc[(j0 >> 1) * 64], c23 = lc[((j0 >> 1) + 1) * 64];
       const uint32_t e0 = eb[j0], e1 = eb[j0 + 1], e2 = eb[j0 + 2], e3 = eb[j0 + 3];
       asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(alo) : "v"(e0), "v"(c01));
       asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(ahi) : "v"(e0), "v"(c01));
@@ -701,7 +714,7 @@ int mkws_frontend_create(const mkws_frontend_cfg* cfg, int max_samples, mkws_fro
   {
     int16_t* lt = reinterpret_cast<int16_t*>(h.data() + o_oc) + ncoef_compact;
     for (int l = 0; l < 64; ++l)
-      for (int j = 0; j < lane_len[l]; ++j) lt[(size_t)l * nm + j] = t.out_coef[lane_src[l] + j];
+      for (int j = 0; j < lane_len[l]; ++j) lt[((size_t)(j >> 1) * 64 + l) * 2 + (j & 1)] = t.out_coef[lane_src[l] + j];      // pair-major, lane-minor
   }
   memcpy(h.data() + o_pc, t.pcan_lut.data(), t.pcan_lut.size() * 2);
   memcpy(h.data() + o_lg, t.log_lut.data(), t.log_lut.size() * 2);
