@@ -1299,6 +1299,24 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
   store1();
   __syncthreads();
 
+  // The SE weights of this thread's role are requested HERE, a whole chunk loop ahead of their use (round 4: requested at the top of the SE
+  // phase, two barriers in front of the reduce FC, their L2 round trip was part of every clip's 3 us of SE; the kernel holds 80-92 of the
+  // 128 registers a wave may use, the ~16 these occupy during the loop are free).
+  float wr_pre[CPS], we_pre[SE_MAX], br_pre = 0.0f, be_pre = 0.0f;
+  auto request_se = [&]() {
+    const int n = tid & 15, sl = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < CPS; ++i) {
+      const int ch = sl * CPS + i;
+      wr_pre[i] = (ch < CEXP && n < a.se) ? a.Wr[(size_t)ch * a.se + n] : 0.0f;
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < SE_MAX; ++n2) we_pre[n2] = (tid < CEXP && n2 < a.se) ? a.We[(size_t)n2 * CEXP + tid] : 0.0f;
+    br_pre = (tid < 16 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
+    be_pre = (tid < CEXP) ? a.be[tid] : 0.0f;
+  };
+  if (!MKWS_ABLATE(16)) request_se();                            // (timing build, MKWS_ABLATE=16: the round-3 position, for the A/B)
+
   for (int chn = 0; chn < NCH; ++chn) {
     const int ch0 = chn * CC;
     // ---- P1: expand this chunk into LDS ----
@@ -1428,21 +1446,9 @@ __global__ __launch_bounds__(NTHR, WPE) void mbconv_mid_kernel(MidArgs a) {
     if (tid == 0) { const unsigned long long t = wall_clock64(); t_p2 += t - t_mark; t_mark = t; }
 #endif
   }
-  // The weights of the remaining phases are requested here (L2 hits: every workgroup uses the same ones): the SE
-  // weights of this thread's role, and the first fragments of the projection weight stream of this wave's n-tile.
-  float wr_pre[CPS], we_pre[SE_MAX];
-  {
-    const int n = tid & 15, sl = tid >> 4;
-#pragma unroll
-    for (int i = 0; i < CPS; ++i) {
-      const int ch = sl * CPS + i;
-      wr_pre[i] = (ch < CEXP && n < a.se) ? a.Wr[(size_t)ch * a.se + n] : 0.0f;
-    }
-#pragma unroll
-    for (int n2 = 0; n2 < SE_MAX; ++n2) we_pre[n2] = (tid < CEXP && n2 < a.se) ? a.We[(size_t)n2 * CEXP + tid] : 0.0f;
-  }
-  const float br_pre = (tid < 16 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
-  const float be_pre = (tid < CEXP) ? a.be[tid] : 0.0f;
+  // The first fragments of the projection weight stream of this wave's n-tile are requested here (L2 hits: every workgroup uses the
+  // same ones); the SE weights of this thread's role were requested in front of the chunk loop.
+  if (MKWS_ABLATE(16)) request_se();
   constexpr int NWP = NW / NTP;                                  // row-tile lanes per n-tile (waves beyond NWP*NTP idle in the projection)
   constexpr int MTW = (MTO + NWP - 1) / NWP;                     // row tiles per wave
   constexpr int PD = (KC >= 8) ? 8 : 4;                          // depth of the projection weight ring
