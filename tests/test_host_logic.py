@@ -232,3 +232,16 @@ def test_single_clip_augment_follows_the_reference_law(tmp_path):
     assert lab == "_unknown_" and any(np.array_equal(a, u) for u in unknown)
     extra = ds._random_silence_unknown(20)
     assert [l for _, l in extra] == ["_silence_"] * 2 + ["_unknown_"] * 10
+
+
+def test_sqrt48_algorithm_matches_the_integer_definition():
+    """The frontend's rounded square root for mel sums < 2^48 (mkws_frontend.hip sqrt48_round: float estimate + one exact integer correction)
+    restated in numpy (tools/sqrt48_check.py) == bits.h Sqrt64 + round-to-nearest on random values and every boundary class, with the
+    estimate forced off by up to +-4."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sqrt48_check.py"), "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("mismatches 0") == 9
+
