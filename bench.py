@@ -450,10 +450,14 @@ def main():
     # Untimed clock warm-up in front of the W warm-up steps: a process's first ~dozen forward passes run at a lower shader clock (rocprofv3 reads
     # the 235 us chain kernel at 251 us in a 13-step run; `--steps 20 --warmup 5` read 1.05-1.06 M clips/s where 200 / 20 reads 1.085 M, same box,
     # same call: profiles/r04_notes.md).  0.3 s of the same step, reported in the line as `prewarm_s`; the timed region is still exactly K steps.
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < PREWARM_S:
-        step()
-        torch.cuda.synchronize()
+    if world > 1:
+        for _ in range(200):             # a fixed count: a step may hold a collective, every rank must run the same number of them
+            step()
+    else:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < PREWARM_S:
+            step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
