@@ -1368,9 +1368,19 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
     // auto: split a long reduction of a small grid until the launch has ~256 workgroups, at least 64 columns of K per slice, as far
     // as the scratch arena reaches.  A function of the shapes and the arena size only: reproducible.
     ksplit = 1;
-    if (tiles < 256 && K >= 512) {
-      ksplit = (256 + tiles - 1) / tiles;
-      if (ksplit > K / 64) ksplit = K / 64;
+    {
+      // Measured rules (round 4, tools/gemm_ksplit.py; times include the fold launch):
+      int few = 1, many = 1;
+      if (tiles <= 128 && K >= 192) {                    // a handful of tiles (weight gradients, 64-clip layers): one workgroup per CU, slices of
+        few = (256 + tiles - 1) / tiles;                 // >= 64 columns of K (4b project at 64 clips, K = 480: 23.7 -> 10.4 us; K = 240: 13.5 -> 9.4)
+        if (few > K / 64) few = K / 64;
+      }
+      if (tiles < 1024 && K >= 384) {                    // up to four workgroups per CU, at most 8 slices of >= 96 columns: a 512-row dense layer
+        many = (1024 + tiles - 1) / tiles;               // is 256 tiles = ONE wave per SIMD walking 128 K steps alone (dense_1 97 -> 69 us with 4
+        if (many > 8) many = 8;                          // slices, 6b project 30 -> 22 with 8, 4b project at 512 clips 25.4 -> 21 with 5; K = 240
+        if (many > K / 96) many = K / 96;                // loses: 13.8 -> 14.5)
+      }
+      ksplit = few > many ? few : many;
       while (ksplit > 1 && !scratch((size_t)ksplit * M * N)) --ksplit;
       if (ksplit < 1) ksplit = 1;
     }
