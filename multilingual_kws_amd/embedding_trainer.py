@@ -568,6 +568,7 @@ class TrainStepGraph:
             tr.L, head.L = lib_t, lib_h
         self._tape = log
         self._tape_stream = _lib.current_stream_ptr().value
+        self._tape_pool = tr._pool          # the buffers the tape names: held here, so they outlive a trainer that moves on to another batch size
 
     def _body(self, overlap=None):
         tr, head = self.tr, self.head
@@ -605,8 +606,10 @@ class TrainStepGraph:
             self.graph.replay()
             return self.stats
         if self._tape is not None:
-            if _lib.current_stream_ptr().value != self._tape_stream:      # the caller moved to another stream: the tape names the old one
-                self._record()                                            # (recording runs the step: this one is done)
+            if _lib.current_stream_ptr().value != self._tape_stream or self.tr._pool is not self._tape_pool:
+                # the caller moved to another stream, or the trainer ran another batch size in between (its buffer pool was rebuilt): the
+                # tape names the old stream / buffers.  Recording runs the step, so this one is done.
+                self._record()
                 return self.stats
             for f, a in self._tape:
                 rc = f(*a)

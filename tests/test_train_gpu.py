@@ -605,6 +605,31 @@ def test_graph_replayed_training_step_equals_the_eager_step():
     assert np.array_equal(tr_s.blob(), pg) and np.array_equal(hd_s.get_params(), hd_g.get_params())
 
 
+def test_recorded_step_survives_another_batch_size_in_between():
+    """The call tape names the trainer's pooled buffers.  A forward pass at ANOTHER batch size rebuilds that pool; the next replay must notice
+    (re-record on the new buffers) instead of writing through stale pointers: same parameters as the same sequence run launch by launch."""
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding_trainer import EmbeddingTrainer, TrainStepGraph
+    from multilingual_kws_amd.head import Head
+    blob = weights.synthetic_blob()
+    rng = np.random.default_rng(21)
+    B, lr = 8, 1e-4
+    specs = [torch.from_numpy(rng.integers(0, 670, size=(B, 49, 40)).astype(np.float32) * np.float32(10 / 256)).cuda() for _ in range(2)]
+    labels = [torch.from_numpy(rng.integers(0, 3, B).astype(np.int32)).cuda() for _ in range(2)]
+    other = torch.from_numpy(rng.integers(0, 670, size=(5, 49, 40)).astype(np.float32) * np.float32(10 / 256)).cuda()
+    out = []
+    for mode in ("eager", "tape"):
+        tr, hd = EmbeddingTrainer(blob), Head(max_batch=B, seed=3)
+        step = TrainStepGraph(tr, hd, B, lr, mode=mode)
+        step.run(specs[0], labels[0])
+        tr.forward_train(other)                    # training-mode forward at batch 5: moving statistics move, the buffer pool is rebuilt
+        tr.tape = None
+        step.run(specs[1], labels[1])
+        torch.cuda.synchronize()
+        out.append((tr.blob(), hd.get_params()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_two_trainers_interleaved_on_one_thread_do_not_share_operator_state():
     """mkws_train_ctx (include/mkws.h): each EmbeddingTrainer owns its scratch arena and deferred-fold queue and binds them at the top of
     every public method.  Two trainers whose forward / backward calls are INTERLEAVED on one host thread -- the second one's forward
