@@ -231,6 +231,21 @@ __global__ __launch_bounds__(256) void fold_batch_kernel(FoldBatch fb) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Thread layout of the row-streaming BatchNorm launches: a workgroup owns a 64-channel slab x a chunk of rows, 16 channel quads x 16 row lanes.
+// A slab with fewer live quads (C = 16, 32, 96's second slab, ...) hands its idle quad lanes to the rows instead: 8 quads x 32 row lanes, or 4 x 64
+// (round 4: the stem / block-1a / 2a layers -- the largest tensors of a step, C = 32 / 16 / 96 -- ran these launches with a quarter to a half of
+// their threads masked off).  Full slabs keep 16 x 16: same sums, same order as before.
+struct BnLanes { int QL, RL, ql, rl; };
+__device__ __forceinline__ BnLanes bn_lanes(int C) {
+  const int live = (C - (int)blockIdx.x * 64 + 3) / 4;          // live quads of this slab (> 0 by the grid)
+  BnLanes b;
+  b.QL = live > 8 ? 16 : (live > 4 ? 8 : 4);
+  b.RL = 256 / b.QL;
+  b.ql = (int)threadIdx.x & (b.QL - 1);
+  b.rl = (int)threadIdx.x / b.QL;
+  return b;
+}
+
 // Batch statistics of Z [M, C] per channel, two levels, fixed order.
 // Level 1 (grid: 64-channel slabs x row chunks, block = 64 channel lanes x 4 row lanes): every workgroup computes the mean of ITS
 // rows and the sum of squared deviations from that mean (two passes over its own rows, which sit in L2 after the first), and
@@ -240,8 +255,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   // block = 16 channel quads (64 channels, one float4 per thread and row) x 16 row lanes.  ONE pass with shifted data: d = z - K
   // with K = the chunk's first row (any value near the mean removes the cancellation of the raw sum-of-squares formula);
   // mean_k = K + sum(d)/n,  M2_k = sum(d^2) - sum(d)^2/n.  The 16 row lanes fold in lane order.
-  __shared__ float s1[16][16][4], s2[16][16][4];
-  const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  __shared__ float s1[256][4], s2[256][4];
+  const BnLanes L = bn_lanes(C);
+  const int ql = L.ql, rl = L.rl;
   const int c0 = blockIdx.x * 64 + 4 * ql;
   const int per = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = (r0 + per < M) ? r0 + per : M;
@@ -251,20 +267,20 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   if (ok) {
     K = *reinterpret_cast<const f32x4*>(Z + (size_t)r0 * C + c0);
 #pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
-    for (int r = r0 + rl; r < r1; r += 16) {
+    for (int r = r0 + rl; r < r1; r += L.RL) {
       const f32x4 d = *reinterpret_cast<const f32x4*>(Z + (size_t)r * C + c0) - K;
       a1 += d;
       a2 += d * d;
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { s1[rl][ql][i] = a1[i]; s2[rl][ql][i] = a2[i]; }
+  for (int i = 0; i < 4; ++i) { s1[rl * L.QL + ql][i] = a1[i]; s2[rl * L.QL + ql][i] = a2[i]; }
   __syncthreads();
   if (rl == 0 && ok) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float t1 = s1[0][ql][i], t2 = s2[0][ql][i];
-      for (int l = 1; l < 16; ++l) { t1 += s1[l][ql][i]; t2 += s2[l][ql][i]; }
+      float t1 = s1[ql][i], t2 = s2[ql][i];
+      for (int l = 1; l < L.RL; ++l) { t1 += s1[l * L.QL + ql][i]; t2 += s2[l * L.QL + ql][i]; }
       part[((size_t)blockIdx.y * 2 + 0) * C + c0 + i] = K[i] + t1 / (float)n;
       part[((size_t)blockIdx.y * 2 + 1) * C + c0 + i] = t2 - t1 * t1 / (float)n;
     }
@@ -340,7 +356,8 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
                                                            float* __restrict__ mvar, float* __restrict__ mean, float* __restrict__ var, float* __restrict__ A, int M,
                                                            int C, const float* __restrict__ res, const float* __restrict__ row_scale, int group, int stat_rows) {
   __shared__ float s_q[4][64][3], s_sh[64], s_var[64], s_sc[64];
-  const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const BnLanes L = bn_lanes(C);
+  const int ql = L.ql, rl = L.rl;
   bn_fold_slab(part, chunks, M, C, blockIdx.x, s_q, s_sh, s_var, stat_rows);          // s_sh = mean
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) { inv[i] = s_sc[4 * ql + i]; mu[i] = s_sh[4 * ql + i]; }
 #pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
-  for (int r = r0 + rl; r < r1; r += 16) {
+  for (int r = r0 + rl; r < r1; r += L.RL) {
     const f32x4 z = *reinterpret_cast<const f32x4*>(Z + (size_t)r * C + c0);
     f32x4 y;
 #pragma unroll
@@ -426,8 +443,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                                                                 float* __restrict__ dA, float* __restrict__ part /*[chunks][2][C]*/, int M, int C,
                                                                 const float* __restrict__ src, const float* __restrict__ row_scale,
                                                                 const float* __restrict__ bcast, float bscale, int group) {
-  __shared__ float s1[16][16][4], s2[16][16][4];
-  const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  __shared__ float s1[256][4], s2[256][4];
+  const BnLanes L = bn_lanes(C);
+  const int ql = L.ql, rl = L.rl;
   const int c0 = blockIdx.x * 64 + 4 * ql;
   const int per = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = (r0 + per < M) ? r0 + per : M;
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) inv[i] = rsqrtf(vv[i] + eps);
 #pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
-    for (int r = r0 + rl; r < r1; r += 16) {
+    for (int r = r0 + rl; r < r1; r += L.RL) {
       const size_t o = (size_t)r * C + c0;
       const f32x4 z = *reinterpret_cast<const f32x4*>(Z + o);
       // incoming gradient (mkws_op_bn_act_bwd_ex): src (or dA itself; neither = zero) * row_scale[row / group] + bcast[row / group][c] * bscale
@@ -459,13 +477,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { s1[rl][ql][i] = a1[i]; s2[rl][ql][i] = a2[i]; }
+  for (int i = 0; i < 4; ++i) { s1[rl * L.QL + ql][i] = a1[i]; s2[rl * L.QL + ql][i] = a2[i]; }
   __syncthreads();
   if (rl == 0 && ok) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float t1 = s1[0][ql][i], t2 = s2[0][ql][i];
-      for (int l = 1; l < 16; ++l) { t1 += s1[l][ql][i]; t2 += s2[l][ql][i]; }
+      float t1 = s1[ql][i], t2 = s2[ql][i];
+      for (int l = 1; l < L.RL; ++l) { t1 += s1[l * L.QL + ql][i]; t2 += s2[l * L.QL + ql][i]; }
       part[((size_t)blockIdx.y * 2 + 0) * C + c0 + i] = t1;
       part[((size_t)blockIdx.y * 2 + 1) * C + c0 + i] = t2;
     }
@@ -478,7 +496,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, float eps, float* __restrict__ dY, const float* __restrict__ part,
                                                            int chunks, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
   __shared__ float s_a[64], s_b[64], s_q[4][64][2];
-  const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const BnLanes L = bn_lanes(C);
+  const int ql = L.ql, rl = L.rl;
   {
     // thread group q folds the q-th quarter of the chunks, group 0 adds the four results in order (a function of `chunks` only)
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
@@ -507,7 +526,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) { inv[i] = rsqrtf(vv[i] + eps); sa[i] = s_a[4 * ql + i] * invM; sb[i] = s_b[4 * ql + i] * invM; }
 #pragma unroll 4      // four rows' loads in flight per thread (the adds keep their order: no fast-math)
-  for (int r = r0 + rl; r < r1; r += 16) {
+  for (int r = r0 + rl; r < r1; r += L.RL) {
     const size_t o = (size_t)r * C + c0;
     const f32x4 z = *reinterpret_cast<const f32x4*>(Z + o);
     f32x4 d = *reinterpret_cast<const f32x4*>(dY + o);
