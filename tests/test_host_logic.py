@@ -245,3 +245,30 @@ def test_sqrt48_algorithm_matches_the_integer_definition():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("mismatches 0") == 9
 
+
+def test_call_tape_logs_and_passes_through():
+    """embedding_trainer._CallTape (the recorder behind TrainStepGraph's default mode): every entry-point call goes through to the library
+    object unchanged and is logged as (function, arguments) in call order, so that replaying the log re-issues the same calls."""
+    from multilingual_kws_amd.embedding_trainer import _CallTape
+
+    class FakeLib:
+        def __init__(self):
+            self.seen = []
+
+        def mkws_op_a(self, x, y):
+            self.seen.append(("a", x, y))
+            return 0
+
+        def mkws_op_b(self, z):
+            self.seen.append(("b", z))
+            return -3
+    lib, log = FakeLib(), []
+    tape = _CallTape(lib, log)
+    assert tape.mkws_op_a(1, "p") == 0 and tape.mkws_op_b(7) == -3 and tape.mkws_op_a(2, "q") == 0
+    assert lib.seen == [("a", 1, "p"), ("b", 7), ("a", 2, "q")]
+    assert [a for _, a in log] == [(1, "p"), (7,), (2, "q")]
+    lib.seen.clear()
+    assert [f(*a) for f, a in log] == [0, -3, 0] and lib.seen == [("a", 1, "p"), ("b", 7), ("a", 2, "q")]
+    with pytest.raises(AttributeError):
+        tape.no_such_entry_point
+
