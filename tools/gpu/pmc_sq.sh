@@ -14,7 +14,7 @@ def rd(d):
     return per
 a,b=rd("p1"),rd("p2")
 for k in sorted(a):
-    if not any(t in k for t in ("block_kernel","pw_gemm_kernel<2,4","mid_kernel","front_kernel<3,2","stem_block","frontend")): continue
+    if not any(t in k for t in ("chain_kernel","pw_gemm_kernel<1,4","mid_kernel","front_kernel<3,2","stem_block","frontend")): continue
     c={n:sum(v[-max(1,len(v)//4):])/max(1,len(v)//4) for n,v in a[k].items()}; c.update({n:sum(v[-max(1,len(v)//4):])/max(1,len(v)//4) for n,v in b.get(k,{}).items()})
     wc=c.get("SQ_WAVE_CYCLES",1)
     print(f"{k[:44]:44s} wait_any {c.get('SQ_WAIT_ANY',0)/wc:.2f} wait_inst {c.get('SQ_WAIT_INST_ANY',0)/wc:.2f} active {c.get('SQ_ACTIVE_INST_ANY',0)/wc:.2f} valu {c.get('SQ_ACTIVE_INST_VALU',0)/wc:.2f} lds {c.get('SQ_ACTIVE_INST_LDS',0)/wc:.2f} vmem {c.get('SQ_ACTIVE_INST_VMEM',0)/wc:.2f} | waitlds {c.get('SQ_WAIT_INST_LDS',0)/wc:.2f} bankconf/ldsinst {c.get('SQ_LDS_BANK_CONFLICT',0)/max(1,c.get('SQ_INSTS_LDS',1)):.2f} valu_insts {c.get('SQ_INSTS_VALU',0):.3g} lds_insts {c.get('SQ_INSTS_LDS',0):.3g} mfma_busy {c.get('SQ_VALU_MFMA_BUSY_CYCLES',0):.3g} wavecyc {wc:.3g}")
