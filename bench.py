@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline samples (1/3 single thread, 2/3 all cores)")
     ap.add_argument("--profile-reps", type=int, default=5)
+    ap.add_argument("--ft-group", type=int, default=None, help="finetune: optimizer steps per forward pass of the frozen embedding "
+                    "(default: transfer_learn's own rule, 1024 // batch; 1 = a forward pass per step as in rounds 1-4)")
+    ap.add_argument("--ft-overlap", type=int, default=0, help="finetune: optimizer steps on a second stream under the next group's kernels (A/B; off in transfer_learn: it measured 1 % slower)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B execution switch passed to mkws_embed_set_option (e.g. fuse_block=1); default = shipped plan")
     return ap.parse_args()
@@ -369,14 +372,19 @@ def main():
     B = args.batch or {"embed": 1024, "frontend": 1024, "finetune": 512, "stream": 256}[cfg]
     blob = weights.synthetic_blob() if cfg != "frontend" else None
     fe = Frontend(max_samples=16000)
-    em = EmbeddingModel(blob, max_batch=B, device=dev) if blob is not None else None
+    FB = B           # clips per forward pass of the embedding
+    if cfg == "finetune":
+        from multilingual_kws_amd.embedding import transfer_learning as tl
+        ft_group = max(1, args.ft_group if args.ft_group is not None else tl.steps_per_forward(B))
+        FB = B * ft_group
+    em = EmbeddingModel(blob, max_batch=FB, device=dev) if blob is not None else None
     for kv in args.opt:
         name, _, val = kv.partition("=")
         em.set_option(name, int(val))
-    audio_np = synth.clips_float32(B, first_clip=rank * B)      # each rank gets its own shard of clips
+    audio_np = synth.clips_float32(FB, first_clip=rank * FB)      # each rank gets its own shard of clips
     audio = torch.from_numpy(audio_np).to(dev)
-    spec = torch.empty((B, 49, 40), dtype=torch.float32, device=dev)
-    emb = torch.empty((B, 1024), dtype=torch.float32, device=dev)
+    spec = torch.empty((FB, 49, 40), dtype=torch.float32, device=dev)
+    emb = torch.empty((FB, 1024), dtype=torch.float32, device=dev)
     units_per_step, unit, extra_out = B, "clips/s", {}
 
     if cfg == "embed":
@@ -396,22 +404,24 @@ def main():
     elif cfg == "finetune":
         from multilingual_kws_amd.embedding import input_data
         metric = "clips/sec 5-shot 3-class head fine-tune step (augment + log-mel + frozen embedding fwd + head fwd/bwd/Adam), batch 512/GPU"
-        workload = ("configs[3]: 512 clips/GPU per step from 5 target + 256 unknown clips + 4x60 s background (synthetic): augmentation -> "
+        workload = (f"configs[3]: {B} clips/GPU per optimizer step from 5 target + 256 unknown clips + 4x60 s background (synthetic): augmentation -> "
                     "micro-frontend -> SpecAugment -> EfficientNet-B0 forward (frozen) -> head loss/gradient -> "
-                    "one RCCL all-reduce of 18 509 floats (N > 1) -> Keras Adam")
+                    "one RCCL all-reduce of 18 509 floats per step (N > 1) -> Keras Adam; the frozen forward is independent of the head, so "
+                    f"{ft_group} consecutive batches share one {FB}-clip launch chain (transfer_learning.FrozenHeadTrainer = what transfer_learn runs); "
+                    "a timed step is ONE optimizer step")
         tmp = tempfile.mkdtemp(prefix="mkws_ft_")
         d = synth.write_fewshot_dataset(tmp)
         ms = input_data.standard_microspeech_model_settings(3)
         ds = input_data.AudioDataset(ms, ["target"], d["bg_dir"], d["unknown"], unknown_percentage=50.0,
                                      spec_aug_params=input_data.SpecAugParams(percentage=80), seed=1 + 1000003 * rank)
-        it = iter(ds.init_single_target(input_data.AUTOTUNE, d["train"], is_training=True).shuffle(1000).repeat().batch(B))
+        train_ds = ds.init_single_target(input_data.AUTOTUNE, d["train"], is_training=True).shuffle(1000).repeat().batch(B)
         p0 = np.random.default_rng(0).uniform(-0.07, 0.07, 18507).astype(np.float32)      # identical head on every rank
         head = Head(params=p0, max_batch=B, device=dev)
+        ft = tl.FrozenHeadTrainer(em, head, train_ds, B, 1e-3, group=ft_group, overlap=bool(args.ft_overlap))
+        extra_out.update({"steps_per_forward": ft.G, "head_steps_on_second_stream": ft.overlap})
 
         def step():
-            s, labels = next(it)
-            e = em.forward(s, out=emb)
-            parallel.dp_step(head, e, labels, lr=1e-3)
+            ft.step()          # ONE optimizer step on its own B clips (every ft.G-th call also launches the next group's forward chain)
     else:   # stream
         from multilingual_kws_amd.embedding import batch_streaming_analysis as bsa, input_data
         metric = "windows/sec streaming inference, 50 keywords on one shared embedding, 20 ms hop, batch 256"
@@ -481,19 +491,22 @@ def main():
         fw = fw if fw in (5, 8, 10) else 4
         fe_name = f"frontend_clip_kernel_w8<float,8>" if fw == 8 else f"frontend_clip_kernel<float,{fw}>"
         fe_entry = {fe_name: {"ms": fe_ms, "launches": 1, "flops": 0.0,
-                                                         "bytes": float(B * arch.FRONTEND_BYTES_PER_CLIP_F32)}}
+                                                         "bytes": float(FB * arch.FRONTEND_BYTES_PER_CLIP_F32)}}
         whole = {"frontend_ms": round(fe_ms, 4)}
         if cfg == "frontend":
             per_kernel = fe_entry
         else:
-            per_kernel, emb_ms = embed_roofline(em, spec, B, args.profile_reps, arch, extra=None if cfg == "stream" else fe_entry)
+            # (finetune: the kernel table describes one forward chain = FB clips = FB / B optimizer steps)
+            per_kernel, emb_ms = embed_roofline(em, spec, FB, args.profile_reps, arch, extra=None if cfg == "stream" else fe_entry)
             whole.update({"embedding_ms": round(emb_ms, 4),
                           "tflops": round(units_per_step * arch.EMBED_FLOPS_PER_CLIP / (ms_per_step * 1e-3) / 1e12, 2)})
             if cfg in ("embed", "finetune"):
                 # what the per-kernel table (frontend + embedding launches) does NOT cover: augmentation, SpecAugment, the head's
                 # loss / gradient / update kernels, collectives.  Round 2 found 290 us hiding here in the fine-tune config.
-                whole["other_ms"] = round(max(0.0, ms_per_step - fe_ms - emb_ms), 4)
-        roof, kernels = roofline_of(per_kernel, B)
+                whole["other_ms"] = round(max(0.0, ms_per_step - (fe_ms + emb_ms) * B / FB), 4)
+                if FB != B:
+                    whole["clips_per_forward"] = FB
+        roof, kernels = roofline_of(per_kernel, FB)
         if cfg == "frontend":       # the whole step IS the one kernel
             roof["whole_step_frac"] = round(B * arch.FRONTEND_BYTES_PER_CLIP_F32 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         else:                       # algorithmic FLOPs of the step (embedding forward of every clip / window) / wall time of the step / MFMA peak

@@ -202,7 +202,11 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "big_tiles" (A/B aid, default 0): 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (what handles above 512 clips use). */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
 /* Current value of an option above, of "exchange_error" (see the failure contract), or of "pair_degraded" (times the handle left the paired kernel after a failed exchange) /
- * "max_batch"; negative mkws_status for an unknown name.  ("pair_fault" is a write-only test hook that forces those failures.) */
+ * "max_batch"; negative mkws_status for an unknown name.  ("pair_fault" is a write-only test hook that forces those failures.)
+ * Guard-band mode (test aid; MKWS_EMBED_GUARD=<floats> in the environment when the handle is created): the workspace starts as a NaN canary
+ * pattern and every sub-buffer carved from it is followed -- the first one also preceded -- by that many floats no kernel may touch.
+ * "guard_floats" / "guard_bands" = size and number of the bands (0 = mode off); "guard_violations" = SYNCHRONISES the device and counts the
+ * guard words that no longer hold the canary (an out-of-range store of any kernel of the handle). */
 int mkws_embed_get_option(const mkws_embed* em, const char* name);
 
 /* Measurement aid (NOT capturable: it records a hipEvent pair around every kernel launch and

@@ -478,6 +478,21 @@ HDF5_SIGNATURE = b"\x89HDF\r\n\x1a\n"
 _UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
+def _format_errors(fn):
+    """A corrupt or truncated file must fail as CheckpointFormatError, not as whatever the first out-of-range unpack / slice / search raises."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        try:
+            return fn(self, *a, **k)
+        except CheckpointFormatError:
+            raise
+        except (struct.error, IndexError, ValueError, UnicodeDecodeError, OverflowError, RecursionError) as exc:
+            raise CheckpointFormatError(f"corrupt or truncated HDF5 file ({fn.__name__}: {exc!r})") from exc
+    return wrapped
+
+
 class H5File:
     """Minimal read-only view of an HDF5 file: groups as {name: object-header address}, datasets as numpy arrays, attributes."""
 
@@ -504,14 +519,23 @@ class H5File:
         p += 32
         _name_off, root_oh, cache, _r = struct.unpack_from("<QQII", b, p)
         self.root = root_oh
-        if self.eof > len(b) + self.base_addr:
-            raise CheckpointFormatError(f"{path}: truncated (end-of-file address {self.eof}, file has {len(b)} bytes)")
+        # addresses in the file are relative to the base address (a user block in front of the superblock moves it)
+        if self.eof + self.base_addr > len(b):
+            raise CheckpointFormatError(f"{path}: truncated (end-of-file address {self.eof} + base address {self.base_addr}, file has {len(b)} bytes)")
+
+    def _span(self, addr, size, what):
+        """Absolute offset of the file address `addr`, checked to hold `size` bytes."""
+        a = addr + self.base_addr
+        if addr < 0 or size < 0 or a + size > len(self.buf):
+            raise CheckpointFormatError(f"{what}: address {addr} + {size} bytes lies outside the file ({len(self.buf)} bytes)")
+        return a
 
     # ---- object headers ------------------------------------------------------------------------------------------
+    @_format_errors
     def messages(self, addr):
         """[(type, flags, payload bytes)] of the version-1 object header at addr (continuation blocks followed)."""
         b = self.buf
-        a = addr + self.base_addr
+        a = self._span(addr, 16, "object header")
         if b[a:a + 4] == b"OHDR":
             raise CheckpointFormatError("version-2 object header (file written with libver='latest'): not read")
         if b[a] != 1:
@@ -529,7 +553,7 @@ class H5File:
                     raise CheckpointFormatError(f"shared object-header message (type {mtype:#x}): not read")
                 if mtype == 0x0010:                                  # continuation: (address, length)
                     ca, cl = struct.unpack_from("<QQ", payload, 0)
-                    blocks.append((ca + self.base_addr, cl))
+                    blocks.append((self._span(ca, cl, "object-header continuation block"), cl))
                 out.append((mtype, mflags, payload))
                 p += 8 + msize
         return out
@@ -544,9 +568,10 @@ class H5File:
         e = b.index(b"\x00", data_addr + off)
         return b[data_addr + off:e].decode("utf-8")
 
+    @_format_errors
     def _btree_group(self, node_addr, heap_addr, out):
         b = self.buf
-        a = node_addr + self.base_addr
+        a = self._span(node_addr, 8, "group B-tree / symbol-table node")
         if b[a:a + 4] == b"SNOD":
             nsym = struct.unpack_from("<H", b, a + 6)[0]
             for i in range(nsym):
@@ -563,6 +588,7 @@ class H5File:
             child = struct.unpack_from("<Q", b, p + 8 + 16 * i)[0]
             self._btree_group(child, heap_addr, out)
 
+    @_format_errors
     def members(self, addr):
         """{link name: object-header address} of the group at addr, in name order (old-style groups only)."""
         for mtype, _f, pl in self.messages(addr):
@@ -628,6 +654,7 @@ class H5File:
         raise CheckpointFormatError(f"global heap object {index} not found in the collection at {coll_addr}")
 
     # ---- datasets --------------------------------------------------------------------------------------------------
+    @_format_errors
     def dataset(self, addr):
         dt = shape = layout = None
         for mtype, _f, pl in self.messages(addr):
@@ -656,7 +683,8 @@ class H5File:
             daddr, size = struct.unpack_from("<QQ", layout, 2)
             if daddr == _UNDEF:
                 return np.zeros(shape, dt.newbyteorder("="))          # never written: fill value 0
-            raw = self.buf[daddr + self.base_addr:daddr + self.base_addr + size]
+            a = self._span(daddr, size, f"contiguous data of the dataset at {addr}")
+            raw = self.buf[a:a + size]
         else:
             raise CheckpointFormatError("chunked dataset layout (chunking / compression): not read -- Keras writes contiguous datasets; "
                                         "h5repack -l CONTI converts")
@@ -665,6 +693,7 @@ class H5File:
         return np.frombuffer(raw, dtype=dt, count=n).reshape(shape).astype(dt.newbyteorder("="))
 
     # ---- attributes ------------------------------------------------------------------------------------------------
+    @_format_errors
     def attributes(self, addr):
         """{name: ndarray} for the attributes this reader understands (others are skipped: Keras' JSON configs may be variable-length)."""
         out = {}

@@ -3999,11 +3999,17 @@ struct BlockPlan {
 
 using namespace mkws;
 
+constexpr uint32_t kGuardCanary = 0x7FC00BADu;      // a quiet NaN with a recognisable payload
+
 struct mkws_embed {
   int max_batch = 0;
   int device = 0;
   float* d_weights = nullptr;     // packed device weights
   float* d_ws = nullptr;          // workspace
+  // guard-band mode (MKWS_EMBED_GUARD=<floats> in the environment at create; tests/test_guard_bands_gpu.py): the whole workspace starts as a NaN
+  // canary pattern and every carved sub-buffer is followed (the first one also preceded) by `guard` floats that no kernel may touch
+  size_t guard = 0;
+  std::vector<std::pair<size_t, size_t>> guard_spans;   // (offset into d_ws, floats)
   // workspace carve (floats per clip in parentheses)
   float *bufA = nullptr, *bufB = nullptr;   // block in/out ping-pong (16000)
   float *bufE = nullptr;                    // expand output (48000)
@@ -5279,41 +5285,77 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // cluster exchange buffers exist for handles that may ever use the kernel (the option can be set after create up to 64 clips)
   const size_t ncl = (max_batch <= 64) ? (size_t)cluster_count(max_batch, 1) : 0;
   const size_t cluster_floats = ncl * ((size_t)kClusterPMax * kClXc1 + (size_t)kClusterPMax * kClMaxTiles * 256 + (size_t)kNumBlocks * 2 * kClFlagRow);
-  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4 + cluster_floats;
+  {
+    const char* g = getenv("MKWS_EMBED_GUARD");
+    const long gv = g ? atol(g) : 0;
+    em->guard = gv > 0 ? (size_t)((gv + 63) / 64 * 64) : 0;      // whole 256-byte lines: the carve keeps its alignment
+  }
+  const size_t kCarves = 17;      // sub-buffers carved below (14, + 3 for handles that may run the cluster kernel)
+  const size_t ws = per_clip * (size_t)max_batch + 64 + 8 * 768 + pair_floats + 4 + cluster_floats + em->guard * (kCarves + 1);
   if (hipMalloc(reinterpret_cast<void**>(&em->d_ws), ws * sizeof(float)) != hipSuccess) {
     (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); delete em; return fail(MKWS_ERR_ALLOC, "hipMalloc(%zu) for workspace failed", ws * sizeof(float));
   }
+  if (em->guard && hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(em->d_ws), (int)kGuardCanary, ws) != hipSuccess) {
+    (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "filling the guarded workspace failed");
+  }
   float* w = em->d_ws;
+  if (em->guard) { em->guard_spans.emplace_back(0, em->guard); w += em->guard; }
+  // carve(n): the next n floats of the workspace (+ a guard band behind them in guard-band mode)
+  auto carve = [&](size_t n) {
+    float* p = w;
+    w += n;
+    if (em->guard) { em->guard_spans.emplace_back((size_t)(w - em->d_ws), em->guard); w += em->guard; }
+    return p;
+  };
   const size_t mb = (size_t)max_batch;
-  em->bufA = w; w += 16000 * mb; em->bufB = w; w += 16000 * mb; em->bufE = w; w += 48000 * mb; em->bufD = w; w += 18720 * mb;
-  em->sums = w; w += 1152 * mb; em->gate = w; w += 1152 * mb; em->gap = w; w += 1280 * mb; em->d0 = w; w += 2048 * mb; em->d1 = w; w += 2048 * mb;
-  em->splitk_ws = w; em->splitk_floats = 20480 * mb; w += 20480 * mb;
-  em->se_part = w; w += 9 * 48 * mb + 8 * 768;      // 8 slices x ceil(mb/16) groups x 768 floats <= 384*mb + 6144
+  em->bufA = carve(16000 * mb); em->bufB = carve(16000 * mb); em->bufE = carve(48000 * mb); em->bufD = carve(18720 * mb);
+  em->sums = carve(1152 * mb); em->gate = carve(1152 * mb); em->gap = carve(1280 * mb); em->d0 = carve(2048 * mb); em->d1 = carve(2048 * mb);
+  em->splitk_floats = 20480 * mb; em->splitk_ws = carve(20480 * mb);
+  em->se_part = carve(9 * 48 * mb + 8 * 768);      // 8 slices x ceil(mb/16) groups x 768 floats <= 384*mb + 6144
   {
     const size_t np = (size_t)pair_count(max_batch, em->pair_mt);
-    em->pair_xc1 = w; w += np * 2 * kPairXc1;
-    em->pair_xd = w; w += np * 2 * kPairXdAll * 2 * 256;
-    em->pair_flags = reinterpret_cast<int*>(w); w += np * 4;                          // mbconv_pair_kernel: [pairs][2 exchanges][2 halves]
-    em->pair_chain_flags = reinterpret_cast<int*>(w); w += np * 4 * kPairChainMax;    // mbconv_pair_chain_kernel: [pairs][blocks][2][2]
+    em->pair_xc1 = carve(np * 2 * kPairXc1);
+    em->pair_xd = carve(np * 2 * kPairXdAll * 2 * 256);
+    // mbconv_pair_kernel: [pairs][2 exchanges][2 halves] | mbconv_pair_chain_kernel: [pairs][blocks][2][2] | the error word (cleared with the flags)
+    em->pair_flags = reinterpret_cast<int*>(carve(np * 4 + np * 4 * kPairChainMax + 4));
+    em->pair_chain_flags = em->pair_flags + np * 4;
     em->pair_flag_count = np * 4 + np * 4 * kPairChainMax;
-    em->pair_err_dev = em->pair_flags + em->pair_flag_count; w += 4;                   // cleared with the flags
+    em->pair_err_dev = em->pair_flags + em->pair_flag_count;
     if (hipMemset(em->pair_flags, 0, (em->pair_flag_count + 4) * sizeof(int)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&em->pair_err_host), 64, hipHostMallocMapped) != hipSuccess) {
       (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); (void)hipFree(em->d_ws); delete em; return fail(MKWS_ERR_HIP, "setting up the pair flags failed");
     }
     *em->pair_err_host = 0;
     if (ncl > 0) {
-      em->cl_xc1 = w; w += ncl * kClusterPMax * kClXc1;
-      em->cl_xd = w; w += ncl * kClusterPMax * kClMaxTiles * 256;
-      em->cl_flags = reinterpret_cast<int*>(w); w += ncl * 2 * kClFlagRow * kNumBlocks;
+      em->cl_xc1 = carve(ncl * kClusterPMax * kClXc1);
+      em->cl_xd = carve(ncl * kClusterPMax * kClMaxTiles * 256);
+      em->cl_flags = reinterpret_cast<int*>(carve(ncl * 2 * kClFlagRow * kNumBlocks));
       em->cl_flag_count = ncl * 2 * kClFlagRow * kNumBlocks;
       if (hipMemset(em->cl_flags, 0, em->cl_flag_count * sizeof(int)) != hipSuccess) {
         (void)hipFree(em->d_weights); (void)hipFree(em->d_chain_tab); (void)hipFree(em->d_ws); (void)hipHostFree(em->pair_err_host); delete em; return fail(MKWS_ERR_HIP, "clearing the cluster flags failed");
       }
     }
   }
+  if ((size_t)(w - em->d_ws) > ws || em->guard_spans.size() > kCarves + 1) {
+    const size_t used = (size_t)(w - em->d_ws), bands = em->guard_spans.size();
+    mkws_embed_destroy(em);
+    return fail(MKWS_ERR_ALLOC, "workspace carve overran its allocation (%zu of %zu floats, %zu guard bands)", used, ws, bands);
+  }
   *out = em;
   return MKWS_OK;
+}
+
+// Guard-band mode: how many guard words no longer hold the canary (synchronises the device; 0 when the mode is off)
+static int guard_violations(const mkws_embed* em) {
+  if (!em->guard) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(MKWS_ERR_HIP, "device synchronisation failed");
+  std::vector<uint32_t> host(em->guard);
+  long bad = 0;
+  for (const auto& sp : em->guard_spans) {
+    if (hipMemcpy(host.data(), em->d_ws + sp.first, sp.second * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return fail(MKWS_ERR_HIP, "reading a guard band failed");
+    for (size_t i = 0; i < sp.second; ++i) bad += host[i] != kGuardCanary;
+  }
+  return bad > 0x7fffffff ? 0x7fffffff : (int)bad;
 }
 
 void mkws_embed_destroy(mkws_embed* em) {
@@ -5385,6 +5427,9 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
   if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;
   if (strcmp(name, "pair_degraded") == 0) return em->pair_degraded;
+  if (strcmp(name, "guard_floats") == 0) return (int)em->guard;
+  if (strcmp(name, "guard_bands") == 0) return (int)em->guard_spans.size();
+  if (strcmp(name, "guard_violations") == 0) return guard_violations(em);
   // nonzero: a launch that has ALREADY EXECUTED recorded a failed exchange and the handle has not been healed yet (the next forward /
   // tap / profile call heals it and returns MKWS_ERR_EXCHANGE).  A host-mapped word: no synchronisation.  This is what hipGraph users
   // poll -- a replay does not pass through mkws_embed_forward, so "pair_degraded" cannot move under it.

@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const float* __restri
   const bool ok = c0 < C;
   const int cc = ok ? c0 : 0;
   // the taps of this thread's channel quad stay in registers; a row's KS*KS input loads are issued together (clamped addresses, the
-  // padding taps multiply by zero), so a thread pays one memory latency per row, not one per tap
+  // padding taps are replaced by zero after the load), so a thread pays one memory latency per row, not one per tap
   f32x4 wv[KS * KS];
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t) wv[t] = *reinterpret_cast<const f32x4*>(W + (size_t)t * C + cc);
@@ -680,7 +680,6 @@ __global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const float* __restri
     const int b = p / Ho;
     const float* xb = X + (size_t)b * H * Wd * C + cc;
     f32x4 xv[KS * KS];
-    float m[KS * KS];
 #pragma unroll
     for (int ii = 0; ii < KS; ++ii)
 #pragma unroll
@@ -688,12 +687,14 @@ __global__ __launch_bounds__(256) void dw_fwd_stats_kernel(const float* __restri
         const int ih = oh * s - pt + ii, iw = ow * s - pl + jj;
         const bool in = ih >= 0 && ih < H && iw >= 0 && iw < Wd;
         const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= Wd ? Wd - 1 : iw);
-        xv[ii * KS + jj] = *reinterpret_cast<const f32x4*>(xb + ((size_t)ihc * Wd + iwc) * C);
-        m[ii * KS + jj] = in ? 1.0f : 0.0f;
+        const f32x4 ld = *reinterpret_cast<const f32x4*>(xb + ((size_t)ihc * Wd + iwc) * C);
+        // a padding tap is SELECTED away, not multiplied by zero: the clamped address may hold a non-finite activation, and Inf * 0 = NaN
+        // would leak into an output that dw_fwd_kernel (which skips the tap) keeps finite
+        xv[ii * KS + jj] = in ? ld : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < KS * KS; ++q) acc += xv[q] * (wv[q] * m[q]);      // same products in the same order as dw_fwd_kernel (skipped taps add +0)
+    for (int q = 0; q < KS * KS; ++q) acc += xv[q] * wv[q];               // same products in the same order as dw_fwd_kernel (padding taps add +-0)
     z[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (live) {
       *reinterpret_cast<f32x4*>(Z + (size_t)r * C + c0) = acc;

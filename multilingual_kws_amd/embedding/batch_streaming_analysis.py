@@ -5,10 +5,12 @@ on each window in a Python loop and runs one full model per keyword.  Here one c
 window's features on the GPU with per-frame FFT / filterbank work shared across the 49x-overlapping
 windows (mkws_frontend_stream_f32; bit-identical to per-window calls), the embedding is computed once and
 any number of few-shot heads are applied to it.  The detector (SingleTargetRecognizeCommands) stays on the
-host.  Accuracy bookkeeping against ground-truth files (accuracy_utils / tpr_fpr) is out of scope."""
+host.  StreamTarget / eval_stream_test (:188-241) are the per-keyword entry points run.py drives; multi_keyword_detections is
+their multi-keyword form on ONE shared embedding pass (run.py:89-152 runs one full model per keyword)."""
 import os
+import pickle
 from dataclasses import dataclass
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
@@ -213,9 +215,20 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
         # the stream on the healed handles (the first run() of the repeat re-captures; a healed handle cannot fail again).  A heal in
         # the middle of the stream -- by a re-capture or by the eager call of a ragged tail -- means earlier batches were poisoned.
         torch.cuda.synchronize(emb_model.device)
-        if _retry and (degraded() != degraded0 or any(g.exchange_failed() or g.heals != h0 for g, h0 in graphs_used.items())):
+        if degraded() != degraded0 or any(g.exchange_failed() or g.heals != h0 for g, h0 in graphs_used.items()):
+            if not _retry:
+                # the repeat ran with every handle of the stream off the exchange kernels (below): nothing left that could fail this way
+                from .._lib import MkwsError
+                raise MkwsError("an in-kernel exchange failed again while the stream was being repeated on the single-workgroup kernels")
             import warnings
             warnings.warn("multilingual_kws_amd: an in-kernel exchange failed during a graph replay; repeating the stream on the single-workgroup kernels", RuntimeWarning)
+            # EVERY serving-lane replica leaves the exchange kernels before the repeat, not only the handle whose error word was set: a
+            # replica that fails during the repeat would return its NaN rows with nobody looking
+            for e in [emb_model] + list(getattr(emb_model, "_replicas", [])):
+                e.get_option("exchange_error") and e.forward(specs[:1])        # (heals: the wrapper repeats the call that reports the error)
+                e.set_option("fuse_pair", 0)
+                e.set_option("fuse_cluster", 0)
+            _BatchGraph.forget(emb_model)                                       # graphs captured on the old plan
             return streaming_inferences(models, model_settings, audio, sample_rate, clip_duration_ms, clip_stride_ms, batch_windows, max_chunk_length_sec,
                                         use_graph, _retry=False)
     res = [torch.cat(o).cpu().numpy() if o else np.zeros((0, 3), np.float32) for o in outs]
@@ -334,3 +347,102 @@ def calculate_streaming_accuracy(model, model_settings, flag_list, existing_infe
             res_thresh[threshold] = detect(inferences, FLAGS, threshold, sample_rate, data_samples=audio.shape[0])
         results.append((FLAGS, res_thresh))
     return results, inferences
+
+
+@dataclass
+class StreamTarget:
+    """Reference :188-195 -- one keyword's streaming evaluation: where its model is, what to run it on, where results go."""
+    target_lang: str
+    target_word: str
+    model_path: os.PathLike
+    stream_flags: List[StreamFlags]
+    destination_result_pkl: Optional[os.PathLike] = None
+    destination_result_inferences: Optional[os.PathLike] = None
+
+
+def eval_stream_test(st: StreamTarget, live_model=None):
+    """Reference :198-241.  -> {target_word: [(FLAGS, {threshold: (found_words, found_words_w_confidences)}), ...]}, or None (after a
+    message) when destination_result_pkl already exists.  The model is `live_model` or TransferLearnedModel.load(st.model_path) (the
+    directory transfer_learn's model.save() wrote -- the counterpart of tf.keras.models.load_model).  Results are pickled to
+    destination_result_pkl and the raw per-window softmax outputs saved (np.save) to destination_result_inferences when those are
+    given; inferences found there are re-used instead of being recomputed.  (The reference reads them back from the PICKLE path --
+    np.load(st.destination_result_pkl), a file it has just established does not exist -- so its re-use branch cannot run; here the
+    branch loads the file it tested for.)"""
+    if live_model is not None:
+        model = live_model
+    else:
+        from .transfer_learning import TransferLearnedModel
+        model = TransferLearnedModel.load(os.fspath(st.model_path))
+    model_settings = input_data.standard_microspeech_model_settings(label_count=3)
+
+    if st.destination_result_pkl is not None and os.path.isfile(st.destination_result_pkl):
+        print("results already present", st.destination_result_pkl, flush=True)
+        return
+    loaded_inferences = None
+    if st.destination_result_inferences is not None and os.path.isfile(st.destination_result_inferences):
+        print("inferences already present", flush=True)
+        loaded_inferences = np.load(st.destination_result_inferences)
+
+    results = {}
+    results[st.target_word], inferences = calculate_streaming_accuracy(model, model_settings, st.stream_flags, loaded_inferences)
+
+    if st.destination_result_pkl is not None:
+        print("SAVING results TO\n", st.destination_result_pkl)
+        with open(st.destination_result_pkl, "wb") as fh:
+            pickle.dump(results, fh)
+    if loaded_inferences is None and st.destination_result_inferences is not None:
+        print("SAVING inferences TO\n", st.destination_result_inferences, flush=True)
+        np.save(st.destination_result_inferences, inferences)
+    return results
+
+
+def multi_keyword_detections(keywords, models, wav, detection_threshold=0.9, inference_chunk_len_seconds=1200, groundtruth=None,
+                             average_window_duration_ms=100, suppression_ms=500, write_detections=None):
+    """The detections dict of run.py:89-152 for N keywords from ONE pass over the recording.
+
+    The reference loads one full Keras model per keyword and repeats the window loop, the micro-frontend and the EfficientNet forward
+    for each (one child process per keyword); here `models` (TransferLearnedModels sharing one embedding, transfer_learning.
+    load_models_shared) are N 18.5 k-parameter heads on one embedding pass (streaming_inferences), and each keyword's detector runs over
+    its own head's outputs.  Per keyword the detections are exactly what eval_stream_test yields for StreamFlags(detection_thresholds=
+    [detection_threshold], average_window_duration_ms=100, suppression_ms=500, max_chunk_length_sec=inference_chunk_len_seconds);
+    they are merged and sorted by time (stable, like the reference's sorted()).  -> dict(keywords=..., detections=[dict(keyword, time_ms,
+    confidence, groundtruth)], min_threshold=...): groundtruth "ng" without a ground-truth file, otherwise tpr_fpr.get_groundtruth's
+    classification against its rows `keyword,time_ms` (as shipped: first keyword only).  Also written as JSON to write_detections."""
+    import json
+    keywords, models = list(keywords), list(models)
+    if len(models) != len(keywords) or len(set(keywords)) != len(keywords):
+        raise ValueError(f"discrepancy: {len(models)} models provided for {len(set(keywords))} keywords")
+    if inference_chunk_len_seconds <= 0:
+        raise ValueError("inference_chunk_len_seconds must be positive")
+    with open(wav, "rb") as f:
+        audio, sample_rate = input_data.decode_wav(f.read())
+    model_settings = input_data.standard_microspeech_model_settings(label_count=3)
+    per_keyword = [None] * len(models)
+    by_embedding = {}
+    for i, m in enumerate(models):                                  # one pass per distinct embedding (normally one)
+        by_embedding.setdefault(id(m.embedding), []).append(i)
+    for idxs in by_embedding.values():
+        got = streaming_inferences([models[i] for i in idxs], model_settings, audio, sample_rate, 1000, 20,
+                                   max_chunk_length_sec=inference_chunk_len_seconds)
+        for i, inf in zip(idxs, got):
+            per_keyword[i] = inf
+    unsorted_detections = []
+    for keyword, inferences in zip(keywords, per_keyword):
+        flags = StreamFlags(wav=wav, ground_truth=groundtruth, target_keyword=keyword, detection_thresholds=[detection_threshold],
+                            average_window_duration_ms=average_window_duration_ms, suppression_ms=suppression_ms, time_tolerance_ms=750,
+                            max_chunk_length_sec=inference_chunk_len_seconds)
+        unsorted_detections.extend(detect(inferences, flags, detection_threshold, sample_rate, data_samples=audio.shape[0])[1])
+    detections_with_confidence = sorted(unsorted_detections, key=lambda d: d[1])
+    if groundtruth is None:
+        detections_with_confidence = [dict(keyword=d[0], time_ms=d[1], confidence=d[2], groundtruth="ng") for d in detections_with_confidence]
+    else:
+        import csv
+        from .tpr_fpr import get_groundtruth
+        with open(groundtruth, "r") as fh:
+            groundtruth_data = [(row[0], float(row[1])) for row in csv.reader(fh) if row]
+        detections_with_confidence = get_groundtruth(detections_with_confidence, keywords, groundtruth_data)
+    detections = dict(keywords=keywords, detections=detections_with_confidence, min_threshold=detection_threshold)
+    if write_detections is not None:
+        with open(write_detections, "w") as fh:
+            json.dump(detections, fh)
+    return detections

@@ -283,18 +283,53 @@ class ClipDataset:
         own, n = self.owner, len(self.files)
         if self._repeat:
             # endless stream (train_ds.shuffle().repeat().batch()): reshuffled passes cut into full batches
-            buf = np.zeros(0, dtype=np.int64)
+            groups = BatchGroups(self)
             while True:
-                buf = np.concatenate([buf, (own.rng.permutation(n) if self._shuffle else np.arange(n)).astype(np.int64)])
-                while len(buf) >= bs:
-                    yield own._make_batch(self, buf[:bs], [])
-                    buf = buf[bs:]
+                yield groups.take(1)
         order = own.rng.permutation(n) if self._shuffle else np.arange(n)
         todo = [("file", int(i)) for i in order] + [("sil", -1)] * self.extra_silence + [("unk", -1)] * self.extra_unknown
         for s in range(0, len(todo), bs):
             chunk = todo[s:s + bs]
             yield own._make_batch(self, np.asarray([i for k, i in chunk if k == "file"], dtype=np.int64),
                                   [k for k, _ in chunk if k != "file"])
+
+
+class BatchGroups:
+    """The endless training stream of a ClipDataset (`.shuffle().repeat().batch(bs)`), handed out G batches at a time.
+
+    The few-shot fine-tune trains a head on a FROZEN embedding (transfer_learning.py:38-53 in the reference), so the forward pass of
+    batch t + 1 does not depend on the optimizer step of batch t.  take(g) makes the host draws of the next g batches -- the same
+    draws, in the same order, as g consecutive single batches -- and assembles them with ONE augmentation launch, ONE micro-frontend
+    launch and ONE SpecAugment launch over g * bs clips (every one of those kernels is per-clip, so the clips are the ones the
+    step-by-step stream produces, bit for bit).  The caller runs one embedding forward over the group and then g optimizer steps,
+    each on its own bs rows."""
+
+    def __init__(self, ds):
+        if not ds._repeat:
+            raise ValueError("BatchGroups needs an endless dataset: .repeat() before .batch()")
+        self.ds, self.bs = ds, ds._batch or 1
+        self.buf = np.zeros(0, dtype=np.int64)
+
+    def _next_indices(self):
+        own, n = self.ds.owner, len(self.ds.files)
+        if n == 0:
+            raise ValueError("cannot draw batches from an empty file list")
+        if len(self.buf) < self.bs:         # reshuffled passes cut into full batches
+            k = -(-(self.bs - len(self.buf)) // n)
+            passes = np.tile(np.arange(n, dtype=np.int64), (k, 1))
+            if self.ds._shuffle:
+                # k passes in ONE generator call: permuted() shuffles the rows one after the other with the draws of k consecutive
+                # rng.permutation(n) calls (same values, same generator state afterwards -- tests/test_host_logic.py); with 5 training
+                # clips and 512-clip batches the 103 separate calls + concatenations of rounds 1-4 were 0.37 ms of host time per batch
+                passes = own.rng.permuted(passes, axis=1)
+            self.buf = np.concatenate([self.buf, passes.reshape(-1)])
+        idx, self.buf = self.buf[:self.bs], self.buf[self.bs:]
+        return idx
+
+    def take(self, g=1):
+        """-> (spectrograms [g * bs, frames, channels, 1], label ids [g * bs]); rows [j * bs, (j + 1) * bs) are batch j."""
+        own = self.ds.owner
+        return own._assemble(self.ds, [own._draw_batch(self.ds, self._next_indices(), []) for _ in range(int(g))])
 
 
 class AudioDataset:
@@ -434,8 +469,11 @@ class AudioDataset:
 
     # -- batch assembly ------------------------------------------------------------------------------
     def _make_batch(self, ds, src_idx, extras):
-        import torch
-        n = self.model_settings["desired_samples"]
+        return self._assemble(ds, [self._draw_batch(ds, src_idx, extras)])
+
+    def _draw_batch(self, ds, src_idx, extras):
+        """Host side of one batch: EVERY random draw (augmentation items, labels, SpecAugment masks), nothing on the device.
+        -> (items, labels, masks or None)."""
         nf, B = len(src_idx), len(src_idx) + len(extras)
         items = np.zeros(B, dtype=_ITEM_DTYPE)
         labels = np.zeros(B, dtype=np.int64)
@@ -466,10 +504,24 @@ class AudioDataset:
             else:                  # _random_unknown
                 items[j]["bank"], items[j]["src"] = 1, int(self.rng.integers(0, len(self.unknown_files)))
                 labels[j] = self._label_id(UNKNOWN_WORD_LABEL)
+        masks = self._draw_specaug_masks(B) if ds.is_training else None
+        return items, labels, masks
+
+    def _assemble(self, ds, drawn):
+        """Device side of one batch -- or of several consecutive ones (BatchGroups): the drawn tables concatenated, ONE asynchronous
+        copy (_HostStager), ONE launch each of augmentation, micro-frontend and SpecAugment over all their clips."""
+        import torch
+        n = self.model_settings["desired_samples"]
+        items = drawn[0][0] if len(drawn) == 1 else np.concatenate([d[0] for d in drawn])
+        labels = drawn[0][1] if len(drawn) == 1 else np.concatenate([d[1] for d in drawn])
+        masks = None
+        if any(d[2] is not None for d in drawn):
+            width = max(d[2].shape[1] for d in drawn if d[2] is not None)
+            masks = np.concatenate([d[2] if d[2] is not None else np.zeros((len(d[0]), width), np.int32) for d in drawn])     # size 0 = unused
+        B = len(items)
         need_unknown = bool((items["bank"] == 1).any())
         L = _lib.lib()
-        # host tables of this batch: every draw happens BEFORE the first launch, then ONE asynchronous copy (_HostStager)
-        masks = self._draw_specaug_masks(B) if ds.is_training else None
+        # host tables: every draw happened BEFORE the first launch, now ONE asynchronous copy (_HostStager)
         use_masks = masks is not None and bool(masks.any())
         if getattr(self, "_stager", None) is None:
             self._stager = _HostStager(self.device)

@@ -96,6 +96,134 @@ class TransferLearnedModel:
         return cls(emb, Head(i, h, c, max_batch=max_batch, params=z["params"]), blob, meta["base_model_path"])
 
 
+def load_models_shared(model_paths, max_batch=1024):
+    """[TransferLearnedModel.save() directories] -> [TransferLearnedModel] that share ONE embedding handle wherever their base weights are
+    the same bytes (the usual case: N few-shot heads on one multilingual embedding, run.py's `modelpaths`).  Models with other base
+    weights get their own handle.  Multi-keyword serving (batch_streaming_analysis.streaming_inferences / multi_keyword_detections)
+    runs one embedding pass per distinct handle."""
+    import hashlib
+    shared, out = {}, []
+    for path in model_paths:
+        path = os.fspath(path)
+        meta = json.load(open(os.path.join(path, "model.json")))
+        base = meta["base_model_path"]
+        if not str(base).startswith("synthetic") and not os.path.isabs(base):
+            base = os.path.join(path, base)
+        cut = meta.get("base_model_output", "dense_2")
+        if str(base).startswith("synthetic"):
+            key = (str(base), cut)
+        else:       # content, not location: every saved model carries its own copy of the base weights
+            h = hashlib.sha256()
+            for root, _, files in sorted(os.walk(base)):
+                for f in sorted(files):
+                    h.update(f.encode())
+                    h.update(open(os.path.join(root, f), "rb").read())
+            key = (h.hexdigest(), cut)
+        if key not in shared:
+            shared[key] = load_base_model(base, max_batch, cut)
+        emb, blob = shared[key]
+        z = np.load(os.path.join(path, "head.npz"))
+        i, h_, c = [int(v) for v in z["dims"]]
+        out.append(TransferLearnedModel(emb, Head(i, h_, c, max_batch=max_batch, params=z["params"], device=emb.device), blob, meta["base_model_path"]))
+    return out
+
+
+FORWARD_CLIPS = 1024     # clips per embedding forward of the frozen phase (the plan the headline benchmark runs: 0.45 ms per 512 clips
+                         # against 0.63 ms on a 512-clip handle, profiles/r04_notes.md)
+
+
+def steps_per_forward(batch_size, forward_clips=None):
+    """Optimizer steps whose batches share one forward pass of the frozen embedding."""
+    return max(1, int(FORWARD_CLIPS if forward_clips is None else forward_clips) // max(int(batch_size), 1))
+
+
+class FrozenHeadTrainer:
+    """The first phase of transfer_learn (reference transfer_learning.py:38-93: `embedding.trainable = False`, head fitted with Adam)
+    as a stream of optimizer steps that does not pay for small forward passes.
+
+    The embedding is frozen, so the forward pass of batch t + 1 is independent of the head update of step t.  G = steps_per_forward
+    consecutive batches are therefore drawn together (input_data.BatchGroups: the same draws in the same order as one batch at a time),
+    augmented / featurised / SpecAugmented by ONE launch each and embedded by ONE forward pass over G * batch_size clips on a handle
+    planned for that size; then the G optimizer steps run one after the other, each on its own batch_size rows and with its own
+    all-reduce under torch.distributed -- the semantics of parallel.dp_step, unchanged.  With overlap=True the optimizer steps (a few
+    small launches each, nowhere near filling the chip) go to a second stream and run under the NEXT group's augmentation, frontend and
+    embedding kernels; two embedding buffers alternate, events order producer and consumer.  Measured on one MI355X at 512 clips per
+    step (profiles/r05_notes.md): one forward per step 663.6 k clips/s, two steps per forward 853.9 k, + the second stream 844.2 k --
+    the embedding kernels fill the chip, the head's launches only take turns with them -- so overlap is off by default.
+
+    step() performs exactly one optimizer step and returns its [sum of row losses, #correct] (summed over ranks) as a device tensor
+    that is rewritten by the next step() and lives on the trainer's stream: add it up with accumulate(), or read it after finish()
+    (which joins the side stream; call it before reading head parameters elsewhere)."""
+
+    def __init__(self, embedding, head, train_ds, batch_size, lr, group=None, overlap=False):
+        import torch
+        self.embedding, self.head, self.lr = embedding, head, lr
+        self.bs = int(batch_size)
+        self.G = max(1, min(int(group) if group is not None else steps_per_forward(self.bs), embedding.max_batch // self.bs))
+        self.groups = train_ds if isinstance(train_ds, input_data.BatchGroups) else input_data.BatchGroups(train_ds)
+        if self.groups.bs != self.bs:
+            raise ValueError(f"dataset is batched by {self.groups.bs}, trainer by {self.bs}")
+        self.device = embedding.device
+        self.overlap = bool(overlap)
+        self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        nbuf = 2 if self.overlap else 1
+        self.emb = [torch.empty((self.G * self.bs, embedding.output_dim), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+        self.consumed = [None] * nbuf            # event: every optimizer step that reads emb[k] has run
+        self.k, self.j, self.g, self.cur = -1, 0, 0, None
+        self.forwards = 0
+
+    def _refill(self, g):
+        """Next group of g batches: draws + one launch chain on the caller's stream, hand-over to the optimizer stream."""
+        import torch
+        self.k = (self.k + 1) % len(self.emb)
+        main = torch.cuda.current_stream(self.device)
+        spec, labels = self.groups.take(g)
+        labels = labels.to(torch.int32)
+        if self.consumed[self.k] is not None:
+            main.wait_event(self.consumed[self.k])           # the steps of two groups ago have finished with this buffer
+        emb = self.embedding.forward(spec, out=self.emb[self.k][:g * self.bs])
+        self.forwards += 1
+        if self.overlap:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            self.side.wait_event(ready)
+            labels.record_stream(self.side)
+        self.cur, self.g, self.j = (emb, labels), g, 0
+
+    def step(self, group_limit=None):
+        """One optimizer step.  group_limit: steps left before the caller needs the head (end of an epoch): a new group is cut to it."""
+        import torch
+        from .. import parallel
+        if self.j >= self.g:
+            self._refill(self.G if group_limit is None else max(1, min(self.G, int(group_limit))))
+        emb, labels = self.cur
+        lo, hi = self.j * self.bs, (self.j + 1) * self.bs
+        self.j += 1
+        if not self.overlap:
+            return parallel.dp_step(self.head, emb[lo:hi], labels[lo:hi], lr=self.lr)
+        with torch.cuda.stream(self.side):
+            stats = parallel.dp_step(self.head, emb[lo:hi], labels[lo:hi], lr=self.lr)
+            if self.j >= self.g:
+                ev = self.consumed[self.k] = self.consumed[self.k] or torch.cuda.Event()
+                ev.record(self.side)
+        return stats
+
+    def accumulate(self, acc, stats):
+        """acc += stats on the stream the optimizer steps run on (the statistics tensor is rewritten by the next step)."""
+        import torch
+        if self.overlap:
+            with torch.cuda.stream(self.side):
+                acc += stats.to(acc.dtype)
+        else:
+            acc += stats.to(acc.dtype)
+
+    def finish(self):
+        """The caller's stream waits for every optimizer step issued so far."""
+        import torch
+        if self.overlap:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
 def transfer_learn(
     target,
     train_files,
@@ -126,7 +254,8 @@ def transfer_learn(
         raise ValueError('backprop_into_embedding=True is implemented for base_model_output="dense_2" (the only value the reference\'s callers pass)')
     import torch
     rank, world = parallel.rank(), parallel.world_size()
-    embedding, blob = load_base_model(base_model_path, max_batch=max(batch_size, 64), base_model_output=base_model_output)
+    group = steps_per_forward(batch_size)                # optimizer steps per forward pass of the frozen embedding (FrozenHeadTrainer)
+    embedding, blob = load_base_model(base_model_path, max_batch=max(batch_size * group, 64), base_model_output=base_model_output)
     feat = embedding.output_dim
     head_seed = None if seed is None else int(seed)
     p0 = glorot_uniform_params(feat, 18, CATEGORIES, head_seed)
@@ -153,7 +282,8 @@ def transfer_learn(
     val_ds = init_val_ds.batch(batch_size)
 
     steps_per_epoch = batch_size * num_batches          # (sic) -- reference :89
-    train_iter = iter(train_ds)
+    train_groups = input_data.BatchGroups(train_ds)      # ONE stream of batches for both phases (the draws continue across them)
+    frozen = FrozenHeadTrainer(embedding, head, train_groups, batch_size, primary_lr, group=group)
     phases = [("head", primary_lr)]
     if backprop_into_embedding:
         # reference :94-112: `layer.trainable = True` on the nested embedding Model un-freezes ALL of its layers
@@ -172,12 +302,15 @@ def transfer_learn(
         for epoch in range(num_epochs):
             acc_stats = torch.zeros(2, dtype=torch.float64, device=embedding.device)
             seen = 0
-            for _ in range(steps_per_epoch):
-                spec, labels = next(train_iter)
+            for step_i in range(steps_per_epoch):
                 if trainer is None:
-                    emb = embedding.forward(spec)
-                    stats = parallel.dp_step(head, emb, labels, lr=lr)
-                elif world == 1:
+                    # frozen embedding: G batches per forward pass, never across the end of an epoch (validation reads the head there)
+                    stats = frozen.step(group_limit=steps_per_epoch - step_i)
+                    frozen.accumulate(acc_stats, stats)
+                    seen += batch_size * world
+                    continue
+                spec, labels = train_groups.take(1)
+                if world == 1:
                     nb = spec.shape[0]
                     masks = {name: audio_dataset.rng.uniform(0, 1, nb) >= DROP_CONNECT_RATE * bi / len(BLOCKS)
                              for bi, (name, cin, cout, k, s, e) in enumerate(BLOCKS) if s == 1 and cin == cout}
@@ -198,6 +331,7 @@ def transfer_learn(
                     trainer.adam_step(lr=lr, grad_scale=1.0 / world)
                 acc_stats += stats.to(torch.float64)
                 seen += spec.shape[0] * world
+            frozen.finish()
             tl, ta = (acc_stats / max(seen, 1)).tolist()
             if trainer is not None:      # validation runs the inference kernels on the current weights (moving statistics)
                 blob = trainer.blob()

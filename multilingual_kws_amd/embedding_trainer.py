@@ -569,6 +569,12 @@ class TrainStepGraph:
         self._tape = log
         self._tape_stream = _lib.current_stream_ptr().value
         self._tape_pool = tr._pool          # the buffers the tape names: held here, so they outlive a trainer that moves on to another batch size
+        self._tape_options = self._options()
+
+    def _options(self):
+        """The trainer switches that decide WHICH launches a step is made of: a tape recorded under other values replays the old step."""
+        tr = self.tr
+        return (bool(tr.overlap_wgrad), int(tr.fuse_bn_stats), int(tr.wgrad_fork_every))
 
     def _body(self, overlap=None):
         tr, head = self.tr, self.head
@@ -606,14 +612,18 @@ class TrainStepGraph:
             self.graph.replay()
             return self.stats
         if self._tape is not None:
-            if _lib.current_stream_ptr().value != self._tape_stream or self.tr._pool is not self._tape_pool:
-                # the caller moved to another stream, or the trainer ran another batch size in between (its buffer pool was rebuilt): the
-                # tape names the old stream / buffers.  Recording runs the step, so this one is done.
-                self._record()
-                return self.stats
-            for f, a in self._tape:
-                rc = f(*a)
-                if rc is not None and rc < 0:
-                    _lib.check(rc)
+            # raw ctypes calls: they launch on the CURRENT device's context, so make the trainer's device current as the eager wrappers do
+            with torch.cuda.device(self.tr.device):
+                if (_lib.current_stream_ptr().value != self._tape_stream or self.tr._pool is not self._tape_pool
+                        or self._options() != self._tape_options):
+                    # the caller moved to another stream, the trainer ran another batch size in between (its buffer pool was rebuilt), or one
+                    # of its launch-plan switches changed: the tape names the old stream / buffers / launches.  Recording runs the step,
+                    # so this one is done.
+                    self._record()
+                    return self.stats
+                for f, a in self._tape:
+                    rc = f(*a)
+                    if rc is not None and rc < 0:
+                        _lib.check(rc)
             return self.stats
         return self._body()

@@ -246,6 +246,45 @@ def test_h5_errors(tmp_path, golden_dir):
         ci.import_h5(os.path.join(golden_dir, "keras_h5", "weights.h5"))
 
 
+def test_h5_corruption_fails_as_a_format_error(tmp_path, golden_dir):
+    """Truncation behind a user block (addresses are relative to the base address: a 512-byte user block in front of a file cut by 100
+    bytes passed the old check `eof > len + base`), and object / continuation / data addresses pointing outside the file: always
+    CheckpointFormatError, never struct.error / IndexError."""
+    import struct
+    raw = open(os.path.join(golden_dir, "keras_h5", "weights.h5"), "rb").read()
+    assert raw[:8] == ci.HDF5_SIGNATURE and raw[8] == 0
+    blocked = bytearray(b"\x00" * 512 + raw)
+    struct.pack_into("<Q", blocked, 512 + 24, 512)                  # base address = the user block's size
+    ok = tmp_path / "userblock.h5"
+    ok.write_bytes(bytes(blocked))
+    plain, moved = ci.H5File(os.path.join(golden_dir, "keras_h5", "weights.h5")), ci.H5File(str(ok))
+    assert moved.base_addr == 512 and list(moved.members(moved.root)) == list(plain.members(plain.root))
+    cut = tmp_path / "userblock_cut.h5"
+    cut.write_bytes(bytes(blocked[:-100]))
+    with pytest.raises(ci.CheckpointFormatError, match="truncated"):
+        ci.H5File(str(cut))
+    # addresses outside the file
+    f = ci.H5File(os.path.join(golden_dir, "keras_h5", "weights.h5"))
+    for bad in (len(raw) - 4, len(raw) + 1000, 1 << 40):
+        with pytest.raises(ci.CheckpointFormatError):
+            f.messages(bad)
+        with pytest.raises(ci.CheckpointFormatError):
+            f.dataset(bad)
+        with pytest.raises(ci.CheckpointFormatError):
+            f.members(bad)
+    # a file whose root object-header address was overwritten, and one cut off behind the superblock with the end-of-file address patched
+    broken = bytearray(raw)
+    struct.pack_into("<Q", broken, 24 + 32 + 8, len(raw) + 12345)
+    (tmp_path / "root.h5").write_bytes(bytes(broken))
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.load_h5(str(tmp_path / "root.h5"))
+    short = bytearray(raw[:len(raw) // 3])
+    struct.pack_into("<Q", short, 24 + 16, len(short))
+    (tmp_path / "short.h5").write_bytes(bytes(short))
+    with pytest.raises(ci.CheckpointFormatError):
+        ci.load_h5(str(tmp_path / "short.h5"))
+
+
 H5PY_PYTHON = "/opt/conda/bin/python3.9"
 
 

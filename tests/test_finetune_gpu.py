@@ -155,3 +155,109 @@ def test_dp_step_over_rccl_on_the_device_head():
         assert torch.equal(out[0], x)
     finally:
         dist.destroy_process_group()
+
+
+def _fresh(data, seed, B):
+    from multilingual_kws_amd.embedding import input_data
+    ms = input_data.standard_microspeech_model_settings(3)
+    ds = input_data.AudioDataset(ms, ["target"], data["bg_dir"], data["unknown"], unknown_percentage=50.0,
+                                 spec_aug_params=input_data.SpecAugParams(percentage=80), seed=seed)
+    return ds, ds.init_single_target(input_data.AUTOTUNE, data["train"], is_training=True).shuffle(1000).repeat().batch(B)
+
+
+def test_grouped_batches_are_the_step_by_step_batches(data):
+    """input_data.BatchGroups.take(G): the same clips, labels and SpecAugment masks, in the same order, as G consecutive batches of the
+    step-by-step stream, bit for bit (same host draws; augmentation, micro-frontend and SpecAugment are per-clip kernels)."""
+    from multilingual_kws_amd.embedding import input_data
+    B, G = 96, 4
+    (ds1, t1), (ds2, t2) = _fresh(data, 11, B), _fresh(data, 11, B)
+    it = iter(t1)
+    singles = [next(it) for _ in range(2 * G + 1)]
+    audio1 = None
+    groups = input_data.BatchGroups(t2)
+    got = [groups.take(G), groups.take(G), groups.take(1)]
+    spec1, lab1 = torch.cat([s for s, _ in singles]), torch.cat([l for _, l in singles])
+    spec2, lab2 = torch.cat([s for s, _ in got]), torch.cat([l for _, l in got])
+    assert got[0][0].shape == (G * B, 49, 40, 1) and got[2][0].shape == (B, 49, 40, 1)
+    assert torch.equal(spec1, spec2) and torch.equal(lab1, lab2)
+    assert (spec1 == 0).any() and len(set(lab1.tolist())) == 3
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_pipelined_head_training_equals_step_by_step(data, overlap):
+    """transfer_learning.FrozenHeadTrainer (G optimizer steps per forward pass of the frozen embedding, optimizer steps optionally on a
+    second stream) against one forward pass per step: on the SAME handle the embedding rows are bit-identical whatever the batch they
+    ride in (plans are per handle), so the head parameters, Adam moments and per-step statistics must be bit-identical too; against a
+    handle planned for the small batch (other tile / split plans: fp32 round-off in the embedding) the parameters agree to a small
+    fraction of one Adam step.  11 steps with G = 4: groups of 4, 4 and a cut group of 3 (group_limit)."""
+    from multilingual_kws_amd import parallel, weights
+    from multilingual_kws_amd.embedding import transfer_learning as tl
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    from multilingual_kws_amd.head import Head
+    from oracle import head_oracle as ho
+    B, G, steps, lr = 64, 4, 11, 1e-3
+    blob = weights.synthetic_blob()
+    big, small = EmbeddingModel(blob, max_batch=G * B), EmbeddingModel(blob, max_batch=B)
+    p0 = ho.glorot_uniform_params(seed=3)
+    # reference legs: a forward pass per optimizer step
+    legs = {}
+    for name, em in (("same_handle", big), ("small_handle", small)):
+        ds, tds = _fresh(data, 21, B)
+        head, it, stats = Head(params=p0, max_batch=B), iter(tds), []
+        for _ in range(steps):
+            spec, labels = next(it)
+            stats.append(parallel.dp_step(head, em.forward(spec), labels, lr=lr).tolist())
+        legs[name] = (head.state_view().cpu().numpy().copy(), stats)
+    # pipelined
+    ds, tds = _fresh(data, 21, B)
+    head = Head(params=p0, max_batch=B)
+    ft = tl.FrozenHeadTrainer(big, head, tds, B, lr, group=G, overlap=overlap)
+    acc, stats = torch.zeros(2, dtype=torch.float64, device="cuda"), []
+    for i in range(steps):
+        st = ft.step(group_limit=steps - i)
+        ft.accumulate(acc, st)
+        if overlap:
+            ft.side.synchronize()
+        stats.append(st.tolist())
+    ft.finish()
+    torch.cuda.synchronize()
+    assert ft.G == G and ft.forwards == 3
+    state = head.state_view().cpu().numpy()
+    assert np.array_equal(state, legs["same_handle"][0])                       # params | grads | m | v, bit for bit
+    assert stats == legs["same_handle"][1]
+    assert np.allclose(acc.cpu().numpy(), np.sum(np.asarray(stats, dtype=np.float64), axis=0), rtol=0, atol=1e-9)
+    n = len(p0)
+    d = np.abs(state[:n] - legs["small_handle"][0][:n])
+    assert d.max() < 0.2 * lr and d.mean() < 2e-3 * lr, (d.max(), d.mean())
+    assert [s[1] for s in stats] == [s[1] for s in legs["small_handle"][1]]    # the same rows classified correctly at every step
+
+
+def test_transfer_learn_groups_steps_of_the_frozen_phase(data):
+    """transfer_learn's frozen phase runs FORWARD_CLIPS // batch_size optimizer steps per forward pass and never carries a group across
+    an epoch boundary (validation reads the head there): 2 epochs x (4 x 4 =) 16 steps of 4 clips at FORWARD_CLIPS = 24 -> groups of 6, 6, 4
+    per epoch; the returned history is that of the same seeds with a forward pass per step."""
+    from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+    ms = input_data.standard_microspeech_model_settings(3)
+    kw = dict(target="target", train_files=data["train"], val_files=data["val"], unknown_files=data["unknown"], num_epochs=2, num_batches=4,
+              batch_size=4, primary_lr=1e-3, backprop_into_embedding=False, embedding_lr=0, model_settings=ms, base_model_path="synthetic",
+              base_model_output="dense_2", bg_datadir=data["bg_dir"], verbose=0, seed=4)
+    seen, real = [], tl.FrozenHeadTrainer._refill
+
+    def spy(self, g):
+        seen.append(g)
+        return real(self, g)
+    old = tl.FORWARD_CLIPS
+    tl.FrozenHeadTrainer._refill = spy
+    try:
+        tl.FORWARD_CLIPS = 24
+        _, m_grouped, _ = tl.transfer_learn(**kw)
+        assert seen == [6, 6, 4, 6, 6, 4]
+        del seen[:]
+        tl.FORWARD_CLIPS = 4
+        _, m_single, _ = tl.transfer_learn(**kw)
+        assert seen == [1] * 32
+    finally:
+        tl.FrozenHeadTrainer._refill, tl.FORWARD_CLIPS = real, old
+    # both calls run a 64-clip handle (max_batch = max(group * batch, 64)): same plan, same bits
+    assert np.array_equal(m_grouped.head.get_params(), m_single.head.get_params())
+    assert m_grouped.history == m_single.history

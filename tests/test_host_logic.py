@@ -272,3 +272,41 @@ def test_call_tape_logs_and_passes_through():
     with pytest.raises(AttributeError):
         tape.no_such_entry_point
 
+
+
+def test_batch_groups_make_the_draws_of_the_step_by_step_stream(tmp_path):
+    """input_data.BatchGroups.take(g) (g optimizer steps per forward pass of the frozen embedding, transfer_learning.FrozenHeadTrainer): the
+    host draws -- shuffled indices, augmentation items, labels, SpecAugment masks -- are those of g consecutive single batches, in the same
+    order, from the same generator state.  (Device assembly stubbed: what the kernels make of the tables is the -m gpu test's business.)"""
+    d = make_fewshot_dataset(str(tmp_path), n_unknown=12)
+    ms = input_data.standard_microspeech_model_settings(3)
+
+    def stream(seed, bs):
+        ds = input_data.AudioDataset(ms, ["target"], d["bg_dir"], d["unknown"], unknown_percentage=50.0,
+                                     spec_aug_params=input_data.SpecAugParams(percentage=80), seed=seed)
+        ds._assemble = lambda cds, drawn: drawn                     # host tables only
+        ds.background_host = None                                    # (keeps get_background_data's sizes; nothing is uploaded)
+        return ds.init_single_target(input_data.AUTOTUNE, d["train"], is_training=True).shuffle(1000).repeat().batch(bs)
+    it = iter(stream(9, 7))
+    single = [next(it)[0] for _ in range(9)]
+    g = input_data.BatchGroups(stream(9, 7))
+    grouped = g.take(4) + g.take(1) + g.take(4)
+    assert len(grouped) == 9
+    for (i1, l1, m1), (i2, l2, m2) in zip(single, grouped):
+        assert i1.tobytes() == i2.tobytes() and np.array_equal(l1, l2) and np.array_equal(m1, m2)
+    assert len({t[0].tobytes() for t in single}) == 9                # the batches differ from each other
+    # the shuffled passes come from ONE Generator.permuted call per refill: the values and the generator state of consecutive
+    # rng.permutation(n) calls (the stream of rounds 1-4: seeded runs keep their batches)
+    for n, k in ((5, 103), (1, 4), (64, 3)):
+        r1, r2 = np.random.default_rng(n), np.random.default_rng(n)
+        assert np.array_equal(np.concatenate([r1.permutation(n) for _ in range(k)]), r2.permuted(np.tile(np.arange(n), (k, 1)), axis=1).reshape(-1))
+        assert r1.integers(0, 1 << 30) == r2.integers(0, 1 << 30)
+    ds = input_data.AudioDataset(ms, ["target"], d["bg_dir"], d["unknown"], seed=3)
+    ref_rng = np.random.default_rng(3)
+    g2 = input_data.BatchGroups(ds.init_single_target(input_data.AUTOTUNE, d["train"], is_training=True).shuffle(1000).repeat().batch(12))
+    want = np.concatenate([ref_rng.permutation(len(d["train"])) for _ in range(3)])
+    assert np.array_equal(g2._next_indices(), want[:12]) and np.array_equal(g2.buf, want[12:])
+    with pytest.raises(ValueError):
+        input_data.BatchGroups(input_data.ClipDataset(stream(1, 2).owner, d["train"], ["target"] * len(d["train"]), True).batch(2))   # no .repeat()
+    assert transfer_learning.steps_per_forward(512) == 2 and transfer_learning.steps_per_forward(64) == 16
+    assert transfer_learning.steps_per_forward(1024) == 1 and transfer_learning.steps_per_forward(4096) == 1

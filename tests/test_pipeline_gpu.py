@@ -124,8 +124,12 @@ def test_transfer_learn_contract_and_learning(data, tmp_path):
     assert np.abs(preds - ref_probs).max() < 1e-4 and np.array_equal(preds.argmax(1), ref_probs.argmax(1))
     # save / load round trip
     model.save(str(tmp_path / "m"))
-    again = tl.TransferLearnedModel.load(str(tmp_path / "m"), max_batch=64)
+    # (the frozen phase embeds FORWARD_CLIPS // batch_size batches per forward pass: the returned model's handle is planned for 1024 clips)
+    assert model.embedding.max_batch == 64 * tl.steps_per_forward(64) == 1024
+    again = tl.TransferLearnedModel.load(str(tmp_path / "m"), max_batch=model.embedding.max_batch)       # same handle size = same plan: bit for bit
     assert np.array_equal(again.predict(specs[..., None]), model.predict(specs[..., None]))
+    small = tl.TransferLearnedModel.load(str(tmp_path / "m"), max_batch=64)                              # another plan: fp32 round-off
+    assert np.abs(small.predict(specs[..., None]) - model.predict(specs[..., None])).max() < 1e-5
 
 
 def test_transfer_learn_cut_at_another_layer(data, tmp_path):
@@ -150,7 +154,7 @@ def test_transfer_learn_cut_at_another_layer(data, tmp_path):
         assert np.abs(preds - ref_probs).max() < 1e-4 and np.array_equal(preds.argmax(1), ref_probs.argmax(1))
         assert preds.shape == (8, 3) and np.allclose(preds.sum(1), 1, atol=1e-5)
         model.save(str(tmp_path / layer))
-        again = tl.TransferLearnedModel.load(str(tmp_path / layer), max_batch=64)           # same handle size = same plan: bit for bit
+        again = tl.TransferLearnedModel.load(str(tmp_path / layer), max_batch=model.embedding.max_batch)   # same handle size = same plan: bit for bit
         assert np.array_equal(again.predict(specs[..., None]), preds)
         small = tl.TransferLearnedModel.load(str(tmp_path / layer), max_batch=16)           # a live-serving handle (cluster plan): fp32 round-off
         assert np.abs(small.predict(specs[..., None]) - preds).max() < 1e-5

@@ -537,6 +537,58 @@ def test_bucketed_gradient_allreduce_over_rccl():
         dist.destroy_process_group()
 
 
+def test_allreduce_ranges_are_final_when_the_collective_reads_them():
+    """The weight gradients run on a second stream; a range's all-reduce must not start before they have landed (flush of the side
+    context, main stream waits on the side stream, flush of the main context, THEN the collective).  A 1-rank SUM cannot show a missing
+    dependency (it is a no-op), so the collective is replaced by a snapshot of the range taken on torch's current stream -- the stream
+    RCCL orders itself behind -- at the moment all_reduce is called: every snapshot must equal the final gradient of a single-stream
+    run, bit for bit (fixed-order reductions)."""
+    import socket
+    import torch.distributed as dist
+    from multilingual_kws_amd import weights
+    from multilingual_kws_amd.embedding_trainer import EmbeddingTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    real = dist.all_reduce
+    try:
+        rng = np.random.default_rng(2)
+        B = 16
+        spec = torch.from_numpy(rng.integers(0, 670, size=(B, 49, 40)).astype(np.float32) * np.float32(10 / 256)).cuda()
+        d_emb = torch.from_numpy(rng.standard_normal((B, 1024)).astype(np.float32)).cuda()
+        ref = EmbeddingTrainer(weights.synthetic_blob())
+        ref.overlap_wgrad = False
+        ref.forward_train(spec)
+        ref.backward(d_emb)
+        torch.cuda.synchronize()
+        want = ref.grads.clone()
+        tr = EmbeddingTrainer(weights.synthetic_blob())
+        assert tr.overlap_wgrad
+        for rep in range(3):                     # the first pass also warms the side stream's context
+            tr.forward_train(spec)
+            base, snaps = tr.grads.data_ptr(), []
+
+            class Done:
+                def wait(self):
+                    pass
+
+            def snapshot(t, *a, **k):
+                lo = (t.data_ptr() - base) // 4
+                snaps.append((lo, t.clone()))
+                return Done()
+            dist.all_reduce = snapshot
+            tr.backward(d_emb, allreduce=True)
+            dist.all_reduce = real
+            torch.cuda.synchronize()
+            assert len(snaps) == 3 and sum(c.numel() for _, c in snaps) == want.numel()
+            for lo, c in snaps:
+                assert torch.equal(c, want[lo:lo + c.numel()]), (rep, lo)
+            assert torch.equal(tr.grads, want)
+    finally:
+        dist.all_reduce = real
+        dist.destroy_process_group()
+
+
 def test_graph_replayed_training_step_equals_the_eager_step():
     """TrainStepGraph: forward + head loss + backward + both Adam updates of one `backprop_into_embedding` step recorded once and
     replayed (the call tape by default, one hipGraph on request).  (a) Three replays with fresh inputs and drop-connect masks leave
