@@ -70,7 +70,9 @@ class TransferLearnedModel:
         x = torch.as_tensor(np.asarray(x, dtype=np.float32)).to(self.embedding.device)
         if x.dim() == 4:
             x = x[..., 0]
-        return self.predict_device(x).cpu().numpy()
+        # checked(): a failed in-kernel exchange poisons the forward that ran it and is otherwise reported by the NEXT call (include/mkws.h);
+        # the copy to the host has synchronised anyway, so the host API looks at the handle now and never returns the poisoned batch
+        return self.embedding.checked(lambda: self.predict_device(x).cpu().numpy())
 
     def save(self, path):
         """Directory with head.npz (+ a copy of / pointer to the base weights)."""

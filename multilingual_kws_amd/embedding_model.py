@@ -94,9 +94,25 @@ class EmbeddingModel:
             rc = self.L.mkws_embed_forward(*args)
         _lib.check(rc)
 
+    def checked(self, run):
+        """run() -> host result of forward passes of this handle, synchronised (it ends in a device-to-host copy).  If one of them ran a
+        failed pair / cluster exchange (include/mkws.h, failure contract: that forward's embeddings are NaN and the error is reported by the
+        NEXT call) the handle is healed and run() repeated once, so that the numpy-facing API never hands back the poisoned batch.  The
+        asynchronous device API (forward) keeps the documented contract: it cannot look without synchronising."""
+        out = run()
+        if self.get_option("exchange_error"):
+            import warnings
+            warnings.warn("multilingual_kws_amd: an in-kernel exchange failed in this forward pass; repeating it on the single-workgroup kernels", RuntimeWarning)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)      # (the repeat's first launch reports MKWS_ERR_EXCHANGE and is re-issued by _call_forward)
+                out = run()
+            if self.get_option("exchange_error"):
+                raise _lib.MkwsError(_lib.MKWS_ERR_EXCHANGE, "an in-kernel exchange failed again on the healed handle")
+        return out
+
     def predict(self, x):
         """Keras-style: numpy in ([B,49,40,1]), numpy out ([B,1024], or the width of the layer the model was cut at)."""
-        return self.forward(x).cpu().numpy()
+        return self.checked(lambda: self.forward(x).cpu().numpy())
 
     def tap(self, spec, stage):
         """Output of a named intermediate stage (flat float32 CUDA tensor) for parity debugging."""

@@ -299,6 +299,15 @@ def test_failed_pair_exchange_degrades_instead_of_poisoning(ctx, fault, chain):
     # re-arming the paired kernel after the reset works: flags and the sticky word were cleared in stream order
     em2.set_option("fuse_pair", 1)
     assert _rel(em2.forward(x).cpu().numpy(), ref) < REL_TOL and em2.get_option("pair_degraded") == 1
+    # the numpy-facing API (predict) has synchronised for its device-to-host copy and looks at the handle before it returns: the poisoned
+    # batch never reaches the caller
+    em3 = EmbeddingModel(ctx["blob"], max_batch=1024)
+    em3.set_option("fuse_chain", chain)
+    em3.set_option("pair_fault", fault)
+    with pytest.warns(RuntimeWarning, match="repeating it"):
+        out = em3.predict(spec[..., None])
+    assert np.isfinite(out).all() and _rel(out, ref) < REL_TOL
+    assert em3.get_option("pair_degraded") == 1 and em3.get_option("fuse_pair") == 0 and em3.get_option("exchange_error") == 0
 
 
 @pytest.mark.parametrize("plan", ["default", "multi-kernel", "no-cluster"])
