@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKWS_ABI_VERSION 4
+#define MKWS_ABI_VERSION 5
 
 typedef enum mkws_status {
   MKWS_OK = 0,
@@ -334,6 +334,15 @@ int mkws_op_set_scratch(float* d_scratch, size_t floats);
  * ksplit = 0 picks the split from the shapes and the arena size (small grids with a long K: ~512 workgroups). */
 int mkws_op_gemm(const float* d_A, const float* d_B, float* d_C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
                  int accumulate, int ksplit, void* stream);
+/* Process-wide switches of the training operators (ABI 5; A/B aids, results equal up to fp32 summation order):
+ *   "gemm_ring"    (default 1; initial value from MKWS_TRAIN_GEMM2): NN / NT GEMMs whose K, N and leading dimensions are multiples of 4 run on the
+ *                  register-ring kernel (operands global / L2 -> registers through buffer loads, no LDS, no barriers: the scheme of the inference
+ *                  GEMM); 0 = the LDS-staged kernel for everything.
+ *   "gemm_ring_tn" (default 0; MKWS_TRAIN_GEMM_TN2): the same for weight gradients (transA = 1): 0 none, 1 small outputs over >= 4096 rows, 2 all.
+ *                  Faster per launch and in a single-stream step, slower inside the trainer's two-stream step (profiles/r05_notes.md).
+ * mkws_op_get_option returns the value, or a negative mkws_status for an unknown name. */
+int mkws_op_set_option(const char* name, int value);
+int mkws_op_get_option(const char* name);
 /* Stream ordering for a trainer that spreads its launches over two streams (weight gradients next to the input-gradient chain): everything queued
  * on signalling_stream so far happens before whatever is queued on waiting_stream afterwards.  Events belong to the bound context.  Capturable. */
 int mkws_op_stream_wait(void* waiting_stream, void* signalling_stream);

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("MKWS_LIB") or os.path.join(_HERE, "lib", "libmkws_hip
 
 MKWS_OK = 0
 MKWS_ERR_EXCHANGE = -7
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MkwsError(RuntimeError):
@@ -80,6 +80,8 @@ SYMBOLS = [
     ("mkws_train_ctx_bind", _I, [_P]),
     ("mkws_op_set_scratch", _I, [_P, _SZ]),
     ("mkws_op_stream_wait", _I, [_P, _P]),
+    ("mkws_op_set_option", _I, [ctypes.c_char_p, _I]),
+    ("mkws_op_get_option", _I, [ctypes.c_char_p]),
     ("mkws_op_fold_defer", _I, [_I, _P]),
     ("mkws_op_fold_flush", _I, [_P]),
     ("mkws_op_bn_train_fwd", _I, [_P, _I, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P]),

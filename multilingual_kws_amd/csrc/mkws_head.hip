@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadDims d, const float*
 #pragma unroll
   for (int r = 0; r < R; ++r) xr[r] = x + (size_t)((row0 + r < B) ? row0 + r : B - 1) * d.in;
   const bool even = (d.hid & 1) == 0;              // rows of W1 are then 8-byte aligned: float2 loads
-  constexpr int KU = (R == 1) ? 4 : 2;             // k steps in flight (their loads issue together)
+  // k steps in flight (their loads issue together; the adds keep their order).  Round 5: the training launch (R = 1, one wave per row) is
+  // pure latency -- 16 k steps of 1 + 9 loads each -- so it keeps 8 of them in flight instead of 4
+  constexpr int KU = (R == 1) ? (TRAIN ? 8 : 4) : 2;
 #pragma unroll KU
   for (int k = lane; k < d.in; k += 64) {
     float xv[R];
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256) void head_dw1_partial_kernel(HeadDims d, const
     for (int i = threadIdx.x; i < nr * d.hid; i += 256) s_dp[i] = dpre[(size_t)rb * d.hid + i];
     __syncthreads();
     if (k < d.in) {
+#pragma unroll 8      // eight rows' loads in flight (the sums keep their row order): the plain loop paid one L2 latency per row
       for (int r = 0; r < nr; ++r) {
         const float xv = x[(size_t)(rb + r) * d.in + k];
 #pragma unroll
@@ -357,6 +360,7 @@ __global__ __launch_bounds__(256) void head_grad_finish_kernel(HeadDims d, const
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < nW1) {
       float s = 0.0f;
+#pragma unroll 8      // (loads of eight slices in flight, added in slice order)
       for (int p = 0; p < splits; ++p) s += partial[(size_t)p * nW1 + i];
       grads[i] = s;
     }

@@ -14,6 +14,8 @@
 #include "mkws_common.h"
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 #pragma clang fp contract(fast)
 
@@ -186,26 +188,402 @@ __global__ __launch_bounds__(256) void train_gemm_kernel(const float* __restrict
       }
 }
 
-// C (+)= part[0] + part[1] + ... (fixed order)
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ C, int M, int N, int ldc, int accumulate,
-                                                          const float* __restrict__ bias, int act, float* __restrict__ Act) {
-  const size_t total = (size_t)M * N;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    float v = part[i];
-    for (int z = 1; z < ksplit; ++z) v += part[(size_t)z * total + i];
-    const size_t o = (i / N) * (size_t)ldc + (i % N);
-    if (accumulate) v += C[o];
-    C[o] = v;
-    if (Act) Act[o] = act_fwd(v + bias[i % N], act);
+// ------------------------------------------------------------------------------------------------
+// Round 5: the NN / NT forms without LDS.  The generic kernel above stages both operands through LDS with one scalar load per element
+// and a barrier per 16 columns of K; on the step's shapes it reaches 12-70 TFLOP/s where the inference GEMM (pw_gemm_kernel,
+// mkws_embed.hip) reaches 121.  This kernel is that one's scheme on unpacked operands: every operand fragment goes global / L2 ->
+// registers through buffer loads with a uniform descriptor, a 32-bit per-lane byte offset and the K-chunk offset in an SGPR (the K loop
+// is MFMAs, loads and counted waits only), a D-deep register ring over the K chunks, no barrier anywhere.
+//   A [M, K] row-major (X, or dZ): lane (g, c) of a row tile reads A[row c][16 j + 4 g .. + 3], one float4.
+//   B, TB = false: W [K, N] row-major (forward): lane (g, c) reads W[16 j + 4 g + s][col c], s = 0 .. 3 -- four dword loads, each 64
+//      contiguous bytes per lane group; W is small and sits in L1 / L2.
+//   B, TB = true: B [N, K] row-major (dX = dZ . W^T with W [Cin, Cout]): lane (g, c) reads B[col c][16 j + 4 g .. + 3], one float4.
+//   MFMA step s of a chunk covers k = 16 j + 4 g + s on both operands.  Accumulation order of an output element: K chunks ascending,
+//   steps ascending inside a chunk, the four lane groups inside a step as the matrix core adds them -- a function of the shapes only.
+// Rows / columns outside the matrices: the descriptors carry the exact byte sizes, out-of-range loads return 0, nothing is stored there.
+// The K tail (K % 16 in {4, 8, 12}) is peeled: the A fragment of lane groups past K is zeroed (its address holds the next row's data).
+// A workgroup = 4 waves = 64 * MT rows x 16 * NT columns; with MT = 1 its rows are one 64-row BatchNorm chunk and the epilogue can leave
+// the chunk statistics (mean, M2) as the generic kernel does.  Needs K, N, lda, ldb, ldc % 4 == 0 and 16-byte aligned A / C / part / Act
+// (activations and scratch: host-checked).  B is a WEIGHT: a view into the trainer's flat parameter buffer at its blob offset, which for most
+// tensors is 8 bytes off a 16-byte boundary -- the TB = true fragment of B is therefore read as BV-float pieces (BV = 4: one float4; 2: two
+// float2; 1: four dwords), the widest the base allows; TB = false reads dwords anyway; the bias is read element by element.
+template <bool TB, int MT, int NT, int BV>
+__global__ __launch_bounds__(256) void train_gemm2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K, int lda,
+                                                          int ldb, int ldc, int accumulate, int ksplit, float* __restrict__ part, const float* __restrict__ bias,
+                                                          int act, float* __restrict__ Act, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int m0 = blockIdx.y * (64 * MT) + wave * (16 * MT);
+  const int n0 = blockIdx.x * (16 * NT);
+  const int KC = (K + 15) >> 4;
+  int jbeg = 0, jend = KC;
+  if (ksplit > 1) {
+    const int per = (KC + ksplit - 1) / ksplit;
+    jbeg = blockIdx.z * per;
+    jend = (jbeg + per < KC) ? jbeg + per : KC;
+    if (jbeg > jend) jbeg = jend;
+  }
+  const unsigned bytesA = (unsigned)(((size_t)(M - 1) * lda + K) * sizeof(float));
+  const unsigned bytesB = (unsigned)(TB ? ((size_t)(N - 1) * ldb + K) * sizeof(float) : ((size_t)(K - 1) * ldb + N) * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, bytesB, 0x00020000);
+  unsigned aoff[MT], boff[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + mt * 16 + c;
+    aoff[mt] = (m < M) ? (unsigned)(((size_t)m * lda + 4 * g) * sizeof(float)) : 0xFFFFFFF0u;       // (past the last row: out of range, reads 0)
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + nt * 16 + c;
+    if (TB) boff[nt] = (n < N) ? (unsigned)(((size_t)n * ldb + 4 * g) * sizeof(float)) : 0xFFFFFFF0u;
+    else boff[nt] = (n < N) ? (unsigned)(((size_t)(4 * g) * ldb + n) * sizeof(float)) : 0xFFFFFFF0u;
+  }
+  const unsigned brow = (unsigned)ldb * (unsigned)sizeof(float);                   // TB = false: bytes between two k rows of W
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int D = 3;
+  f32x4 aq[D][MT], bq[D][NT];
+  auto load = [&](int j, f32x4 (&av)[MT], f32x4 (&bv)[NT]) {
+    const unsigned kx = 64u * (unsigned)j;                                          // 16 floats of K per chunk
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) av[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, aoff[mt], kx, 0));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (TB) {
+        if constexpr (BV == 4) {
+          bv[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, boff[nt], kx, 0));
+        } else if constexpr (BV == 2) {
+          typedef float f32x2_ __attribute__((ext_vector_type(2)));
+          const f32x2_ lo = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(rB, boff[nt], kx, 0));
+          const f32x2_ hi = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(rB, boff[nt], kx + 8u, 0));
+          bv[nt] = (f32x4){lo.x, lo.y, hi.x, hi.y};
+        } else {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bv[nt][s4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, boff[nt], kx + 4u * (unsigned)s4, 0));
+        }
+      } else {
+        const unsigned k0 = 16u * (unsigned)j * brow;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) bv[nt][s4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, boff[nt], k0 + (unsigned)s4 * brow, 0));
+      }
+    }
+  };
+  auto compute = [&](const f32x4 (&av)[MT], const f32x4 (&bv)[NT]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][s4], av[mt][s4], acc[mt][nt], 0, 0, 0);
+  };
+  const bool ktail = (K & 15) != 0;                                                  // uniform
+  const int jpipe_end = (ktail && jend == KC && jend > jbeg) ? jend - 1 : jend;
+  const int n = jpipe_end - jbeg;
+  if (n >= D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(jbeg + d, aq[d], bq[d]);
+    int j = jbeg;
+    for (; j + 2 * D <= jpipe_end; j += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        compute(aq[d], bq[d]);
+        load(j + D + d, aq[d], bq[d]);
+        __builtin_amdgcn_sched_barrier(0);       // keep each reload behind its slot's MFMAs (see pw_gemm_kernel)
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      compute(aq[d], bq[d]);
+      if (j + D + d < jpipe_end) load(j + D + d, aq[d], bq[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    j += D;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (j + d < jpipe_end) compute(aq[d], bq[d]);
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < n) load(jbeg + d, aq[d], bq[d]);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < n) compute(aq[d], bq[d]);
+  }
+  if (jpipe_end != jend) {                       // peeled K-tail chunk: lane groups whose four columns lie past K contribute nothing
+    load(jend - 1, aq[0], bq[0]);
+    if (16 * (jend - 1) + 4 * g >= K) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) aq[0][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bq[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    compute(aq[0], bq[0]);
+  }
+  // lane (g, c) holds rows m0 + mt * 16 + c, columns n0 + nt * 16 + 4 g .. + 3
+  if (MT == 1 && stats) {
+    // BatchNorm chunk statistics of this workgroup's 64 rows (see train_gemm_kernel): per column the mean of the valid rows and the sum of
+    // squared deviations from it, two passes over the accumulators.  Order: the 16 rows of a wave by butterfly, the four waves in order.
+    __shared__ float s_cs[4][16 * NT], s_cq[4][16 * NT];
+    const int r0 = blockIdx.y * 64;
+    const int nrows = (M - r0 < 64) ? M - r0 : 64;
+    const bool rowok = m0 + c < M;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 t = rowok ? acc[0][nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += __shfl_xor(t[r], off);
+      if (c == 0) *reinterpret_cast<f32x4*>(&s_cs[wave][nt * 16 + 4 * g]) = t;
+    }
+    __syncthreads();
+    f32x4 mu[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mu[nt][r] = (((s_cs[0][col + r] + s_cs[1][col + r]) + s_cs[2][col + r]) + s_cs[3][col + r]) / (float)nrows;
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
+      if (rowok) { const f32x4 dlt = acc[0][nt] - mu[nt]; q = dlt * dlt; }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] += __shfl_xor(q[r], off);
+      if (c == 0) *reinterpret_cast<f32x4*>(&s_cq[wave][col]) = q;
+    }
+    __syncthreads();
+    if (wave == 0 && c == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 16 + 4 * g, nn = n0 + col;
+        if (nn < N) {
+          f32x4 qq;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qq[r] = ((s_cq[0][col + r] + s_cq[1][col + r]) + s_cq[2][col + r]) + s_cq[3][col + r];
+          *reinterpret_cast<f32x4*>(stats + ((size_t)blockIdx.y * 2 + 0) * N + nn) = mu[nt];
+          *reinterpret_cast<f32x4*>(stats + ((size_t)blockIdx.y * 2 + 1) * N + nn) = qq;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + mt * 16 + c;
+    if (m >= M) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int nn = n0 + nt * 16 + 4 * g;
+      if (nn >= N) continue;
+      if (ksplit > 1) {
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.z * M + m) * N + nn) = acc[mt][nt];       // raw slice sums; gemm_reduce_kernel folds them in order
+      } else {
+        float* dst = C + (size_t)m * ldc + nn;
+        f32x4 v = acc[mt][nt];
+        if (accumulate) v = *reinterpret_cast<const f32x4*>(dst) + v;
+        *reinterpret_cast<f32x4*>(dst) = v;
+        if (Act) {
+          f32x4 y;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = act_fwd(v[r] + bias[nn + r], act);
+          *reinterpret_cast<f32x4*>(Act + (size_t)m * ldc + nn) = y;
+        }
+      }
+    }
   }
 }
 
-// out[i] (+)= sum over chunks of part[chunk][i]  (fixed order): second stage of every cross-workgroup reduction below
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out, float scale, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float v = part[i];
-  for (int z = 1; z < chunks; ++z) v += part[(size_t)z * n + i];
+// The TN form (weight gradient dW [Kin, N] = X^T [Kin, R] . dZ [R, N], R = rows of the layer: up to 256 000 at 512 clips) on the same
+// scheme.  The reduction index is the ROW of both operands, so a lane's four k values sit in four different rows: lane (g, c) reads
+// X[16 j + 4 g + s][k0 + c] and dZ[16 j + 4 g + s][n0 + c], s = 0 .. 3 -- dword loads, each 64 contiguous bytes per lane group, every byte
+// of both operands fetched once per output block.  A workgroup owns a KT x NT block of 16 x 16 output tiles and ONE slice of the rows
+// (blockIdx.z); its four waves walk interleaved 16-row chunks of the slice and their partial tiles meet in LDS, added in wave order; the
+// slice sums go to part[slice] and are folded in slice order by the launch that follows (gemm_reduce_kernel / fold_defer): fixed order
+// everywhere.  The LDS-staged kernel ran the step's tall shapes (32 x 16 outputs over 256 000 rows: 48 MB of operands) at 2-10 TFLOP/s,
+// i.e. 110-127 us for what the memory system delivers in ~15.
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void train_gemm_tn2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K, int lda,
+                                                             int ldb, int ldc, int accumulate, int ksplit, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float s_tn[];                     // [3 waves][KT * NT][64 lanes][4]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int k0 = blockIdx.y * (16 * KT), n0 = blockIdx.x * (16 * NT);            // output block: rows k0.. of dW (columns of A), columns n0..
+  // rows (the reduction, length K) of this slice, in 16-row chunks dealt round-robin to the four waves
+  const int RC = (K + 15) >> 4;
+  const int per = (RC + ksplit - 1) / ksplit;
+  int jbeg = blockIdx.z * per, jend = (jbeg + per < RC) ? jbeg + per : RC;
+  if (jbeg > jend) jbeg = jend;
+  const unsigned bytesA = (unsigned)(((size_t)(K - 1) * lda + M) * sizeof(float));
+  const unsigned bytesB = (unsigned)(((size_t)(K - 1) * ldb + N) * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, bytesB, 0x00020000);
+  unsigned aoff[KT], boff[NT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int k = k0 + kt * 16 + c;
+    aoff[kt] = (k < M) ? (unsigned)(((size_t)(4 * g) * lda + k) * sizeof(float)) : 0xFFFFFFF0u;       // (columns past the matrix: out of range, read 0)
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + nt * 16 + c;
+    boff[nt] = (n < N) ? (unsigned)(((size_t)(4 * g) * ldb + n) * sizeof(float)) : 0xFFFFFFF0u;
+  }
+  const unsigned arow = (unsigned)lda * (unsigned)sizeof(float), brow = (unsigned)ldb * (unsigned)sizeof(float);
+  f32x4 acc[KT][NT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int D = 3;
+  f32x4 aq[D][KT], bq[D][NT];
+  // rows past the end of the matrices lie past the descriptors' ranges as long as the LAST row is the last thing in the buffer; a row
+  // tail inside a chunk (K % 16 != 0) therefore reads zeros on both operands
+  auto load = [&](int j, f32x4 (&av)[KT], f32x4 (&bv)[NT]) {
+    const unsigned ra = 16u * (unsigned)j * arow, rb = 16u * (unsigned)j * brow;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) av[kt][s4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, aoff[kt], ra + (unsigned)s4 * arow, 0));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt][s4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, boff[nt], rb + (unsigned)s4 * brow, 0));
+    }
+  };
+  auto compute = [&](const f32x4 (&av)[KT], const f32x4 (&bv)[NT]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][s4], av[kt][s4], acc[kt][nt], 0, 0, 0);
+  };
+  // this wave's chunks: jbeg + wave, + 4, ...
+  const int first = jbeg + wave;
+  const int n = (jend > first) ? (jend - first + 3) / 4 : 0;
+  if (n >= D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(first + 4 * d, aq[d], bq[d]);
+    int i = 0;
+    for (; i + 2 * D <= n; i += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        compute(aq[d], bq[d]);
+        load(first + 4 * (i + D + d), aq[d], bq[d]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      compute(aq[d], bq[d]);
+      if (i + D + d < n) load(first + 4 * (i + D + d), aq[d], bq[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    i += D;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (i + d < n) compute(aq[d], bq[d]);
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < n) load(first + 4 * d, aq[d], bq[d]);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < n) compute(aq[d], bq[d]);
+  }
+  // the four waves' partial tiles, added in wave order by wave 0
+  if (wave > 0) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(s_tn + ((size_t)((wave - 1) * KT * NT + kt * NT + nt) * 64 + lane) * 4) = acc[kt][nt];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // lane (g, c) holds dW rows k0 + kt * 16 + c, columns n0 + nt * 16 + 4 g .. + 3
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int k = k0 + kt * 16 + c;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v = acc[kt][nt];
+#pragma unroll
+      for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(s_tn + ((size_t)(w * KT * NT + kt * NT + nt) * 64 + lane) * 4);
+      const int nn = n0 + nt * 16 + 4 * g;
+      if (k >= M || nn >= N) continue;
+      if (ksplit > 1) {
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.z * M + k) * N + nn) = v;
+      } else {
+        float* dst = C + (size_t)k * ldc + nn;                   // (a weight gradient: a view into the flat gradient buffer, not 16-byte aligned)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r] = accumulate ? dst[r] + v[r] : v[r];
+      }
+    }
+  }
+}
+
+// ---- second stages: out[i] (+)= sum over slices z of part[z][i], fixed order ----
+// A fold of many slices into FEW elements is pure latency when one thread walks all the slices of its element (a 256-slice fold of a 32 x 16
+// weight gradient: two workgroups, 57-230 us of dependent loads, several times the GEMM that produced the slices).  So an element is shared
+// by S threads: thread `sub` adds the slices [sub * per, (sub + 1) * per) in order, eight loads in flight, and the S sub-sums meet in LDS and
+// are added in sub order.  S is a function of the element and slice counts only (fold_subs), the same in the immediate and in the deferred
+// launch of a fold: bit-identical results either way, bit-reproducible from run to run.
+__host__ __device__ inline int fold_subs(long n, int chunks) { return (chunks >= 32 && n <= 16384) ? 16 : ((chunks >= 16 && n <= 262144) ? 4 : 1); }
+__host__ __device__ inline int fold_grid(long n, int S) { return (int)((n + 256 / S - 1) / (256 / S)); }
+
+// block = 256 threads = (256 / S) element lanes x S subs; returns the element index of this thread (-1: none) and, in sub 0, its sum
+__device__ __forceinline__ long fold_sum(const float* __restrict__ part, int chunks, size_t stride, long n, int block, int S, float* s_buf, float* sum) {
+  const int E = 256 / S, e = (int)threadIdx.x % E, sub = (int)threadIdx.x / E;
+  const long i = (long)block * E + e;
+  const int per = (chunks + S - 1) / S;
+  const int z0 = sub * per, z1 = (z0 + per < chunks) ? z0 + per : chunks;
+  float v = 0.0f;
+  if (i < n) {
+    int z = z0;
+    for (; z + 8 <= z1; z += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(z + u) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < z1; ++z) v += part[(size_t)z * stride + i];
+  }
+  if (S > 1) {                                   // (S is uniform over the workgroup)
+    s_buf[threadIdx.x] = v;
+    __syncthreads();
+    if (sub == 0) {
+      v = s_buf[e];
+      for (int q = 1; q < S; ++q) v += s_buf[q * E + e];
+    }
+  }
+  *sum = v;
+  return (i < n && sub == 0) ? i : -1;
+}
+
+// C (+)= part[0] + part[1] + ... (fixed order); grid = fold_grid(M * N, S)
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ C, int M, int N, int ldc, int accumulate,
+                                                          const float* __restrict__ bias, int act, float* __restrict__ Act, int S) {
+  __shared__ float s_buf[256];
+  const long total = (long)M * N;
+  float v;
+  const long i = fold_sum(part, ksplit, (size_t)total, total, (int)blockIdx.x, S, s_buf, &v);
+  if (i < 0) return;
+  const size_t o = (size_t)(i / N) * (size_t)ldc + (size_t)(i % N);
+  if (accumulate) v += C[o];
+  C[o] = v;
+  if (Act) Act[o] = act_fwd(v + bias[i % N], act);
+}
+
+// out[i] (+)= scale * sum over chunks of part[chunk][i]  (fixed order): second stage of every cross-workgroup reduction below; grid = fold_grid(n, S)
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out, float scale, int accumulate, int S) {
+  __shared__ float s_buf[256];
+  float v;
+  const long i = fold_sum(part, chunks, (size_t)n, n, (int)blockIdx.x, S, s_buf, &v);
+  if (i < 0) return;
   v *= scale;
   out[i] = accumulate ? out[i] + v : v;
 }
@@ -214,17 +592,17 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 // output element is the same fixed-order sum the single-descriptor kernels (fold_partials_kernel, gemm_reduce_kernel without an epilogue)
 // compute: bit-identical results, one launch instead of up to kMaxFolds.
 constexpr int kMaxFolds = 24;
-struct FoldDesc { const float* part; float* out; int chunks, n, N, ldc; float scale; int accumulate; int block0; };
+struct FoldDesc { const float* part; float* out; int chunks, n, N, ldc; float scale; int accumulate; int block0; int S; };
 struct FoldBatch { FoldDesc d[kMaxFolds]; int n; };
 __global__ __launch_bounds__(256) void fold_batch_kernel(FoldBatch fb) {
+  __shared__ float s_buf[256];
   int k = 0;
   for (int j = 1; j < fb.n; ++j)
     if ((int)blockIdx.x >= fb.d[j].block0) k = j;
   const FoldDesc& d = fb.d[k];
-  const int i = ((int)blockIdx.x - d.block0) * 256 + (int)threadIdx.x;
-  if (i >= d.n) return;
-  float v = d.part[i];
-  for (int z = 1; z < d.chunks; ++z) v += d.part[(size_t)z * d.n + i];
+  float v;
+  const long i = fold_sum(d.part, d.chunks, (size_t)d.n, d.n, (int)blockIdx.x - d.block0, d.S, s_buf, &v);
+  if (i < 0) return;
   v *= d.scale;
   const size_t o = (size_t)(i / d.N) * d.ldc + (i % d.N);
   d.out[o] = d.accumulate ? d.out[o] + v : v;
@@ -1307,9 +1685,18 @@ inline bool fold_defer(const float* part, float* out, int chunks, int n, int N, 
   if (c.fb.n == kMaxFolds) { fold_flush(s); return false; }          // (the caller's partials sit at the old bump position: fold them now)
   FoldDesc& d = c.fb.d[c.fb.n++];
   d.part = part; d.out = out; d.chunks = chunks; d.n = n; d.N = N; d.ldc = ldc; d.scale = scale; d.accumulate = accumulate; d.block0 = c.fold_blocks;
-  c.fold_blocks += (n + 255) / 256;
+  d.S = fold_subs(n, chunks);
+  c.fold_blocks += fold_grid(n, d.S);
   c.bump += ((size_t)chunks * n + 63) & ~(size_t)63;
   return true;
+}
+inline void launch_fold_partials(const float* part, int chunks, int n, float* out, float scale, int accumulate, hipStream_t s) {
+  const int S = fold_subs(n, chunks);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(fold_grid(n, S)), dim3(256), 0, s, part, chunks, n, out, scale, accumulate, S);
+}
+inline void launch_gemm_reduce(const float* part, int ksplit, float* C, int M, int N, int ldc, int accumulate, const float* bias, int act, float* Act, hipStream_t s) {
+  const int S = fold_subs((long)M * N, ksplit);
+  hipLaunchKernelGGL(gemm_reduce_kernel, dim3(fold_grid((long)M * N, S)), dim3(256), 0, s, part, ksplit, C, M, N, ldc, accumulate, bias, act, Act, S);
 }
 constexpr int kBnMaxChunks = 256;          // chunk statistics one BatchNorm launch folds per channel (a producer with more chunks keeps the separate statistics launch)
 constexpr int kBnMaxGemmTiles = 160;       // the same for GEMM row tiles (64 rows each: more, smaller chunks than the statistics kernel would make)
@@ -1379,6 +1766,23 @@ int mkws_op_fold_flush(void* stream) {
   return MKWS_OK;
 }
 
+// Which GEMM kernels mkws_op_gemm / dense_fwd / conv_bn_fwd launch (mkws_op_set_option; the environment gives the initial values):
+//   "gemm_ring"    (MKWS_TRAIN_GEMM2, default 1): NN / NT on train_gemm2_kernel; 0 = everything on the LDS-staged kernel
+//   "gemm_ring_tn" (MKWS_TRAIN_GEMM_TN2, default 0): weight gradients on train_gemm_tn2_kernel: 0 none, 1 = outputs of at most 256 tiles over
+//                  at least 4096 rows (the big-image layers), 2 = all.  Faster on every shape of the step in isolation and when the step runs on
+//                  one stream (1.14 -> 0.65 ms per 512-clip step), but it is off by default: in the trainer's two-stream step, where the weight
+//                  gradients run NEXT TO the input-gradient chain, the step is bound by what the two streams move together, and the faster,
+//                  greedier launch costs the other stream what it gains (7.39 -> 7.48 ms at 512 clips; profiles/r05_notes.md)
+static int g_gemm2 = [] { const char* e = getenv("MKWS_TRAIN_GEMM2"); return (e && e[0] == '0') ? 0 : 1; }();
+
+static int g_tn2 = [] { const char* e = getenv("MKWS_TRAIN_GEMM_TN2"); return e ? atoi(e) : 0; }();
+static const int g_tn2_wgs = [] { const char* e = getenv("MKWS_TRAIN_TN2_WGS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();   // workgroups a TN launch aims for
+static bool tn2_wanted(int M, int N, int K) {
+  if (g_tn2 == 0) return false;
+  if (g_tn2 == 2) return true;
+  return (size_t)((M + 15) / 16) * ((N + 15) / 16) <= 256 && K >= 4096;
+}
+
 static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
                      const float* bias, int act, float* Act, hipStream_t s, float* stats = nullptr, bool* stats_done = nullptr) {
   MKWS_REQ(A && B && C, "gemm: NULL operand");
@@ -1414,6 +1818,77 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
   // chunk statistics ride in the epilogue of an unsplit NN GEMM whose row tiles are few enough for the BatchNorm launch to fold
   float* st = (stats && ksplit == 1 && !transA && !transB && !accumulate && (M + 63) / 64 <= kBnMaxGemmTiles) ? stats : nullptr;
   if (stats_done) *stats_done = st != nullptr;
+  // NN / NT on the register-ring kernel (train_gemm2_kernel) whenever the operands allow float4 accesses
+  // (activations and scratch must allow float4 accesses; weights -- B of NN / NT, C of TN, the bias -- are views at blob offsets and need not)
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool aligned = al16(A) && al16(part) && al16(Act) && al16(st) && (transA ? al16(B) : al16(C));
+  const int bvec = (reinterpret_cast<uintptr_t>(B) & 15) == 0 ? 4 : ((reinterpret_cast<uintptr_t>(B) & 7) == 0 ? 2 : 1);
+  const size_t spanA = ((size_t)(M - 1) * lda + K) * sizeof(float), spanB = (transB ? (size_t)(N - 1) * ldb + K : (size_t)(K - 1) * ldb + N) * sizeof(float);
+  if (g_gemm2 && !transA && aligned && ((K | N | lda | ldb | ldc) & 3) == 0 && spanA < 0xFFFFFF00ull && spanB < 0xFFFFFF00ull) {
+    const int T = (N + 15) / 16;
+    int nt = T <= 4 ? T : 4;                          // n-tiles per wave: the fewest idle tile slots of 4 / 3 / 2, the larger on ties
+    if (T > 4) {
+      int best = 1 << 30;
+      for (int cand = 4; cand >= 2; --cand) {
+        const int waste = (T + cand - 1) / cand * cand - T;
+        if (waste < best) { best = waste; nt = cand; }
+      }
+    }
+    const int nblk = (T + nt - 1) / nt;
+    // two row tiles per wave (every B fragment feeds both) while the launch still has ~2 workgroups per CU; BatchNorm statistics need 64-row workgroups
+    const int mt = (!st && (size_t)((M + 127) / 128) * nblk * ksplit >= 512) ? 2 : 1;
+    const dim3 grid2(nblk, (M + 64 * mt - 1) / (64 * mt), ksplit);
+#define MKWS_TG2(TB_, MT_, NT_, BV_) hipLaunchKernelGGL((train_gemm2_kernel<TB_, MT_, NT_, BV_>), grid2, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, \
+                                                        part, bias, act, ksplit > 1 ? nullptr : Act, st)
+#define MKWS_TG2_NT(TB_, MT_, BV_) do { switch (nt) { case 1: MKWS_TG2(TB_, MT_, 1, BV_); break; case 2: MKWS_TG2(TB_, MT_, 2, BV_); break; \
+                                                      case 3: MKWS_TG2(TB_, MT_, 3, BV_); break; default: MKWS_TG2(TB_, MT_, 4, BV_); break; } } while (0)
+#define MKWS_TG2_BV(MT_) do { if (bvec == 4) MKWS_TG2_NT(true, MT_, 4); else if (bvec == 2) MKWS_TG2_NT(true, MT_, 2); else MKWS_TG2_NT(true, MT_, 1); } while (0)
+    if (transB) { if (mt == 2) MKWS_TG2_BV(2); else MKWS_TG2_BV(1); }
+    else { if (mt == 2) MKWS_TG2_NT(false, 2, 4); else MKWS_TG2_NT(false, 1, 4); }
+#undef MKWS_TG2_BV
+#undef MKWS_TG2_NT
+#undef MKWS_TG2
+    if (ksplit > 1) launch_gemm_reduce(part, ksplit, C, M, N, ldc, accumulate, bias, act, Act, s);
+    MKWS_HIP(hipGetLastError());
+    return MKWS_OK;
+  }
+  // TN (weight gradients) on the register-ring kernel: small outputs over long reductions (the tall shapes of the big-image layers)
+  if (g_gemm2 && transA && !transB && aligned && !Act && ((M | N | lda | ldb | ldc) & 3) == 0 && tn2_wanted(M, N, K) &&
+      ((size_t)(K - 1) * lda + M) * sizeof(float) < 0xFFFFFF00ull && ((size_t)(K - 1) * ldb + N) * sizeof(float) < 0xFFFFFF00ull) {
+    const int TK = (M + 15) / 16, TN = (N + 15) / 16;
+    const int kt = TK >= 2 ? 2 : 1;
+    int nt = TN <= 4 ? TN : 4;
+    if (TN > 4) {
+      int best = 1 << 30;
+      for (int cand = 4; cand >= 2; --cand) {
+        const int waste = (TN + cand - 1) / cand * cand - TN;
+        if (waste < best) { best = waste; nt = cand; }
+      }
+    }
+    const int blocks = ((TK + kt - 1) / kt) * ((TN + nt - 1) / nt);
+    // slices of the rows: ~4 workgroups per CU, at least 1024 rows (16 chunks per wave) each, as far as the scratch arena reaches
+    int slices = (g_tn2_wgs + blocks - 1) / blocks;
+    const int RC = (K + 15) / 16;
+    if (slices > (RC + 63) / 64) slices = (RC + 63) / 64;
+    if (slices < 1) slices = 1;
+    while (slices > 1 && !scratch((size_t)slices * M * N)) --slices;
+    float* part2 = nullptr;
+    if (slices > 1) {
+      part2 = scratch_at((size_t)slices * M * N, s);
+      MKWS_REQ(part2, "gemm: %d row slices need %zu floats of scratch (mkws_op_set_scratch)", slices, (size_t)slices * M * N);
+    }
+    const dim3 grid3((TN + nt - 1) / nt, (TK + kt - 1) / kt, slices);
+    const size_t lds = (size_t)3 * kt * nt * 256 * sizeof(float);
+#define MKWS_TN2(KT_, NT_) hipLaunchKernelGGL((train_gemm_tn2_kernel<KT_, NT_>), grid3, dim3(256), lds, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, slices, part2)
+#define MKWS_TN2_NT(KT_) do { switch (nt) { case 1: MKWS_TN2(KT_, 1); break; case 2: MKWS_TN2(KT_, 2); break; case 3: MKWS_TN2(KT_, 3); break; default: MKWS_TN2(KT_, 4); break; } } while (0)
+    if (kt == 2) MKWS_TN2_NT(2); else MKWS_TN2_NT(1);
+#undef MKWS_TN2_NT
+#undef MKWS_TN2
+    if (slices > 1 && !fold_defer(part2, C, slices, M * N, N, ldc, 1.0f, accumulate, s))
+      launch_gemm_reduce(part2, slices, C, M, N, ldc, accumulate, nullptr, 0, nullptr, s);
+    MKWS_HIP(hipGetLastError());
+    return MKWS_OK;
+  }
 #define MKWS_TG(TA_, TB_) hipLaunchKernelGGL((train_gemm_kernel<TA_, TB_>), grid, dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, accumulate, ksplit, part, bias, act, \
                                              ksplit > 1 ? nullptr : Act, st)
   if (!transA && !transB) MKWS_TG(false, false);
@@ -1423,9 +1898,23 @@ static int gemm_impl(const float* A, const float* B, float* C, int M, int N, int
 #undef MKWS_TG
   // the fold of a weight-gradient GEMM (transA, no epilogue) may wait for the batch launch: nobody reads dW before the optimizer / all-reduce
   if (ksplit > 1 && !(transA && !Act && fold_defer(part, C, ksplit, M * N, N, ldc, 1.0f, accumulate, s)))
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N)), dim3(256), 0, s, part, ksplit, C, M, N, ldc, accumulate, bias, act, Act);
+    launch_gemm_reduce(part, ksplit, C, M, N, ldc, accumulate, bias, act, Act, s);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
+}
+
+int mkws_op_set_option(const char* name, int value) {
+  MKWS_REQ(name, "op_set_option: name is NULL");
+  if (strcmp(name, "gemm_ring") == 0) { g_gemm2 = value != 0; return MKWS_OK; }
+  if (strcmp(name, "gemm_ring_tn") == 0) { MKWS_REQ(value >= 0 && value <= 2, "gemm_ring_tn: 0, 1 or 2"); g_tn2 = value; return MKWS_OK; }
+  return fail(MKWS_ERR_INVALID_ARG, "unknown training-operator option '%s'", name);
+}
+
+int mkws_op_get_option(const char* name) {
+  MKWS_REQ(name, "op_get_option: name is NULL");
+  if (strcmp(name, "gemm_ring") == 0) return g_gemm2;
+  if (strcmp(name, "gemm_ring_tn") == 0) return g_tn2;
+  return fail(MKWS_ERR_INVALID_ARG, "unknown training-operator option '%s'", name);
 }
 
 int mkws_op_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int accumulate, int ksplit,
@@ -1593,7 +2082,7 @@ int mkws_op_dwconv_bwd(const float* X, const float* W, const float* dZ, float* d
   if (k == 3) hipLaunchKernelGGL((dw_bwd_weight_kernel<3>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   else hipLaunchKernelGGL((dw_bwd_weight_kernel<5>), grid, dim3(256), 0, st, X, dZ, part, B, H, Wd, C, s, pt, pl, Ho, Wo);
   if (!fold_defer(part, dW, chunks, k * k * C, k * k * C, k * k * C, 1.0f, 0, st))
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((k * k * C + 255) / 256), dim3(256), 0, st, part, chunks, k * k * C, dW, 1.0f, 0);
+    launch_fold_partials(part, chunks, k * k * C, dW, 1.0f, 0, st);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -1612,7 +2101,7 @@ int mkws_op_stem_bwd_weight(const float* spec, const float* dZ, float norm_mean,
   float* part = scratch_at((size_t)blocks * 288, s);
   MKWS_REQ(part, "stem_bwd_weight: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)blocks * 288);
   hipLaunchKernelGGL(stem_bwd_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, dZ, norm_mean, norm_std, part, B);
-  if (!fold_defer(part, dW, blocks, 288, 288, 288, 1.0f, 0, s)) hipLaunchKernelGGL(fold_partials_kernel, dim3(2), dim3(256), 0, s, part, blocks, 288, dW, 1.0f, 0);
+  if (!fold_defer(part, dW, blocks, 288, 288, 288, 1.0f, 0, s)) launch_fold_partials(part, blocks, 288, dW, 1.0f, 0, s);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }
@@ -1659,7 +2148,7 @@ static int se_wgrad_launch(const float* mean, const float* R, const float* dYg, 
   struct { float* part; float* out; int n; } f[4] = {{pWr, dWr, (int)nW}, {pWe, dWe, (int)nW}, {pbe, dbe, C}, {pbr, dbr, se}};
   for (auto& d : f)
     if (!fold_defer(d.part, d.out, chunks, d.n, d.n, d.n, 1.0f, 0, s))
-      hipLaunchKernelGGL(fold_partials_kernel, dim3((d.n + 255) / 256), dim3(256), 0, s, d.part, chunks, d.n, d.out, 1.0f, 0);
+      launch_fold_partials(d.part, chunks, d.n, d.out, 1.0f, 0, s);
   return MKWS_OK;
 }
 
@@ -1725,7 +2214,7 @@ int mkws_op_bias_act_bwd(const float* Z, const float* bias, int act, float* dA, 
   MKWS_REQ(part, "bias_act_bwd: needs %zu floats of scratch (mkws_op_set_scratch)", (size_t)chunks * N);
   // one pass: dA <- dA * act'(Z + bias) in place and this chunk's column sums; then the chunks fold in order into dbias
   hipLaunchKernelGGL((col_sum_partial_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, dA, Z, bias, act, part, M, N);
-  if (!fold_defer(part, dbias, chunks, N, N, N, 1.0f, 0, s)) hipLaunchKernelGGL(fold_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, chunks, N, dbias, 1.0f, 0);
+  if (!fold_defer(part, dbias, chunks, N, N, N, 1.0f, 0, s)) launch_fold_partials(part, chunks, N, dbias, 1.0f, 0, s);
   MKWS_HIP(hipGetLastError());
   return MKWS_OK;
 }

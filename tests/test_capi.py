@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
     lib = _lib.lib()
-    assert lib.mkws_abi_version() == _lib.ABI_VERSION == 4 and lib.mkws_build_arch() == b"gfx950"
+    assert lib.mkws_abi_version() == _lib.ABI_VERSION == 5 and lib.mkws_build_arch() == b"gfx950"
 
 
 CONFIGS = [

@@ -37,10 +37,37 @@ def ops():
     return o
 
 
+@pytest.fixture(params=[0, 2], ids=["tn-staged", "tn-ring"])
+def ring_tn(request, ops):
+    """Weight gradients on the LDS-staged kernel (the shipped default) and on the register-ring kernel (mkws_op_set_option "gemm_ring_tn")."""
+    old = ops.L.mkws_op_get_option(b"gemm_ring_tn")
+    ops.check(ops.L.mkws_op_set_option(b"gemm_ring_tn", request.param))
+    yield request.param
+    ops.check(ops.L.mkws_op_set_option(b"gemm_ring_tn", old))
+
+
+def test_training_operator_options(ops):
+    L = ops.L
+    assert L.mkws_op_get_option(b"gemm_ring") == 1 and L.mkws_op_get_option(b"gemm_ring_tn") == 0          # shipped defaults
+    assert L.mkws_op_set_option(b"gemm_ring_tn", 3) < 0 and L.mkws_op_set_option(b"no_such_option", 1) < 0 and L.mkws_op_get_option(b"no_such_option") < 0
+    for name, vals in ((b"gemm_ring", (0, 1)), (b"gemm_ring_tn", (1, 2, 0))):
+        for v in vals:
+            assert L.mkws_op_set_option(name, v) == 0 and L.mkws_op_get_option(name) == v
+
+
 @pytest.mark.parametrize("M,N,K,ta,tb,ks", [(130, 96, 16, 0, 0, 1), (77, 24, 144, 0, 0, 1), (64, 40, 100, 0, 1, 1), (16, 96, 4000, 1, 0, 7),
                                             (240, 10, 6, 0, 0, 1), (5, 6, 240, 0, 1, 1), (2048, 1024, 8, 1, 0, 1), (33, 65, 17, 1, 1, 1),
-                                            (64, 2048, 2048, 0, 0, 0), (16, 96, 32000, 1, 0, 0), (64, 300, 1000, 0, 1, 0), (100, 70, 33, 0, 0, 0)])
-def test_gemm_all_transposes(ops, M, N, K, ta, tb, ks):
+                                            (64, 2048, 2048, 0, 0, 0), (16, 96, 32000, 1, 0, 0), (64, 300, 1000, 0, 1, 0), (100, 70, 33, 0, 0, 0),
+                                            # shapes of the register-ring kernel (NN / NT with K, N % 4 == 0; round 5): two row tiles per wave
+                                            # (M large), K tails of 4 / 8 / 12 columns, ragged last row / column tiles, explicit split-K
+                                            (70000, 16, 32, 0, 0, 1), (4099, 144, 24, 0, 0, 1), (4099, 24, 144, 0, 1, 1), (300, 96, 2048, 0, 0, 4),
+                                            (513, 112, 672, 0, 1, 0), (1000, 40, 8, 0, 0, 1), (50, 4, 4, 0, 0, 1), (6144, 480, 80, 0, 0, 1),
+                                            (2048, 192, 1152, 0, 1, 0), (777, 80, 44, 0, 0, 1), (777, 44, 80, 0, 1, 1), (130, 240, 12, 0, 0, 1),
+                                            # weight gradients of the big-image layers on the register-ring TN kernel (small outputs over >= 4096 rows):
+                                            # row tails, ragged output tiles, one and two k-tiles per workgroup
+                                            (32, 16, 70000, 1, 0, 0), (96, 24, 5003, 1, 0, 0), (24, 144, 4099, 1, 0, 0), (144, 40, 17920, 1, 0, 0),
+                                            (8, 4, 4096, 1, 0, 0), (240, 240, 4500, 1, 0, 0), (40, 240, 9000, 1, 0, 1)])
+def test_gemm_all_transposes(ops, M, N, K, ta, tb, ks, ring_tn):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
     B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
@@ -58,6 +85,39 @@ def test_gemm_all_transposes(ops, M, N, K, ta, tb, ks):
     if ks == 1:      # accumulate
         ops.check(ops.L.mkws_op_gemm(ops.p(dA), ops.p(dB), ops.p(C), M, N, K, A.shape[1], B.shape[1], N, ta, tb, 1, 1, ops.s()))
         assert _rel(C.cpu().numpy(), 2 * ref) < 1e-5
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_gemm_on_weight_views_at_blob_offsets(ops, shift, ring_tn):
+    """The trainer's weights and weight gradients are views into flat buffers at their blob offsets -- for most tensors 8 bytes off a 16-byte
+    boundary.  The register-ring kernels take B (NN / NT) and C (TN) at any 4-byte alignment: float4, float2 or dword pieces of the NT fragment,
+    dword loads for NN, element stores for the weight gradient.  Results must equal those on aligned copies bit for bit (same arithmetic)."""
+    rng = np.random.default_rng(shift)
+    M, K, N = 1000, 96, 24
+    X, W, dZ = (rng.standard_normal(sh).astype(np.float32) for sh in ((M, K), (K, N), (M, N)))
+    dX_ref, dW_ref, Z_ref = dZ.astype(np.float64) @ W.T.astype(np.float64), X.T.astype(np.float64) @ dZ.astype(np.float64), X.astype(np.float64) @ W.astype(np.float64)
+    flat = torch.zeros(K * N + 8, dtype=torch.float32, device=ops.dev)
+    gflat = torch.full((K * N + 8,), 5.0, dtype=torch.float32, device=ops.dev)
+    Wv, dWv = flat[shift:shift + K * N].view(K, N), gflat[shift:shift + K * N].view(K, N)
+    Wv.copy_(ops.t(W))
+    assert Wv.data_ptr() % 16 == 4 * shift
+    dX, dZd, Xd = ops.t(X), ops.t(dZ), ops.t(X)
+    outs = {}
+    for name, Wt, dWt in (("view", Wv, dWv), ("aligned", ops.t(W), torch.full((K, N), 5.0, dtype=torch.float32, device=ops.dev))):
+        Z = torch.empty((M, N), dtype=torch.float32, device=ops.dev)
+        dXo = torch.empty((M, K), dtype=torch.float32, device=ops.dev)
+        ops.check(ops.L.mkws_op_gemm(ops.p(Xd), ops.p(Wt), ops.p(Z), M, N, K, K, N, N, 0, 0, 0, 1, ops.s()))               # forward: NN
+        ops.check(ops.L.mkws_op_gemm(ops.p(dZd), ops.p(Wt), ops.p(dXo), M, K, N, N, N, K, 0, 1, 0, 1, ops.s()))            # input gradient: NT
+        ops.check(ops.L.mkws_op_gemm(ops.p(Xd), ops.p(dZd), ops.p(dWt), K, N, M, K, N, N, 1, 0, 0, 0, ops.s()))            # weight gradient: TN (split, folded)
+        dW1 = dWt.clone()
+        ops.check(ops.L.mkws_op_gemm(ops.p(Xd), ops.p(dZd), ops.p(dWt), K, N, M, K, N, N, 1, 0, 1, 1, ops.s()))            # TN, unsplit, accumulating (direct stores)
+        outs[name] = (Z, dXo, dW1, dWt.clone())
+    for a, b in zip(outs["view"], outs["aligned"]):
+        assert torch.equal(a, b)
+    Z, dXo, dW1, dW2 = outs["view"]
+    assert _rel(Z.cpu().numpy(), Z_ref) < 1e-5 and _rel(dXo.cpu().numpy(), dX_ref) < 1e-5 and _rel(dW1.cpu().numpy(), dW_ref) < 1e-5
+    assert _rel(dW2.cpu().numpy(), 2 * dW_ref) < 1e-5
+    assert float(gflat[:shift].min()) == 5.0 and float(gflat[shift + K * N:].min()) == 5.0 and float(gflat[shift + K * N:].max()) == 5.0     # nothing stored around the view
 
 
 @pytest.mark.parametrize("B,HW,C,act", [(6, 35, 40, 0), (5, 130, 24, 1)])
