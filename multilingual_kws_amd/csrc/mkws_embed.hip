@@ -2649,6 +2649,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca)
 // records the failure (pair_report); every later launch of the handle then poisons without exchanging, and the next
 // mkws_embed_forward moves the handle to mbconv_block_kernel for good and returns MKWS_ERR_EXCHANGE (check_pair_health).
 // Reductions keep a fixed order (p0 + p1 commutes), so results are bit-identical across batch sizes.
+// Store of an exchange partial (pair chain).  -DMKWS_PAIR_NT_STORES builds the A/B library whose exchange stores carry the non-temporal hint
+// (round-5 PMC A/B of the chain's HBM write traffic, profiles/r05_notes.md: no gain, the plain store ships).
+#ifdef MKWS_PAIR_NT_STORES
+#define MKWS_XSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define MKWS_XSTORE(ptr, val) (*(ptr) = (val))
+#endif
+
 struct PairArgs {
   BlockArgs b;
   float* xc1;      // [pairs][2][384]
@@ -3331,7 +3339,7 @@ __device__ __forceinline__ void pair_chain_block(const BlockArgs& a, const Block
             const int t = wave + NWAVES * q;
             if (t < a.NTp) {
 #pragma unroll
-              for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(xd_mine + ((size_t)(t * 2 + m) * 64 + lane) * 4) = acc[q][m];
+              for (int m = 0; m < MT; ++m) MKWS_XSTORE(reinterpret_cast<f32x4*>(xd_mine + ((size_t)(t * 2 + m) * 64 + lane) * 4), acc[q][m]);
             }
           }
         }
