@@ -130,8 +130,9 @@ def load_models_shared(model_paths, max_batch=1024):
     return out
 
 
-FORWARD_CLIPS = 1024     # clips per embedding forward of the frozen phase (the plan the headline benchmark runs: 0.45 ms per 512 clips
-                         # against 0.63 ms on a 512-clip handle, profiles/r04_notes.md)
+FORWARD_CLIPS = 2048     # clips per embedding forward of the frozen phase.  Measured on one MI355X, 512 clips per optimizer step, same call
+                         # (profiles/r05_notes.md): 512 clips per forward (a forward per step) 0.74 ms per step; 1024: 0.579; 2048: 0.546 (the kernels'
+                         # workgroup loops run two rounds per launch: half the launch boundaries and tails per clip); 4096: 0.93 (falls off)
 
 
 def steps_per_forward(batch_size, forward_clips=None):
