@@ -16,16 +16,16 @@ timeout 300 python tools/train_bench.py 64 512 2>&1 | grep "B=" > gpurun_out/r05
 bash tools/gpu/latency_stats.sh 1 > gpurun_out/r05_latency_stats.txt 2>&1; cp $(find gpurun_out/lat_stats -name "*kernel_stats.csv" | head -1) gpurun_out/r05_kernel_stats_latency.csv; tail -2 gpurun_out/r05_latency_stats.txt
 # the reference's canonical fine-tune shape (transfer_learning.py: 64 clips per step): 16 optimizer steps per forward pass vs one
 for g in 16 1; do
-  timeout 300 python bench.py --config finetune --batch 64 --ft-group $g --no-cpu-baseline > gpurun_out/r05_bench_finetune64_g$g.json 2> gpurun_out/r05_bench_finetune64_g$g.err
+  timeout 300 python bench.py --config finetune --batch 64 --ft-group $g --no-cpu-baseline > gpurun_out/r05_variant_finetune64_g$g.json 2> gpurun_out/r05_variant_finetune64_g$g.err
   python -c "
-import json;d=json.load(open('gpurun_out/r05_bench_finetune64_g$g.json'));print('finetune batch 64, steps per forward $g:', d['value'], 'clips/s', d['ms_per_step'], 'ms per optimizer step')"
+import json;d=json.load(open('gpurun_out/r05_variant_finetune64_g$g.json'));print('finetune batch 64, steps per forward $g:', d['value'], 'clips/s', d['ms_per_step'], 'ms per optimizer step')"
 done
-timeout 300 python bench.py --config finetune --no-cpu-baseline --ft-group 1 > gpurun_out/r05_bench_finetune_g1.json 2>/dev/null
+timeout 300 python bench.py --config finetune --no-cpu-baseline --ft-group 1 > gpurun_out/r05_variant_finetune_g1.json 2>/dev/null
 timeout 300 python tools/finetune_group_profile.py > gpurun_out/r05_finetune_group_profile.txt 2>&1
 python - <<'PY'
 import json
 for c in ("embed","frontend","finetune","stream"):
     d=json.load(open(f"gpurun_out/final/r05_bench_{c}.json")); r=d["roofline"]
     print(c, d["value"], d["unit"], d["ms_per_step"], r["kernel"], r["frac"], r.get("whole_step_frac"), r.get("time_weighted_frac"), r["traffic"], d.get("latency_ms_batch1"), d.get("latency_ms_batch1_eager"), d["cpu_baseline"]["value"], d["cpu_baseline"]["single_thread"]["value"])
-d=json.load(open("gpurun_out/r05_bench_finetune_g1.json")); print("finetune, one forward per step:", d["value"], d["ms_per_step"])
+d=json.load(open("gpurun_out/r05_variant_finetune_g1.json")); print("finetune, one forward per step:", d["value"], d["ms_per_step"])
 PY
