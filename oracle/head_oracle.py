@@ -3,7 +3,8 @@
 SparseCategoricalCrossentropy, Keras Adam (keras/optimizer_v2/adam.py).
 
 TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED BY THE REFERENCE (no tests/vectors there; Keras is not
-installable here): checked against finite differences and hand-computed cases in tests/.
+installable here): checked against finite differences, hand-computed cases and -- loss, gradients and 50 Adam steps -- a PyTorch
+float64 autograd / torch.optim.Adam rendering of the same head (tests/test_oracle_head.py).
 Parameter vector layout: W1[in,hid] | b1[hid] | W2[hid,cls] | b2[cls].
 """
 import numpy as np

@@ -42,3 +42,43 @@ def test_init_and_probabilities():
     assert np.abs(W1).max() <= np.sqrt(6 / (1024 + 18)) and np.abs(W2).max() <= np.sqrt(6 / 21)
     probs, _ = ho.forward(p, np.random.default_rng(0).standard_normal((5, 1024)))
     assert np.allclose(probs.sum(1), 1) and (probs > 0).all()
+
+
+def test_head_oracle_against_pytorch_autograd_and_adam():
+    """A pin of the head oracle that this project did not write: the same head in PyTorch (torch.nn.functional linear / tanh / cross_entropy in
+    float64, gradients by autograd) and torch.optim.Adam.  Keras' Adam (optimizer_v2/adam.py: theta -= lr_t m / (sqrt(v) + eps) with lr_t =
+    lr sqrt(1 - b2^t) / (1 - b1^t)) and PyTorch's (theta -= lr / (1 - b1^t) m / (sqrt(v) / sqrt(1 - b2^t) + eps)) are the same recurrence
+    up to where eps sits: Keras(eps) == PyTorch(eps / sqrt(1 - b2^t)) at step t, so the torch optimizer's eps is set per step.  50 steps on fresh
+    batches: loss, every gradient and every parameter agree to float64 round-off -- m / v recurrences, bias correction and update included."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    dims = (40, 18, 3)
+    n = dims[0] * dims[1] + dims[1] + dims[1] * dims[2] + dims[2]
+    p = ho.glorot_uniform_params(*dims, seed=5).astype(np.float64)
+    p[dims[0] * dims[1]:dims[0] * dims[1] + dims[1]] = 0.1 * rng.standard_normal(dims[1])         # non-zero biases
+    W1, b1, W2, b2 = [torch.tensor(a.copy(), dtype=torch.float64, requires_grad=True) for a in ho.unpack(p, *dims)]
+    lr, beta1, beta2, eps = 1e-2, 0.9, 0.999, 1e-7
+    topt = torch.optim.Adam([W1, b1, W2, b2], lr=lr, betas=(beta1, beta2), eps=eps)
+    opt = ho.KerasAdam(n, lr=lr, beta1=beta1, beta2=beta2, eps=eps)
+    for t in range(1, 51):
+        x = rng.standard_normal((16, dims[0])) * 0.5
+        y = rng.integers(0, 3, 16)
+        loss, g, ncorrect, lsum = ho.loss_and_grad(p, x, y, *dims)
+        topt.zero_grad()
+        xt = torch.tensor(x, dtype=torch.float64)
+        logits = F.linear(torch.tanh(F.linear(xt, W1.T, b1)), W2.T, b2)
+        tloss = F.cross_entropy(logits, torch.tensor(y, dtype=torch.long))            # mean sparse CE from logits = Keras' softmax + SparseCategoricalCrossentropy
+        tloss.backward()
+        tg = np.concatenate([W1.grad.numpy().ravel(), b1.grad.numpy(), W2.grad.numpy().ravel(), b2.grad.numpy()])
+        assert abs(float(tloss) - loss) < 1e-12 and np.abs(tg - g).max() < 1e-13, t
+        assert ncorrect == int((logits.argmax(1).numpy() == y).sum())
+        probs, _ = ho.forward(p, x, *dims)
+        assert np.abs(probs - torch.softmax(logits, 1).detach().numpy()).max() < 1e-14
+        for grp in topt.param_groups:
+            grp["eps"] = eps / np.sqrt(1.0 - beta2 ** t)
+        topt.step()
+        p = opt.step(p, g)
+        tp = np.concatenate([W1.detach().numpy().ravel(), b1.detach().numpy(), W2.detach().numpy().ravel(), b2.detach().numpy()])
+        assert np.abs(tp - p).max() < 1e-12, t
+    assert np.abs(p - ho.glorot_uniform_params(*dims, seed=5)).max() > 0.05                      # the 50 steps moved the parameters
