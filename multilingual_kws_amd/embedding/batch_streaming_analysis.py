@@ -218,8 +218,8 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
         if degraded() != degraded0 or any(g.exchange_failed() or g.heals != h0 for g, h0 in graphs_used.items()):
             if not _retry:
                 # the repeat ran with every handle of the stream off the exchange kernels (below): nothing left that could fail this way
-                from .._lib import MkwsError
-                raise MkwsError("an in-kernel exchange failed again while the stream was being repeated on the single-workgroup kernels")
+                from .._lib import MKWS_ERR_EXCHANGE, MkwsError
+                raise MkwsError(MKWS_ERR_EXCHANGE, "an in-kernel exchange failed again while the stream was being repeated on the single-workgroup kernels")
             import warnings
             warnings.warn("multilingual_kws_amd: an in-kernel exchange failed during a graph replay; repeating the stream on the single-workgroup kernels", RuntimeWarning)
             # EVERY serving-lane replica leaves the exchange kernels before the repeat, not only the handle whose error word was set: a

@@ -233,3 +233,47 @@ def test_graph_serving_recovers_from_a_failed_exchange(batch, tmp_path):
     assert any("repeating the stream" in str(x.message) for x in w)
     for r, g in zip(ref, got):
         assert np.isfinite(g).all() and np.allclose(g, r, rtol=1e-4, atol=1e-6) and np.array_equal(g.argmax(1), r.argmax(1))
+
+
+@pytest.mark.gpu
+def test_offline_stream_raises_when_the_repeat_fails_too(tmp_path):
+    """streaming_inferences repeats a stream once after a failed in-graph exchange -- with EVERY serving-lane replica taken off the exchange
+    kernels first -- and must not hand back poisoned probabilities if the repeat reports a failure as well: MkwsError(MKWS_ERR_EXCHANGE)."""
+    torch = pytest.importorskip("torch")
+    import warnings
+    from multilingual_kws_amd import _lib
+    from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+    from multilingual_kws_amd.head import Head
+    ms = input_data.standard_microspeech_model_settings(3)
+    emb, blob = tl.load_base_model("synthetic", max_batch=64)
+    if emb.get_option("fuse_pair") != 1:
+        pytest.skip("the exchange kernels are not in this handle's plan on this device")
+    models = [tl.TransferLearnedModel(emb, Head(max_batch=64, seed=s), blob, "synthetic") for s in range(2)]
+    rng = np.random.default_rng(4)
+    pcm = np.concatenate([tone_clip(500 + 200 * k, rng, n=8000) for k in range(8)])
+    audio = pcm.astype(np.float32) / 32768
+    ref = bsa.streaming_inferences(models, ms, audio, batch_windows=32)
+    orig_run = bsa._BatchGraph.run
+
+    def always_fail(self, parts):                               # every replay leaves the error word set, as a failed exchange would
+        out = orig_run(self, parts)
+        self.keep[0][0].set_option("inject_exchange_error", 1)
+        return out
+    bsa._BatchGraph.run = always_fail
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            with pytest.raises(_lib.MkwsError) as ei:
+                bsa.streaming_inferences(models, ms, audio, batch_windows=32)
+        assert ei.value.code == _lib.MKWS_ERR_EXCHANGE
+    finally:
+        bsa._BatchGraph.run = orig_run
+    # every handle of the stream left the exchange kernels before the repeat; the stream runs clean again afterwards
+    reps = [emb] + list(emb._replicas)
+    assert all(e.get_option("fuse_pair") == 0 and e.get_option("fuse_cluster") == 0 for e in reps)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        emb.forward(torch.zeros((1, 49, 40), device=emb.device))          # (clears the injected word: the wrapper repeats the call that reports it)
+    again = bsa.streaming_inferences(models, ms, audio, batch_windows=32)
+    for r, g in zip(ref, again):
+        assert np.isfinite(g).all() and np.allclose(g, r, rtol=1e-4, atol=1e-6)

@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest -m gpu -q tests/test_streaming.py 2>&1 | tail -8
