@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--profile-reps", type=int, default=5)
     ap.add_argument("--ft-group", type=int, default=None, help="finetune: optimizer steps per forward pass of the frozen embedding "
                     "(default: transfer_learn's own rule, 1024 // batch; 1 = a forward pass per step as in rounds 1-4)")
-    ap.add_argument("--ft-overlap", type=int, default=0, help="finetune: optimizer steps on a second stream under the next group's kernels (A/B; off in transfer_learn: it measured 1 % slower)")
+    ap.add_argument("--ft-overlap", type=int, default=-1, help="finetune: optimizer steps on a second stream under the next group's kernels: 1 / 0, -1 = transfer_learn's own rule (on from 4 steps per forward)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B execution switch passed to mkws_embed_set_option (e.g. fuse_block=1); default = shipped plan")
     return ap.parse_args()
@@ -417,7 +417,7 @@ def main():
         train_ds = ds.init_single_target(input_data.AUTOTUNE, d["train"], is_training=True).shuffle(1000).repeat().batch(B)
         p0 = np.random.default_rng(0).uniform(-0.07, 0.07, 18507).astype(np.float32)      # identical head on every rank
         head = Head(params=p0, max_batch=B, device=dev)
-        ft = tl.FrozenHeadTrainer(em, head, train_ds, B, 1e-3, group=ft_group, overlap=bool(args.ft_overlap))
+        ft = tl.FrozenHeadTrainer(em, head, train_ds, B, 1e-3, group=ft_group, overlap=None if args.ft_overlap < 0 else bool(args.ft_overlap))
         extra_out.update({"steps_per_forward": ft.G, "head_steps_on_second_stream": ft.overlap})
 
         def step():

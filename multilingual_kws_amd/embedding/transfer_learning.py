@@ -130,9 +130,11 @@ def load_models_shared(model_paths, max_batch=1024):
     return out
 
 
-FORWARD_CLIPS = 2048     # clips per embedding forward of the frozen phase.  Measured on one MI355X, 512 clips per optimizer step, same call
-                         # (profiles/r05_notes.md): 512 clips per forward (a forward per step) 0.74 ms per step; 1024: 0.579; 2048: 0.546 (the kernels'
-                         # workgroup loops run two rounds per launch: half the launch boundaries and tails per clip); 4096: 0.93 (falls off)
+FORWARD_CLIPS = 3072     # clips per embedding forward of the frozen phase.  Measured on one MI355X, 512 clips per optimizer step, same calls
+                         # (profiles/r05_notes.md section 6): 512 clips per forward (a forward per step) 0.74 ms per step; 1024: 0.58; 2048: 0.548; 3072: 0.534;
+                         # 4096: 0.536 (whole multiples of the 1024-clip plan: its workgroup loops run several rounds per launch -- fewer launch
+                         # boundaries and tails per clip; 1536 / 2560 clips, a partial last round, are slower than 1024 / 2048)
+OVERLAP_FROM_GROUP = 4   # optimizer steps on a second stream from this many steps per forward: +3-4 % at 4 / 6 / 8 steps, -1 % at 2
 
 
 def steps_per_forward(batch_size, forward_clips=None):
@@ -151,14 +153,15 @@ class FrozenHeadTrainer:
     all-reduce under torch.distributed -- the semantics of parallel.dp_step, unchanged.  With overlap=True the optimizer steps (a few
     small launches each, nowhere near filling the chip) go to a second stream and run under the NEXT group's augmentation, frontend and
     embedding kernels; two embedding buffers alternate, events order producer and consumer.  Measured on one MI355X at 512 clips per
-    step (profiles/r05_notes.md): one forward per step 663.6 k clips/s, two steps per forward 853.9 k, + the second stream 844.2 k --
-    the embedding kernels fill the chip, the head's launches only take turns with them -- so overlap is off by default.
+    step (profiles/r05_notes.md): with two steps per forward the second stream loses 1 % (853.9 k -> 844.2 k clips/s: the head's few
+    launches only take turns with the embedding's), from four steps per forward it gains 3-4 % (932 k -> 966 k at 4, 958 k -> 984 k at 6):
+    overlap=None switches it on from OVERLAP_FROM_GROUP steps per forward.  Results are bit-identical either way.
 
     step() performs exactly one optimizer step and returns its [sum of row losses, #correct] (summed over ranks) as a device tensor
     that is rewritten by the next step() and lives on the trainer's stream: add it up with accumulate(), or read it after finish()
     (which joins the side stream; call it before reading head parameters elsewhere)."""
 
-    def __init__(self, embedding, head, train_ds, batch_size, lr, group=None, overlap=False):
+    def __init__(self, embedding, head, train_ds, batch_size, lr, group=None, overlap=None):
         import torch
         self.embedding, self.head, self.lr = embedding, head, lr
         self.bs = int(batch_size)
@@ -167,7 +170,7 @@ class FrozenHeadTrainer:
         if self.groups.bs != self.bs:
             raise ValueError(f"dataset is batched by {self.groups.bs}, trainer by {self.bs}")
         self.device = embedding.device
-        self.overlap = bool(overlap)
+        self.overlap = (self.G >= OVERLAP_FROM_GROUP) if overlap is None else bool(overlap)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         nbuf = 2 if self.overlap else 1
         self.emb = [torch.empty((self.G * self.bs, embedding.output_dim), dtype=torch.float32, device=self.device) for _ in range(nbuf)]

@@ -308,6 +308,6 @@ def test_batch_groups_make_the_draws_of_the_step_by_step_stream(tmp_path):
     assert np.array_equal(g2._next_indices(), want[:12]) and np.array_equal(g2.buf, want[12:])
     with pytest.raises(ValueError):
         input_data.BatchGroups(input_data.ClipDataset(stream(1, 2).owner, d["train"], ["target"] * len(d["train"]), True).batch(2))   # no .repeat()
-    assert transfer_learning.FORWARD_CLIPS == 2048
-    assert transfer_learning.steps_per_forward(512) == 4 and transfer_learning.steps_per_forward(64) == 32
+    assert transfer_learning.FORWARD_CLIPS == 3072 and transfer_learning.OVERLAP_FROM_GROUP == 4
+    assert transfer_learning.steps_per_forward(512) == 6 and transfer_learning.steps_per_forward(64) == 48
     assert transfer_learning.steps_per_forward(2048) == 1 and transfer_learning.steps_per_forward(4096) == 1 and transfer_learning.steps_per_forward(512, 1024) == 2

@@ -124,8 +124,8 @@ def test_transfer_learn_contract_and_learning(data, tmp_path):
     assert np.abs(preds - ref_probs).max() < 1e-4 and np.array_equal(preds.argmax(1), ref_probs.argmax(1))
     # save / load round trip
     model.save(str(tmp_path / "m"))
-    # (the frozen phase embeds FORWARD_CLIPS // batch_size batches per forward pass: the returned model's handle is planned for 2048 clips)
-    assert model.embedding.max_batch == 64 * tl.steps_per_forward(64) == tl.FORWARD_CLIPS == 2048
+    # (the frozen phase embeds FORWARD_CLIPS // batch_size batches per forward pass: the returned model's handle is planned for 3072 clips)
+    assert model.embedding.max_batch == 64 * tl.steps_per_forward(64) == tl.FORWARD_CLIPS == 3072
     again = tl.TransferLearnedModel.load(str(tmp_path / "m"), max_batch=model.embedding.max_batch)       # same handle size = same plan: bit for bit
     assert np.array_equal(again.predict(specs[..., None]), model.predict(specs[..., None]))
     small = tl.TransferLearnedModel.load(str(tmp_path / "m"), max_batch=64)                              # another plan: fp32 round-off

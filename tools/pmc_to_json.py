@@ -70,7 +70,7 @@ def main():
         out[k] = {"fetch_size_kib": round(fk, 1), "write_size_kib": round(wk, 1), "hbm_bytes_per_launch": int(round((2.0 * fk + wk) * 1024))}
     # the handles of the fine-tune (512 clips) and streaming (256) configs launch other workgroup shapes and move other byte counts per
     # launch: extra passes with ONE_FWD_B=512 / 256, stored as "<label>@<batch>" (bench.py looks a kernel up under its config's batch)
-    for bsz in (2048, 512, 256):
+    for bsz in (3072, 2048, 512, 256):
         fd, wd = os.path.join(base, f"pmc_fetch_{bsz}"), os.path.join(base, f"pmc_write_{bsz}")
         if not (os.path.isdir(fd) and os.path.isdir(wd)):
             continue
