@@ -140,3 +140,62 @@ def test_embedding_gradient_allreduce_two_ranks_equals_the_sum_of_the_shards():
     gmax = max(float(np.abs(v).max()) for v in want.values())
     for k, v in want.items():
         assert np.abs(got[k] - v).max() <= 1e-5 * max(float(np.abs(v).max()), 1e-3 * gmax), k
+
+
+def _grouped_worker(rank, world, port, out, root):
+    dist = _init(rank, world, port)
+    try:
+        from multilingual_kws_amd import weights
+        from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
+        from multilingual_kws_amd.embedding_model import EmbeddingModel
+        from multilingual_kws_amd.head import Head
+        from oracle import head_oracle as ho
+        from tests.util_data import make_fewshot_dataset
+        data = make_fewshot_dataset(os.path.join(root, f"rank{rank}"), n_unknown=16)
+        ms = input_data.standard_microspeech_model_settings(3)
+        em = EmbeddingModel(weights.synthetic_blob(), max_batch=64)
+        res = {}
+        for overlap in (False, True):
+            ds = input_data.AudioDataset(ms, ["target"], data["bg_dir"], data["unknown"], unknown_percentage=50.0,
+                                         spec_aug_params=input_data.SpecAugParams(percentage=80), seed=7 + 1000003 * rank)
+            tds = ds.init_single_target(input_data.AUTOTUNE, data["train"], is_training=True).shuffle(1000).repeat().batch(16)
+            head = Head(params=ho.glorot_uniform_params(seed=4), max_batch=16)
+            calls, real = [], dist.all_reduce
+
+            def counting(t, *a, **k):
+                calls.append(t.numel())
+                return real(t, *a, **k)
+            dist.all_reduce = counting
+            ft = tl.FrozenHeadTrainer(em, head, tds, 16, 1e-2, group=4, overlap=overlap)
+            for i in range(10):
+                ft.step(group_limit=10 - i)
+            ft.finish()
+            torch.cuda.synchronize()
+            dist.all_reduce = real
+            assert calls == [head.nparams + 2] * 10 and ft.forwards == 3, (calls, ft.forwards)      # one collective per OPTIMIZER step: groups 4, 4, 2
+            res[overlap] = head.get_params()
+        assert np.array_equal(res[False], res[True])                                                 # the second stream changes nothing
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res[True])
+        if rank == 0:
+            out.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_grouped_fine_tune_two_ranks_keeps_one_collective_per_step_and_identical_replicas(tmp_path):
+    """transfer_learning.FrozenHeadTrainer under 2 ranks over RCCL: G optimizer steps share a forward pass, every step still does its OWN
+    all-reduce of [gradients | loss sum | #correct] (on the second stream when overlap is on), the replicas end bit-identical, and the
+    second stream changes nothing."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_grouped_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    per_rank = q.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(per_rank[0], per_rank[1])
