@@ -156,13 +156,16 @@ def test_ragged_batch_sizes_and_row_masks(ctx):
 
 
 def test_full_batch_properties(ctx):
-    """BASELINE size (B=1024): oracle on a subset, batch-composition invariance and determinism on all."""
+    """BASELINE size (B=1024): EVERY row against the oracle (round 5: the PyTorch-CPU oracle embeds 128 clips in 0.1 s, there is no reason for a
+    subset), batch-composition invariance and determinism on all."""
     rng = np.random.default_rng(2)
     spec = _spec(rng, 1024)
     x = torch.from_numpy(spec).to(ctx["dev"])
     emb = ctx["em"].forward(x)
-    idx = np.arange(0, 1024, 97)
-    assert _rel(emb[idx].cpu().numpy(), ctx["oracle"].forward(spec[idx]).numpy()) < REL_TOL
+    got = emb.cpu().numpy()
+    ref = np.concatenate([ctx["oracle"].forward(spec[s:s + 128]).numpy() for s in range(0, 1024, 128)])
+    assert _rel(got, ref) < REL_TOL
+    assert np.abs(got - ref).max(axis=1).max() < REL_TOL * np.abs(ref).max()             # no single row off, whatever its workgroup / pair half
     perm = torch.randperm(1024, device=ctx["dev"])
     assert torch.equal(ctx["em"].forward(x[perm]), emb[perm])
     assert torch.equal(ctx["em"].forward(x), emb)

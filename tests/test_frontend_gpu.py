@@ -109,14 +109,16 @@ def test_shapes_empty_short_and_unaligned(dev):
 
 
 def test_full_batch_properties(dev):
-    """BASELINE size (B=1024): oracle on a subset + clip independence / permutation invariance on all."""
+    """BASELINE size (B=1024): EVERY clip bit for bit against the C oracle (raw integers and scaled features), clip independence / permutation
+    invariance on all."""
     from multilingual_kws_amd import synth
     a = synth.clips_float32(1024)
     fe = _fe()
     x = torch.from_numpy(a).to(dev)
     spec, raw = fe.forward(x, want_raw=True)
-    idx = np.arange(0, 1024, 37)
-    assert np.array_equal(spec[idx].cpu().numpy(), _oracle().run_batch_f32(a[idx]))
+    ref_spec, ref_raw = _oracle().run_batch_f32(a, want_u16=True)
+    assert np.array_equal(spec.cpu().numpy(), ref_spec)
+    assert np.array_equal(raw.cpu().numpy().view(np.uint16), ref_raw)
     perm = torch.randperm(1024, device=dev)
     assert torch.equal(fe.forward(x[perm]), spec[perm])                                   # clips are independent
     assert torch.equal(fe.forward(x[5:6])[0], spec[5])                                     # batch-size invariant
