@@ -101,7 +101,7 @@ def test_streaming_inferences_match_per_window_predict(tmp_path):
     """Frame sharing, graph replay and multi-head serving against the package's own per-window predict (HIP vs HIP, bit for bit).  That
     comparison is sound because each leg is oracle-checked on its own -- frame sharing against the C oracle (tests/test_frontend_gpu.py,
     hops 320 / 640 / 1600), the embedding (tests/test_embedding_gpu.py), the heads (tests/test_head_gpu.py) -- and the row does not rest on
-    transitivity alone: tests/test_surface.py::test_fifty_keyword_detections_from_one_embedding_pass compares 8 windows of a 50-head
+    transitivity alone: tests/test_surface.py::test_fifty_keyword_detections_from_one_embedding_pass compares every window of a 50-head
     stream with the CPU oracle chain directly."""
     torch = pytest.importorskip("torch")
     from multilingual_kws_amd.embedding import input_data, transfer_learning as tl
