@@ -519,9 +519,11 @@ class H5File:
         p += 32
         _name_off, root_oh, cache, _r = struct.unpack_from("<QQII", b, p)
         self.root = root_oh
-        # addresses in the file are relative to the base address (a user block in front of the superblock moves it)
-        if self.eof + self.base_addr > len(b):
-            raise CheckpointFormatError(f"{path}: truncated (end-of-file address {self.eof} + base address {self.base_addr}, file has {len(b)} bytes)")
+        # OBJECT addresses in the file are relative to the base address (a user block in front of the superblock moves it: _span);
+        # the END-OF-FILE address is stored absolute (libhdf5 writes rel_eoa + base_addr: a file h5py wrote with userblock_size=512
+        # has base 512 and eof == its size), so it is compared with the file length as it stands
+        if self.eof > len(b):
+            raise CheckpointFormatError(f"{path}: truncated (end-of-file address {self.eof}, file has {len(b)} bytes)")
 
     def _span(self, addr, size, what):
         """Absolute offset of the file address `addr`, checked to hold `size` bytes."""

@@ -221,11 +221,15 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
                 from .._lib import MKWS_ERR_EXCHANGE, MkwsError
                 raise MkwsError(MKWS_ERR_EXCHANGE, "an in-kernel exchange failed again while the stream was being repeated on the single-workgroup kernels")
             import warnings
-            warnings.warn("multilingual_kws_amd: an in-kernel exchange failed during a graph replay; repeating the stream on the single-workgroup kernels", RuntimeWarning)
+            warnings.warn("multilingual_kws_amd: an in-kernel exchange failed during a graph replay; repeating the stream on the single-workgroup kernels. "
+                          "This embedding handle and its serving replicas STAY on that plan for the rest of the process (the library retires a handle's "
+                          "exchange kernels for good once one exchange has failed: include/mkws.h, MKWS_ERR_EXCHANGE); create a new handle to get them back",
+                          RuntimeWarning)
             # EVERY serving-lane replica leaves the exchange kernels before the repeat, not only the handle whose error word was set: a
             # replica that fails during the repeat would return its NaN rows with nobody looking
             for e in [emb_model] + list(getattr(emb_model, "_replicas", [])):
-                e.get_option("exchange_error") and e.forward(specs[:1])        # (heals: the wrapper repeats the call that reports the error)
+                if e.get_option("exchange_error"):                              # heals: the wrapper repeats the call that reports the error.  A known
+                    e.forward(torch.zeros((1, 49, 40), dtype=torch.float32, device=emb_model.device))   # one-window batch, not the last chunk's (maybe empty) one
                 e.set_option("fuse_pair", 0)
                 e.set_option("fuse_cluster", 0)
             _BatchGraph.forget(emb_model)                                       # graphs captured on the old plan

@@ -116,11 +116,18 @@ def load_models_shared(model_paths, max_batch=1024):
             key = (str(base), cut)
         else:       # content, not location: every saved model carries its own copy of the base weights
             h = hashlib.sha256()
-            for root, _, files in sorted(os.walk(base)):
-                for f in sorted(files):
-                    h.update(f.encode())
-                    h.update(open(os.path.join(root, f), "rb").read())
-            key = (h.hexdigest(), cut)
+            if os.path.isdir(base):                 # SavedModel directory / blob directory
+                kind = "dir"
+                for root, _, files in sorted(os.walk(base)):
+                    for f in sorted(files):
+                        h.update(os.path.relpath(os.path.join(root, f), base).encode())
+                        h.update(open(os.path.join(root, f), "rb").read())
+            elif os.path.isfile(base):              # a Keras .h5 / .npy blob named by model.json (models saved without a blob of their own)
+                kind = "file"
+                h.update(open(base, "rb").read())
+            else:
+                raise FileNotFoundError(f"{path}: base model '{base}' (model.json: base_model_path) does not exist")
+            key = (kind, h.hexdigest(), cut)
         if key not in shared:
             shared[key] = load_base_model(base, max_batch, cut)
         emb, blob = shared[key]

@@ -125,15 +125,12 @@ class EmbeddingTrainer:
     def _on_side(self, fn):
         torch = self.torch
         if self._side is None:
-            # the side stream only has to be done before the optimizer: it gets the LOWEST priority the device offers, so that its launches (the
-            # weight-gradient GEMMs put ~1 000 workgroups on the chip each) fill the gaps of the input-gradient chain instead of delaying it
-            # (MKWS_TRAIN_SIDE_PRIORITY overrides; values outside the device's range are clamped by the runtime)
+            # the side stream only has to be done before the optimizer.  It runs at the DEFAULT priority, the same as the caller's stream: torch
+            # offers no priority below the default (`priority_range()` is (0, -1) on ROCm too and positive values are clamped to 0), so nothing
+            # is deprioritised here -- the two streams share the chip as the hardware queues arbitrate (profiles/r05_notes.md section 4).
+            # MKWS_TRAIN_SIDE_PRIORITY = -1 raises the SIDE stream instead (an A/B knob; it lost).
             prio = os.environ.get("MKWS_TRAIN_SIDE_PRIORITY")
-            try:
-                lowest = torch.cuda.Stream.priority_range()[0]
-            except Exception:
-                lowest = 0
-            self._side = torch.cuda.Stream(device=self.device, priority=int(prio) if prio is not None else max(lowest, 0))
+            self._side = torch.cuda.Stream(device=self.device, priority=min(int(prio), 0) if prio is not None else 0)
             self._scratch_side = torch.empty(16 << 20, dtype=torch.float32, device=self.device)
             _lib.check(self.L.mkws_train_ctx_create(self._p(self._scratch_side), self._scratch_side.numel(), ctypes.byref(self._ctx_side)))
             self._side_ptr = ctypes.c_void_p(self._side.cuda_stream)

@@ -1,5 +1,5 @@
 #!/opt/conda/bin/python3.9
-"""Writes tests/golden/keras_h5/{weights.h5, model.h5, expected.npz}: HDF5 files in the layout Keras 2.7 gives an `.h5` checkpoint
+"""Writes tests/golden/keras_h5/{weights.h5, model.h5, userblock.h5, expected.npz}: HDF5 files in the layout Keras 2.7 gives an `.h5` checkpoint
 (keras/saving/hdf5_format.py: save_weights_to_hdf5_group / save_model_to_hdf5), written by h5py -- a THIRD-PARTY writer (HDF5 1.10
 library) -- so that multilingual_kws_amd/checkpoint_import.py's pure-Python HDF5 reader is checked against files its author's code
 did not produce.  Run with an interpreter that has h5py (this image: /opt/conda/bin/python3.9, h5py 3.3.0); the fixture is data.
@@ -104,6 +104,15 @@ def main():
     named["dense_2/scalar"] = np.float32(2.5); order.append("dense_2/scalar")
     named["dense_2/big_endian"] = rng.standard_normal((4, 3)).astype(">f4"); order.append("dense_2/big_endian")
     layers = layers_from_named(named, order)
+    # the same weights file behind a 512-byte USER BLOCK (superblock at 512, base address 512; libhdf5 stores the end-of-file
+    # address as an ABSOLUTE offset, object addresses relative to the base): written by h5py, not patched together
+    with h5py.File(os.path.join(OUT, "userblock.h5"), "w", userblock_size=512, libver="earliest") as f:
+        save_weights(f, layers)
+    with open(os.path.join(OUT, "userblock.h5"), "r+b") as fh:
+        fh.write(b"#!user block: 512 bytes the HDF5 library never reads\n")
+    if "--userblock-only" in sys.argv:
+        print("wrote", os.path.join(OUT, "userblock.h5"), os.path.getsize(os.path.join(OUT, "userblock.h5")))
+        return
     with h5py.File(os.path.join(OUT, "weights.h5"), "w") as f:                     # model.save_weights("x.h5")
         save_weights(f, layers)
     with h5py.File(os.path.join(OUT, "model.h5"), "w") as f:                       # model.save("x.h5")

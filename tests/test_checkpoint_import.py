@@ -247,20 +247,25 @@ def test_h5_errors(tmp_path, golden_dir):
 
 
 def test_h5_corruption_fails_as_a_format_error(tmp_path, golden_dir):
-    """Truncation behind a user block (addresses are relative to the base address: a 512-byte user block in front of a file cut by 100
-    bytes passed the old check `eof > len + base`), and object / continuation / data addresses pointing outside the file: always
-    CheckpointFormatError, never struct.error / IndexError."""
+    """A user block in front of the superblock (object addresses are relative to the base address, the end-of-file address is
+    ABSOLUTE: `userblock.h5` was written by h5py with userblock_size=512, it is not patched together), truncation of such a file,
+    and object / continuation / data addresses pointing outside the file: always CheckpointFormatError, never struct.error / IndexError."""
     import struct
     raw = open(os.path.join(golden_dir, "keras_h5", "weights.h5"), "rb").read()
     assert raw[:8] == ci.HDF5_SIGNATURE and raw[8] == 0
-    blocked = bytearray(b"\x00" * 512 + raw)
-    struct.pack_into("<Q", blocked, 512 + 24, 512)                  # base address = the user block's size
-    ok = tmp_path / "userblock.h5"
-    ok.write_bytes(bytes(blocked))
-    plain, moved = ci.H5File(os.path.join(golden_dir, "keras_h5", "weights.h5")), ci.H5File(str(ok))
-    assert moved.base_addr == 512 and list(moved.members(moved.root)) == list(plain.members(plain.root))
+    ub_path = os.path.join(golden_dir, "keras_h5", "userblock.h5")
+    blocked = open(ub_path, "rb").read()
+    assert blocked[:8] != ci.HDF5_SIGNATURE and blocked[512:520] == ci.HDF5_SIGNATURE
+    plain, moved = ci.H5File(os.path.join(golden_dir, "keras_h5", "weights.h5")), ci.H5File(ub_path)
+    assert moved.base_addr == 512 and moved.eof == len(blocked)              # what libhdf5 wrote: eof is absolute
+    assert list(moved.members(moved.root)) == list(plain.members(plain.root))
+    exp = np.load(os.path.join(golden_dir, "keras_h5", "expected.npz"))
+    got = ci.load_h5(ub_path)["named"]
+    assert len(got) == len(exp.files)
+    for k in exp.files:
+        assert np.array_equal(got[k.replace("|", "/")], exp[k]), k
     cut = tmp_path / "userblock_cut.h5"
-    cut.write_bytes(bytes(blocked[:-100]))
+    cut.write_bytes(blocked[:-100])
     with pytest.raises(ci.CheckpointFormatError, match="truncated"):
         ci.H5File(str(cut))
     # addresses outside the file

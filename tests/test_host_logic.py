@@ -311,3 +311,38 @@ def test_batch_groups_make_the_draws_of_the_step_by_step_stream(tmp_path):
     assert transfer_learning.FORWARD_CLIPS == 3072 and transfer_learning.OVERLAP_FROM_GROUP == 4
     assert transfer_learning.steps_per_forward(512) == 6 and transfer_learning.steps_per_forward(64) == 48
     assert transfer_learning.steps_per_forward(2048) == 1 and transfer_learning.steps_per_forward(4096) == 1 and transfer_learning.steps_per_forward(512, 1024) == 2
+
+
+def test_shared_embedding_key_is_the_base_weights_content_for_files_too(tmp_path, monkeypatch):
+    """load_models_shared keys the shared handle on the CONTENT of the base weights: directories are walked, a single file (a
+    Keras .h5 that model.json names by absolute path) is hashed itself -- two models on different .h5 files must not share an
+    embedding -- and a missing base raises instead of hashing nothing."""
+    import json
+    loads = []
+
+    class FakeEmb(str):
+        device = "cpu"
+    monkeypatch.setattr(transfer_learning, "load_base_model", lambda base, mb, cut: (loads.append(base) or (FakeEmb(f"emb{len(loads)}"), None)))
+    monkeypatch.setattr(transfer_learning, "Head", lambda *a, **k: ("head", a[:3]))
+    monkeypatch.setattr(transfer_learning, "TransferLearnedModel", lambda emb, head, blob, base: emb)
+    bases = []
+    for i, payload in enumerate([b"weights A", b"weights B", b"weights A"]):
+        b = tmp_path / f"base{i}.h5"
+        b.write_bytes(payload)
+        bases.append(str(b))
+    d = tmp_path / "dirbase"
+    (d / "variables").mkdir(parents=True)
+    (d / "variables" / "variables.index").write_bytes(b"weights A")
+    paths = []
+    for i, base in enumerate(bases + [str(d), str(tmp_path / "missing.h5")]):
+        m = tmp_path / f"model{i}"
+        m.mkdir()
+        json.dump({"base_model_path": base, "base_model_output": "dense_2"}, open(m / "model.json", "w"))
+        np.savez(m / "head.npz", dims=np.array([1024, 18, 3]), params=np.zeros(18507, np.float32))
+        paths.append(str(m))
+    models = transfer_learning.load_models_shared(paths[:4])
+    assert models[0] == models[2] and models[0] != models[1]          # same bytes share, other bytes do not
+    assert models[3] not in (models[0], models[1])                    # a directory with the same bytes inside is still another kind of base
+    assert len(loads) == 3
+    with pytest.raises(FileNotFoundError, match="does not exist"):
+        transfer_learning.load_models_shared(paths[4:])
