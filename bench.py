@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--ft-group", type=int, default=None, help="finetune: optimizer steps per forward pass of the frozen embedding "
                     "(default: transfer_learn's own rule, 1024 // batch; 1 = a forward pass per step as in rounds 1-4)")
     ap.add_argument("--ft-overlap", type=int, default=-1, help="finetune: optimizer steps on a second stream under the next group's kernels: 1 / 0, -1 = transfer_learn's own rule (on from 4 steps per forward)")
+    ap.add_argument("--lanes", type=int, default=None, help="embed: independent batches in flight, each on its own HIP stream with its own frontend / embedding "
+                    "handles (default 2: batch k's launches fill the tails of batch k-1's; 1 = one stream, the figure of rounds 1-5, reported beside it as `single_stream`)")
+    ap.add_argument("--sustain-s", type=float, default=2.0, help="embed: after the K timed steps, the same step for at least this long; its mean is reported as `sustained` (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="embed at N = 1: do not append short runs of the other three BASELINE configs (`secondary`)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B execution switch passed to mkws_embed_set_option (e.g. fuse_block=1); default = shipped plan")
     return ap.parse_args()
@@ -392,9 +396,29 @@ def main():
         workload = ("configs[2]: batch=1024/GPU synthetic 1s@16kHz clips -> micro-frontend (int16 fixed-point, fp32 I/O) -> "
                     "EfficientNet-B0 embedding forward (frozen, fp32 MFMA pointwise conv) -> [1024,1024]")
 
+        # `lanes` independent batches in flight: lane i has its own stream, frontend handle, embedding handle (workspace), spectrogram and
+        # embedding buffers; consecutive steps go to consecutive lanes.  Every step is still one full pass over one 1024-clip batch; what
+        # overlaps is the tail of one batch's launches (13 dependent kernels of 256-3072 workgroups each) with the head of the next one's.
+        nl = max(1, args.lanes if args.lanes is not None else 1)
+        lanes_ = [dict(stream=torch.cuda.Stream(device=dev), fe=fe if i == 0 else Frontend(max_samples=16000),
+                       em=em if i == 0 else EmbeddingModel(blob, max_batch=FB, device=dev),
+                       spec=spec if i == 0 else torch.empty_like(spec), emb=emb if i == 0 else torch.empty_like(emb)) for i in range(nl)]
+        for ln in lanes_[1:]:
+            for kv in args.opt:
+                name, _, val = kv.partition("=")
+                ln["em"].set_option(name, int(val))
+        torch.cuda.synchronize()
+        turn = [0]
+        extra_out["lanes"] = nl
+
+        def step_on(ln):
+            with torch.cuda.stream(ln["stream"]):
+                ln["fe"].forward(audio, out=ln["spec"])
+                ln["em"].forward(ln["spec"], out=ln["emb"])
+
         def step():
-            fe.forward(audio, out=spec)
-            em.forward(spec, out=emb)
+            step_on(lanes_[turn[0] % nl])
+            turn[0] += 1
     elif cfg == "frontend":
         metric = "clips/sec micro-frontend only, batch 1024, 1s@16kHz"
         workload = "configs[1]: batch=1024/GPU synthetic 1s@16kHz fp32 clips -> micro-frontend -> [1024,49,40] fp32 (71 840 algorithmic bytes/clip)"
@@ -482,6 +506,36 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * units_per_step * args.steps / elapsed
+    if cfg == "embed":
+        def timed(fn, min_s, min_steps):
+            """>= min_s seconds and >= min_steps steps of fn, fenced on both sides, every rank the same count (the count is agreed on first)."""
+            n = min_steps
+            if min_s > 0:
+                fence(); t1 = time.perf_counter()
+                for _ in range(min_steps):
+                    fn()
+                fence()
+                per = (time.perf_counter() - t1) / min_steps
+                n = max(min_steps, int(min_s / per) + 1)
+                if world > 1:
+                    tn = torch.tensor([n], dtype=torch.int64, device=dev)
+                    dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                    n = int(tn.item())
+            fence(); t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            fence()
+            el = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return {"value": round(world * units_per_step * n / el, 1), "ms_per_step": round(el / n * 1e3, 4), "steps": n, "seconds": round(el, 3)}
+        if args.sustain_s > 0:
+            # the driver's K steps last ~20 ms: too short for a power / clock sampler to see.  The same step for >= sustain_s seconds.
+            extra_out["sustained"] = timed(step, args.sustain_s, 50)
+        if nl > 1:
+            extra_out["single_stream"] = timed(lambda: step_on(lanes_[0]), 0.0, max(50, args.steps))
 
     result = None
     if rank == 0:
@@ -543,6 +597,26 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and world == 1 and cfg == "embed" and not args.no_secondary:
+        # The other three BASELINE configs as SHORT runs of this same file (`--config X`: same code path as a full run of that config), so that
+        # the one line the driver records carries all four.  Each is its own process: its own handles, its own clock warm-up, no CPU baseline.
+        result["secondary"] = {}
+        for name, extra in (("frontend", ["--steps", "400", "--warmup", "40"]), ("finetune", ["--steps", "240", "--warmup", "48"]),
+                            ("stream", ["--steps", "30", "--warmup", "4"])):
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--no-cpu-baseline", "--no-secondary"] + extra
+            try:
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ))
+                d = json.loads(out.stdout.strip().splitlines()[-1])
+                keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup") if k in d}
+                keep["whole_step_frac"] = d["roofline"].get("whole_step_frac")
+                keep["dominant"] = {k: d["roofline"].get(k) for k in ("kernel", "bound", "frac", "avg_launch_ms")}
+                for k in ("latency_ms_batch1", "latency_ms_batch1_eager", "serving_lanes", "steps_per_forward", "windows_per_stream"):
+                    if k in d:
+                        keep[k] = d[k]
+                keep["workload"] = d["config"]["workload"]
+                result["secondary"][name] = keep
+            except Exception as exc:
+                result["secondary"][name] = {"value": None, "error": repr(exc)[:300]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             del em, fe

@@ -193,6 +193,10 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "fuse_mid" (default 1): blocks with big images run expand -> depthwise -> SE ->
  *                 project as ONE kernel per block (depthwise output of all channels resident in LDS): 1 = blocks 2b, 3a and 4a
  *                 (where it measured faster than the front / back kernel pair), 2 = all of 2a..4a, 3 = 3a and 4a only, 0 = never.
+ *   "fuse_rows" (default 0; 1 =): the stride-1 big-image blocks 2b and 3b run as ONE kernel per block in which a wave owns a 16-row tile
+ *                 of a clip from the expand to the projection and the depthwise output stays in its registers (mbconv_rows_kernel,
+ *                 csrc/mkws_embed_rows.hip: 43 / 57 KB of LDS per workgroup, so two or three workgroups share a CU); 0 = "fuse_mid" /
+ *                 the front + back pair decide for those blocks as before round 6.
  *   "fuse_gap" (default 1): global average pool fused into the top conv epilogue (its [B*4,1280] output is never stored).
  *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (persistent workgroups, one per CU, each walking
  *                 clips blockIdx, blockIdx + grid, ... with the next clip's spectrogram prefetched; both 25x20x32 activations stay

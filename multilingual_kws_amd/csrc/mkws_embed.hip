@@ -38,39 +38,11 @@
 // fp32 multiply-adds of the convolution / epilogue code may fuse (v_pk_fma_f32): one rounding instead of two,
 // like the MFMA accumulation itself; the build's default (-ffp-contract=off) stays in force for the other files.
 #pragma clang fp contract(fast)
+#include "mkws_embed_dev.h"
+#include "mkws_embed_rows.h"
 
 namespace mkws {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SELU = 3, ACT_SIGMOID = 4 };
-
-// sigmoid on the hardware transcendentals: v_exp_f32 + v_rcp_f32 (1 ulp each) -- 4 instructions, vs ~20 for
-// expf + IEEE division; swish sits in every epilogue and was the largest VALU cost of the fused kernels.
-__device__ __forceinline__ float sigmoidf_(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
-// Four at once, written on the vector so that the multiply / add around the two transcendentals become packed instructions
-// (v_pk_mul_f32 / v_pk_add_f32: half the VALU issue of the scalar form; MFMA and VALU work serialize on a SIMD,
-// tools/microbench/mfma_valu_overlap.hip, so every VALU instruction saved in an epilogue is MFMA time gained).  Same operations
-// in the same order as sigmoidf_ / swishf_: bit-identical.
-__device__ __forceinline__ f32x4 sigmoid4_(f32x4 v) {
-  f32x4 t = v * -1.4426950408889634f;
-  t.x = __builtin_amdgcn_exp2f(t.x); t.y = __builtin_amdgcn_exp2f(t.y); t.z = __builtin_amdgcn_exp2f(t.z); t.w = __builtin_amdgcn_exp2f(t.w);
-  t = t + 1.0f;
-  t.x = __builtin_amdgcn_rcpf(t.x); t.y = __builtin_amdgcn_rcpf(t.y); t.z = __builtin_amdgcn_rcpf(t.z); t.w = __builtin_amdgcn_rcpf(t.w);
-  return t;
-}
-__device__ __forceinline__ f32x4 swish4_(f32x4 v) { return v * sigmoid4_(v); }
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ f32x2 swish2_(f32x2 v) {          // the same operations per element as swish4_ / swishf_
-  f32x2 t = v * -1.4426950408889634f;
-  t.x = __builtin_amdgcn_exp2f(t.x); t.y = __builtin_amdgcn_exp2f(t.y);
-  t = t + 1.0f;
-  t.x = __builtin_amdgcn_rcpf(t.x); t.y = __builtin_amdgcn_rcpf(t.y);
-  return v * t;
-}
 // value the optimizer cannot see through (stops loop-invariant hoisting of cheap index arithmetic into spilled registers)
 __device__ __forceinline__ int opaque_(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -682,6 +654,7 @@ struct FrontArgs {
   const float* Wd; const float* scD; const float* shD;
   float* Y; float* sums;
   int B, H, W, Ho, Wo, pt, pl, Cexp, G;
+  int ncb;                         // big-image mode: channel blocks a workgroup walks (grid.y = blocks / ncb)
 #ifdef MKWS_FRONT_TIMING
   unsigned long long* dbg_t;
 #endif
@@ -708,314 +681,321 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
   const int b0 = blockIdx.x * a.G;
   const int gvalid = (a.B - b0 < a.G) ? (a.B - b0) : a.G;
   const int rows = gvalid * HW;
-  const int ch0 = blockIdx.y * CC;             // first expanded channel of this block
   MKWS_WG_BEGIN();
   if (tid < LDE / 4) *reinterpret_cast<f32x4*>(s_front + (size_t)a.G * HW * LDE + 4 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifdef MKWS_FRONT_TIMING
   unsigned long long* dbgp = a.dbg_t + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
   if (tid == 0) dbgp[0] = wall_clock64();
 #endif
-  // nt_valid: n-tiles of this block that exist (the last chunk of a layer may be partial)
-  const int nt_valid = ((a.Cexp - ch0) / 16 < NT) ? (a.Cexp - ch0) / 16 : NT;
-  // depthwise BN constants of this thread's channel quad (item % Q == tid % Q for every item of the thread):
-  // requested now, used after the barrier
-  f32x4 scd_pre = {0.f, 0.f, 0.f, 0.f}, shd_pre = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (PIXEL_LANES) {
-    const int tq0 = tid % Q;
-    const int cq0 = (tq0 < nt_valid * 4) ? ch0 + 4 * tq0 : ch0;
-    scd_pre = *reinterpret_cast<const f32x4*>(a.scD + cq0);
-    shd_pre = *reinterpret_cast<const f32x4*>(a.shD + cq0);
-  }
-  if constexpr (PIXEL_LANES) {                 // depthwise taps of this channel chunk -> LDS (consumed after phase 1)
-    for (int i = tid; i < KS * KS * Q; i += NTHREADS) {
-      const int t = i / Q, q4 = (i - t * Q) * 4;
-      const int cq = (q4 < nt_valid * 16) ? ch0 + q4 : ch0;
-      *reinterpret_cast<f32x4*>(s_wd + t * CC + q4) = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)t * a.Cexp + cq);
-    }
-  }
-  // ---- phase 1: expand into LDS ----
-  // Operand fragments go global -> registers through the vector L1 (64 B/clk/CU), which is what bounds
-  // small MFMA tiles; so weights are fetched as rarely as possible:
-  //   PIXEL_LANES (few K chunks, many row tiles): all weight fragments of the block live in registers;
-  //   tiny images (many K chunks, CC = 128): each weight fragment feeds MT = 2 row tiles.
-  {
-    const float* Xb = a.X + (size_t)b0 * HW * a.Cin;
-    const float* wbase = a.WpE + ((size_t)(ch0 / 16) * 4 + g) * 64 + c * 4;     // + (j*NTtotE + nt)*256
-    const size_t wchunk = (size_t)a.NTtotE * 256;
-    const int ntiles = (rows + 15) / 16;
+  // Channel blocks this workgroup walks one after the other (a.ncb; 1 = one block per blockIdx.y, the shape until round 5).  Block 2a's three
+  // 32-channel blocks used to be three workgroups per clip, each pulling the clip's 32 KB input from HBM (94 MB fetched per launch for 33 MB
+  // of input, profiles/pmc_traffic.json); walked by ONE workgroup the second and third pass find it in L2.
+  const int ncb = PIXEL_LANES ? a.ncb : 1;
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int ch0 = (blockIdx.y * ncb + cb) * CC;   // first expanded channel of this pass
+    // nt_valid: n-tiles of this block that exist (the last chunk of a layer may be partial)
+    const int nt_valid = ((a.Cexp - ch0) / 16 < NT) ? (a.Cexp - ch0) / 16 : NT;
+    // depthwise BN constants of this thread's channel quad (item % Q == tid % Q for every item of the thread):
+    // requested now, used after the barrier
+    f32x4 scd_pre = {0.f, 0.f, 0.f, 0.f}, shd_pre = {0.f, 0.f, 0.f, 0.f};
     if constexpr (PIXEL_LANES) {
-      // All loads of the tile loop are unconditional (clamped row / k offsets; padded k positions meet zero
-      // weights), the BN constants sit in registers, and the X ring is prologue / steady state / tail, so
-      // hipcc emits counted vmcnt waits instead of draining the ring at every tile.
-      constexpr int MAXKC = KCT;             // exact K chunk count of the layer (Cin = 16, 24, 40 -> 1, 2, 3)
-      f32x4 wreg[MAXKC][NT], scr[NT], shr[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int ntc = nt < nt_valid ? nt : nt_valid - 1;
-        scr[nt] = *reinterpret_cast<const f32x4*>(a.scE + ch0 + ntc * 16 + 4 * g);
-        shr[nt] = *reinterpret_cast<const f32x4*>(a.shE + ch0 + ntc * 16 + 4 * g);
-#pragma unroll
-        for (int j = 0; j < MAXKC; ++j) wreg[j][nt] = *reinterpret_cast<const f32x4*>(wbase + (size_t)j * wchunk + ntc * 256);
+      const int tq0 = tid % Q;
+      const int cq0 = (tq0 < nt_valid * 4) ? ch0 + 4 * tq0 : ch0;
+      scd_pre = *reinterpret_cast<const f32x4*>(a.scD + cq0);
+      shd_pre = *reinterpret_cast<const f32x4*>(a.shD + cq0);
+    }
+    if constexpr (PIXEL_LANES) {                 // depthwise taps of this channel chunk -> LDS (consumed after phase 1)
+      for (int i = tid; i < KS * KS * Q; i += NTHREADS) {
+        const int t = i / Q, q4 = (i - t * Q) * 4;
+        const int cq = (q4 < nt_valid * 16) ? ch0 + q4 : ch0;
+        *reinterpret_cast<f32x4*>(s_wd + t * CC + q4) = *reinterpret_cast<const f32x4*>(a.Wd + (size_t)t * a.Cexp + cq);
       }
-      int koff[MAXKC];
+    }
+    // ---- phase 1: expand into LDS ----
+    // Operand fragments go global -> registers through the vector L1 (64 B/clk/CU), which is what bounds
+    // small MFMA tiles; so weights are fetched as rarely as possible:
+    //   PIXEL_LANES (few K chunks, many row tiles): all weight fragments of the block live in registers;
+    //   tiny images (many K chunks, CC = 128): each weight fragment feeds MT = 2 row tiles.
+    {
+      const float* Xb = a.X + (size_t)b0 * HW * a.Cin;
+      const float* wbase = a.WpE + ((size_t)(ch0 / 16) * 4 + g) * 64 + c * 4;     // + (j*NTtotE + nt)*256
+      const size_t wchunk = (size_t)a.NTtotE * 256;
+      const int ntiles = (rows + 15) / 16;
+      if constexpr (PIXEL_LANES) {
+        // All loads of the tile loop are unconditional (clamped row / k offsets; padded k positions meet zero
+        // weights), the BN constants sit in registers, and the X ring is prologue / steady state / tail, so
+        // hipcc emits counted vmcnt waits instead of draining the ring at every tile.
+        constexpr int MAXKC = KCT;             // exact K chunk count of the layer (Cin = 16, 24, 40 -> 1, 2, 3)
+        f32x4 wreg[MAXKC][NT], scr[NT], shr[NT];
 #pragma unroll
-      for (int j = 0; j < MAXKC; ++j) koff[j] = (16 * j + 4 * g < a.Cin - 4) ? 16 * j + 4 * g : a.Cin - 4;
-      constexpr int NW = NTHREADS / 64;
-      const int nmy = (ntiles - wave + NW - 1) / NW;          // row tiles of this wave: wave, wave + NW, ...
-      constexpr int D = 4;
-      f32x4 xq[D][MAXKC];
-      auto loadx = [&](int i, f32x4 (&xv)[MAXKC]) {
-        int row = (wave + NW * i) * 16 + c;
-        row = row < rows ? row : rows - 1;
-        const float* xp = Xb + (size_t)row * a.Cin;
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ntc = nt < nt_valid ? nt : nt_valid - 1;
+          scr[nt] = *reinterpret_cast<const f32x4*>(a.scE + ch0 + ntc * 16 + 4 * g);
+          shr[nt] = *reinterpret_cast<const f32x4*>(a.shE + ch0 + ntc * 16 + 4 * g);
 #pragma unroll
-        for (int j = 0; j < MAXKC; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xp + koff[j]);
-      };
-      auto tile = [&](int i, const f32x4 (&xv)[MAXKC]) {
-        f32x4 acc[NT];
+          for (int j = 0; j < MAXKC; ++j) wreg[j][nt] = *reinterpret_cast<const f32x4*>(wbase + (size_t)j * wchunk + ntc * 256);
+        }
+        int koff[MAXKC];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MAXKC; ++j) koff[j] = (16 * j + 4 * g < a.Cin - 4) ? 16 * j + 4 * g : a.Cin - 4;
+        constexpr int NW = NTHREADS / 64;
+        const int nmy = (ntiles - wave + NW - 1) / NW;          // row tiles of this wave: wave, wave + NW, ...
+        constexpr int D = 4;
+        f32x4 xq[D][MAXKC];
+        auto loadx = [&](int i, f32x4 (&xv)[MAXKC]) {
+          int row = (wave + NW * i) * 16 + c;
+          row = row < rows ? row : rows - 1;
+          const float* xp = Xb + (size_t)row * a.Cin;
 #pragma unroll
-        for (int j = 0; j < MAXKC; ++j)
+          for (int j = 0; j < MAXKC; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xp + koff[j]);
+        };
+        auto tile = [&](int i, const f32x4 (&xv)[MAXKC]) {
+          f32x4 acc[NT];
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][nt][s], xv[j][s], acc[nt], 0, 0, 0);
-        const int row = (wave + NW * i) * 16 + c;
-        if (row < rows) {
+          for (int j = 0; j < MAXKC; ++j)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            if (nt < nt_valid) {
-              f32x4 y = acc[nt] * scr[nt] + shr[nt];
-              y = swish4_(y);
-              *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + nt * 16 + 4 * g) = y;
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][nt][s], xv[j][s], acc[nt], 0, 0, 0);
+          const int row = (wave + NW * i) * 16 + c;
+          if (row < rows) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              if (nt < nt_valid) {
+                f32x4 y = acc[nt] * scr[nt] + shr[nt];
+                y = swish4_(y);
+                *reinterpret_cast<f32x4*>(s_E + (size_t)row * LDE + nt * 16 + 4 * g) = y;
+              }
             }
           }
-        }
-      };
-#pragma unroll
-      for (int d = 0; d < D; ++d) loadx(d, xq[d]);
-      int i = 0;
-      for (; i + D <= nmy; i += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          tile(i + d, xq[d]);
-          loadx(i + d + D, xq[d]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int d = 0; d < D; ++d)
-        if (i + d < nmy) tile(i + d, xq[d]);
-    } else {
-      // 8 waves = 4 row-pair lanes x 2 column halves: wave tile = 2 row tiles x NT/2 column tiles, so one
-      // K chunk costs 2 X + NT/2 weight fragments for 2*(NT/2)*4 MFMAs.  Same load discipline as above.
-      constexpr int NTW = (NT >= 2) ? NT / 2 : 1;
-      const int nhalf = wave >> 2, plane = wave & 3;
-      const int npairs = (ntiles + 1) / 2;
-      f32x4 scr[NTW], shr[NTW];
-      const float* wpq[NTW];
-#pragma unroll
-      for (int q = 0; q < NTW; ++q) {
-        const int nt = nhalf * NTW + q;
-        const int ntc = nt < nt_valid ? nt : nt_valid - 1;
-        scr[q] = *reinterpret_cast<const f32x4*>(a.scE + ch0 + ntc * 16 + 4 * g);
-        shr[q] = *reinterpret_cast<const f32x4*>(a.shE + ch0 + ntc * 16 + 4 * g);
-        wpq[q] = wbase + (size_t)ntc * 256;
-      }
-      for (int pr = plane; pr < npairs; pr += 4) {
-        const int row0 = pr * 32 + c, row1 = row0 + 16;
-        const float* xp0 = Xb + (size_t)(row0 < rows ? row0 : rows - 1) * a.Cin;
-        const float* xp1 = Xb + (size_t)(row1 < rows ? row1 : rows - 1) * a.Cin;
-        f32x4 acc0[NTW], acc1[NTW];
-#pragma unroll
-        for (int q = 0; q < NTW; ++q) { acc0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        constexpr int D = 3;
-        f32x4 x0[D], x1[D], wq[D][NTW];
-        auto load = [&](int j, f32x4& v0, f32x4& v1, f32x4 (&wv)[NTW]) {
-          j = j < a.KC ? j : a.KC - 1;                      // past the end: harmless reload, never consumed
-          const int ko = (16 * j + 4 * g < a.Cin - 4) ? 16 * j + 4 * g : a.Cin - 4;
-          v0 = *reinterpret_cast<const f32x4*>(xp0 + ko);
-          v1 = *reinterpret_cast<const f32x4*>(xp1 + ko);
-#pragma unroll
-          for (int q = 0; q < NTW; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wpq[q] + (size_t)j * wchunk);
-        };
-        auto compute = [&](const f32x4& v0, const f32x4& v1, const f32x4 (&wv)[NTW]) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int q = 0; q < NTW; ++q) {
-              acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], v0[s], acc0[q], 0, 0, 0);
-              acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], v1[s], acc1[q], 0, 0, 0);
-            }
         };
 #pragma unroll
-        for (int d = 0; d < D; ++d) load(d, x0[d], x1[d], wq[d]);
-        int j = 0;
-        for (; j + D <= a.KC; j += D) {
+        for (int d = 0; d < D; ++d) loadx(d, xq[d]);
+        int i = 0;
+        for (; i + D <= nmy; i += D) {
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            compute(x0[d], x1[d], wq[d]);
-            load(j + d + D, x0[d], x1[d], wq[d]);
-            __builtin_amdgcn_sched_barrier(0);     // keep the reload right behind its slot's MFMAs
+            tile(i + d, xq[d]);
+            loadx(i + d + D, xq[d]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
 #pragma unroll
         for (int d = 0; d < D; ++d)
-          if (j + d < a.KC) compute(x0[d], x1[d], wq[d]);
+          if (i + d < nmy) tile(i + d, xq[d]);
+      } else {
+        // 8 waves = 4 row-pair lanes x 2 column halves: wave tile = 2 row tiles x NT/2 column tiles, so one
+        // K chunk costs 2 X + NT/2 weight fragments for 2*(NT/2)*4 MFMAs.  Same load discipline as above.
+        constexpr int NTW = (NT >= 2) ? NT / 2 : 1;
+        const int nhalf = wave >> 2, plane = wave & 3;
+        const int npairs = (ntiles + 1) / 2;
+        f32x4 scr[NTW], shr[NTW];
+        const float* wpq[NTW];
 #pragma unroll
         for (int q = 0; q < NTW; ++q) {
           const int nt = nhalf * NTW + q;
-          if (nt < nt_valid) {
-            if (row0 < rows) {
-              f32x4 y = acc0[q] * scr[q] + shr[q];
-              y = swish4_(y);
-              *reinterpret_cast<f32x4*>(s_E + (size_t)row0 * LDE + nt * 16 + 4 * g) = y;
+          const int ntc = nt < nt_valid ? nt : nt_valid - 1;
+          scr[q] = *reinterpret_cast<const f32x4*>(a.scE + ch0 + ntc * 16 + 4 * g);
+          shr[q] = *reinterpret_cast<const f32x4*>(a.shE + ch0 + ntc * 16 + 4 * g);
+          wpq[q] = wbase + (size_t)ntc * 256;
+        }
+        for (int pr = plane; pr < npairs; pr += 4) {
+          const int row0 = pr * 32 + c, row1 = row0 + 16;
+          const float* xp0 = Xb + (size_t)(row0 < rows ? row0 : rows - 1) * a.Cin;
+          const float* xp1 = Xb + (size_t)(row1 < rows ? row1 : rows - 1) * a.Cin;
+          f32x4 acc0[NTW], acc1[NTW];
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) { acc0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+          constexpr int D = 3;
+          f32x4 x0[D], x1[D], wq[D][NTW];
+          auto load = [&](int j, f32x4& v0, f32x4& v1, f32x4 (&wv)[NTW]) {
+            j = j < a.KC ? j : a.KC - 1;                      // past the end: harmless reload, never consumed
+            const int ko = (16 * j + 4 * g < a.Cin - 4) ? 16 * j + 4 * g : a.Cin - 4;
+            v0 = *reinterpret_cast<const f32x4*>(xp0 + ko);
+            v1 = *reinterpret_cast<const f32x4*>(xp1 + ko);
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wpq[q] + (size_t)j * wchunk);
+          };
+          auto compute = [&](const f32x4& v0, const f32x4& v1, const f32x4 (&wv)[NTW]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int q = 0; q < NTW; ++q) {
+                acc0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], v0[s], acc0[q], 0, 0, 0);
+                acc1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], v1[s], acc1[q], 0, 0, 0);
+              }
+          };
+#pragma unroll
+          for (int d = 0; d < D; ++d) load(d, x0[d], x1[d], wq[d]);
+          int j = 0;
+          for (; j + D <= a.KC; j += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              compute(x0[d], x1[d], wq[d]);
+              load(j + d + D, x0[d], x1[d], wq[d]);
+              __builtin_amdgcn_sched_barrier(0);     // keep the reload right behind its slot's MFMAs
             }
-            if (row1 < rows) {
-              f32x4 y = acc1[q] * scr[q] + shr[q];
-              y = swish4_(y);
-              *reinterpret_cast<f32x4*>(s_E + (size_t)row1 * LDE + nt * 16 + 4 * g) = y;
+          }
+#pragma unroll
+          for (int d = 0; d < D; ++d)
+            if (j + d < a.KC) compute(x0[d], x1[d], wq[d]);
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) {
+            const int nt = nhalf * NTW + q;
+            if (nt < nt_valid) {
+              if (row0 < rows) {
+                f32x4 y = acc0[q] * scr[q] + shr[q];
+                y = swish4_(y);
+                *reinterpret_cast<f32x4*>(s_E + (size_t)row0 * LDE + nt * 16 + 4 * g) = y;
+              }
+              if (row1 < rows) {
+                f32x4 y = acc1[q] * scr[q] + shr[q];
+                y = swish4_(y);
+                *reinterpret_cast<f32x4*>(s_E + (size_t)row1 * LDE + nt * 16 + 4 * g) = y;
+              }
             }
           }
         }
       }
     }
-  }
 #ifdef MKWS_FRONT_TIMING
-  if (tid == 0) dbgp[1] = wall_clock64();
+    if (tid == 0) dbgp[1] = wall_clock64();
 #endif
-  __syncthreads();
+    __syncthreads();
 #ifdef MKWS_FRONT_TIMING
-  if (tid == 0) dbgp[2] = wall_clock64();
+    if (tid == 0) dbgp[2] = wall_clock64();
 #endif
-  // ---- phase 2: depthwise from LDS ----
-  if constexpr (PIXEL_LANES) {
-    // Row strips: item = (clip, output row, column segment, channel quad) computes SEG adjacent outputs of one
-    // row.  The image size is a template constant, so a strip reads each of its KS x ((SEG-1)*S + KS) inputs
-    // once (instead of KS*KS per output), column offsets are immediates, out-of-image taps read the LDS zero
-    // row (no branches: all ds_reads of a row are in flight together), and the taps come from LDS.
-    constexpr int HoT = (S == 1) ? HT : (HT + 1) / 2, WoT = (S == 1) ? WT : (WT + 1) / 2;
-    constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
-    constexpr int SEG = (WoT % 5 == 0) ? 5 : WoT;
-    constexpr int NSEG = WoT / SEG;
-    constexpr int NC = (SEG - 1) * S + KS;
-    static_assert(NSEG * SEG == WoT, "segments tile the output row");
-    const int zrow = a.G * HW;
-    const int nitems = gvalid * HoT * NSEG * Q;
-    for (int item = tid; item < nitems; item += NTHREADS) {
-      const int tq = item % Q;
-      int r = item / Q;
-      const int sg = r % NSEG; r /= NSEG;
-      const int oh = r % HoT, gi = r / HoT;
-      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
-      if (tq < nt_valid * 4) {
+    // ---- phase 2: depthwise from LDS ----
+    if constexpr (PIXEL_LANES) {
+      // Row strips: item = (clip, output row, column segment, channel quad) computes SEG adjacent outputs of one
+      // row.  The image size is a template constant, so a strip reads each of its KS x ((SEG-1)*S + KS) inputs
+      // once (instead of KS*KS per output), column offsets are immediates, out-of-image taps read the LDS zero
+      // row (no branches: all ds_reads of a row are in flight together), and the taps come from LDS.
+      constexpr int HoT = (S == 1) ? HT : (HT + 1) / 2, WoT = (S == 1) ? WT : (WT + 1) / 2;
+      constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+      constexpr int SEG = (WoT % 5 == 0) ? 5 : WoT;
+      constexpr int NSEG = WoT / SEG;
+      constexpr int NC = (SEG - 1) * S + KS;
+      static_assert(NSEG * SEG == WoT, "segments tile the output row");
+      const int zrow = a.G * HW;
+      const int nitems = gvalid * HoT * NSEG * Q;
+      for (int item = tid; item < nitems; item += NTHREADS) {
+        const int tq = item % Q;
+        int r = item / Q;
+        const int sg = r % NSEG; r /= NSEG;
+        const int oh = r % HoT, gi = r / HoT;
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+        if (tq < nt_valid * 4) {
+          const int cq = ch0 + 4 * tq;
+          const float* E0 = s_E + 4 * tq;
+          const int ih0 = oh * S - PT, iw0 = sg * SEG * S - PLF;
+          int coff[NC];
+#pragma unroll
+          for (int ci = 0; ci < NC; ++ci) coff[ci] = ((unsigned)(iw0 + ci) < (unsigned)WT) ? iw0 + ci : -1;
+          f32x4 acc[SEG];
+#pragma unroll
+          for (int o = 0; o < SEG; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < KS; ++i) {
+            const int ih = ih0 + i;
+            const bool rok = (unsigned)ih < (unsigned)HT;
+            const int rbase = gi * HW + ih * WT;
+            f32x4 v[NC], w[KS];
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci) {
+              const int row = (rok && coff[ci] >= 0) ? rbase + coff[ci] : zrow;
+              v[ci] = *reinterpret_cast<const f32x4*>(E0 + (size_t)row * LDE);
+            }
+#pragma unroll
+            for (int jx = 0; jx < KS; ++jx) w[jx] = *reinterpret_cast<const f32x4*>(s_wd + (i * KS + jx) * CC + 4 * tq);
+#pragma unroll
+            for (int o = 0; o < SEG; ++o)
+#pragma unroll
+              for (int jx = 0; jx < KS; ++jx) acc[o] += v[o * S + jx] * w[jx];
+          }
+          const f32x4 sc = scd_pre, sh = shd_pre;
+          float* yout = a.Y + ((size_t)(b0 + gi) * (HoT * WoT) + oh * WoT + sg * SEG) * a.Cexp + cq;
+#pragma unroll
+          for (int o = 0; o < SEG; ++o) {
+            f32x4 y = acc[o] * sc + sh;
+            y = swish4_(y);
+            *reinterpret_cast<f32x4*>(yout + (size_t)o * a.Cexp) = y;
+            ssum += y;
+          }
+        }
+        s_red[item] = ssum;
+      }
+      __syncthreads();
+      // channel sums per clip: the strips' partial sums are added in fixed (row, segment) order
+      if (tid < gvalid * Q) {
+        const int gi = tid / Q, tq = tid - gi * Q;
+        if (tq < nt_valid * 4) {
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          for (int k = 0; k < HoT * NSEG; ++k) t += s_red[(gi * HoT * NSEG + k) * Q + tq];
+          *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + ch0 + 4 * tq) = t;
+          *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = t;
+        }
+      }
+    } else {
+      // image size is a template constant here: the tap loops unroll completely and taps that fall outside
+      // the 4x3 / 2x2 image disappear at compile time (most of a 5x5 kernel does)
+      constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1);
+      // Keras padding as constants: "same" for stride 1, correct_pad for stride 2
+      constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
+      for (int task = tid; task < gvalid * Q; task += NTHREADS) {
+        const int tq = task % Q, gi = task / Q;
+        if (tq >= nt_valid * 4) continue;
         const int cq = ch0 + 4 * tq;
-        const float* E0 = s_E + 4 * tq;
-        const int ih0 = oh * S - PT, iw0 = sg * SEG * S - PLF;
-        int coff[NC];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
+        const float* E = s_E + (size_t)gi * (HT * WT) * LDE + 4 * tq;
+        const float* wd = a.Wd + cq;
+        float* yout = a.Y + (size_t)(b0 + gi) * (HoT * WoT) * a.Cexp + cq;
+        f32x4 ein[HT * WT];
 #pragma unroll
-        for (int ci = 0; ci < NC; ++ci) coff[ci] = ((unsigned)(iw0 + ci) < (unsigned)WT) ? iw0 + ci : -1;
-        f32x4 acc[SEG];
+        for (int pix = 0; pix < HT * WT; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(E + (size_t)pix * LDE);
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[HoT * WoT];
 #pragma unroll
-        for (int o = 0; o < SEG; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < HoT * WoT; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
-          const int ih = ih0 + i;
-          const bool rok = (unsigned)ih < (unsigned)HT;
-          const int rbase = gi * HW + ih * WT;
-          f32x4 v[NC], w[KS];
 #pragma unroll
-          for (int ci = 0; ci < NC; ++ci) {
-            const int row = (rok && coff[ci] >= 0) ? rbase + coff[ci] : zrow;
-            v[ci] = *reinterpret_cast<const f32x4*>(E0 + (size_t)row * LDE);
+          for (int jx = 0; jx < KS; ++jx) {
+            // is this tap used by any output pixel?
+            bool used = false;
+#pragma unroll
+            for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+              for (int ow = 0; ow < WoT; ++ow) {
+                const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+                used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
+              }
+            if (!used) continue;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wd + (size_t)(i * KS + jx) * a.Cexp);
+#pragma unroll
+            for (int oh = 0; oh < HoT; ++oh)
+#pragma unroll
+              for (int ow = 0; ow < WoT; ++ow) {
+                const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
+                if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv;
+              }
           }
-#pragma unroll
-          for (int jx = 0; jx < KS; ++jx) w[jx] = *reinterpret_cast<const f32x4*>(s_wd + (i * KS + jx) * CC + 4 * tq);
-#pragma unroll
-          for (int o = 0; o < SEG; ++o)
-#pragma unroll
-            for (int jx = 0; jx < KS; ++jx) acc[o] += v[o * S + jx] * w[jx];
         }
-        const f32x4 sc = scd_pre, sh = shd_pre;
-        float* yout = a.Y + ((size_t)(b0 + gi) * (HoT * WoT) + oh * WoT + sg * SEG) * a.Cexp + cq;
 #pragma unroll
-        for (int o = 0; o < SEG; ++o) {
+        for (int o = 0; o < HoT * WoT; ++o) {
           f32x4 y = acc[o] * sc + sh;
           y = swish4_(y);
           *reinterpret_cast<f32x4*>(yout + (size_t)o * a.Cexp) = y;
           ssum += y;
         }
-      }
-      s_red[item] = ssum;
-    }
-    __syncthreads();
-    // channel sums per clip: the strips' partial sums are added in fixed (row, segment) order
-    if (tid < gvalid * Q) {
-      const int gi = tid / Q, tq = tid - gi * Q;
-      if (tq < nt_valid * 4) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < HoT * NSEG; ++k) t += s_red[(gi * HoT * NSEG + k) * Q + tq];
-        *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + ch0 + 4 * tq) = t;
-        *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = t;
+        *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + cq) = ssum;
+        *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = ssum;
       }
     }
-  } else {
-    // image size is a template constant here: the tap loops unroll completely and taps that fall outside
-    // the 4x3 / 2x2 image disappear at compile time (most of a 5x5 kernel does)
-    constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1);
-    // Keras padding as constants: "same" for stride 1, correct_pad for stride 2
-    constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
-    for (int task = tid; task < gvalid * Q; task += NTHREADS) {
-      const int tq = task % Q, gi = task / Q;
-      if (tq >= nt_valid * 4) continue;
-      const int cq = ch0 + 4 * tq;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scD + cq);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shD + cq);
-      const float* E = s_E + (size_t)gi * (HT * WT) * LDE + 4 * tq;
-      const float* wd = a.Wd + cq;
-      float* yout = a.Y + (size_t)(b0 + gi) * (HoT * WoT) * a.Cexp + cq;
-      f32x4 ein[HT * WT];
-#pragma unroll
-      for (int pix = 0; pix < HT * WT; ++pix) ein[pix] = *reinterpret_cast<const f32x4*>(E + (size_t)pix * LDE);
-      f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
-      f32x4 acc[HoT * WoT];
-#pragma unroll
-      for (int o = 0; o < HoT * WoT; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < KS; ++i) {
-#pragma unroll
-        for (int jx = 0; jx < KS; ++jx) {
-          // is this tap used by any output pixel?
-          bool used = false;
-#pragma unroll
-          for (int oh = 0; oh < HoT; ++oh)
-#pragma unroll
-            for (int ow = 0; ow < WoT; ++ow) {
-              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
-              used |= (ih >= 0 && ih < HT && iw >= 0 && iw < WT);
-            }
-          if (!used) continue;
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(wd + (size_t)(i * KS + jx) * a.Cexp);
-#pragma unroll
-          for (int oh = 0; oh < HoT; ++oh)
-#pragma unroll
-            for (int ow = 0; ow < WoT; ++ow) {
-              const int ih = oh * S - PT + i, iw = ow * S - PLF + jx;
-              if (ih >= 0 && ih < HT && iw >= 0 && iw < WT) acc[oh * WoT + ow] += ein[ih * WT + iw] * wv;
-            }
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < HoT * WoT; ++o) {
-        f32x4 y = acc[o] * sc + sh;
-        y = swish4_(y);
-        *reinterpret_cast<f32x4*>(yout + (size_t)o * a.Cexp) = y;
-        ssum += y;
-      }
-      *reinterpret_cast<f32x4*>(a.sums + (size_t)(b0 + gi) * a.Cexp + cq) = ssum;
-      *reinterpret_cast<f32x4*>(s_sumc + (size_t)gi * CC + 4 * tq) = ssum;
-    }
+    if (cb + 1 < ncb) __syncthreads();             // the next pass overwrites s_E / s_wd / s_red
   }
 #ifdef MKWS_FRONT_TIMING
   __syncthreads();
@@ -1031,14 +1011,6 @@ __global__ __launch_bounds__(KCT > 0 ? 256 : 512) void mbconv_front_kernel(Front
 //         (buffer_load_dwordx4 v, voffset, rsrc, soffset offen): NO VALU instruction per load.  That matters because VALU and MFMA
 //         work of a SIMD serialize (tools/microbench/mfma_valu_overlap.hip).  idx must be wave-uniform: kernels that use WBuf take
 //         their wave index through readfirstlane.
-struct WBuf {
-  __amdgpu_buffer_rsrc_t r; unsigned voff;
-  __device__ __forceinline__ WBuf(const float* base, unsigned lane_off_floats)
-      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)), voff(lane_off_floats * 4u) {}
-  __device__ __forceinline__ f32x4 ld(size_t idx) const {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (unsigned)(idx * 4u), 0));
-  }
-};
 __device__ __forceinline__ f32x4 wload(const float* p, size_t idx) { return *reinterpret_cast<const f32x4*>(p + idx); }
 __device__ __forceinline__ f32x4 wload(const WBuf& b, size_t idx) { return b.ld(idx); }
 
@@ -1168,20 +1140,6 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc)[NTW][MT], f32x4 (&wq)[D
 // Measured (profiles/r02_notes.md): wins for 3a (50 vs 68 us) and 4a (33 vs 49 us); for 2a / 2b / 3b the per-clip
 // serialisation of MFMA and VALU phases (their depthwise outputs leave room for one or two clips per CU only) ties
 // the three-kernel path, which therefore stays in place for those blocks.
-struct MidArgs {
-  const float* X; int Cin;
-  const float* WpE; const float* scE; const float* shE; int NTtotE;
-  const float* Wd; const float* scD; const float* shD;
-  const float* Wr; const float* br; const float* We; const float* be; int se;
-  const float* WpP; const float* scP; const float* shP;
-  float* Y; int Cout; int residual;
-  float* dbg_dw; float* dbg_gate;
-  int B;
-#ifdef MKWS_FRONT_TIMING
-  unsigned long long* dbg_t;
-#endif
-};
-
 template <int KS, int S, int KCT, int HT, int WT, int CEXP, int CC, int G, int SEG>
 struct MidGeom {
   static constexpr int HW = HT * WT;
@@ -4034,6 +3992,8 @@ struct mkws_embed {
   int fuse_stem = 1;               // 1: stem + whole block 1a in one kernel (stem_block1a_kernel); 0: separate kernels (parity taps)
   int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 2b, 3a and 4a (where it measured faster), 2 = 2a..4a, 3 = 3a and 4a only, 0 = never
+  int fuse_walk = 1;               // block 2a's front kernel: one workgroup walks the clip's three channel blocks (input read from HBM once); 0 = three workgroups per clip
+  int fuse_rows = 0;               // 1 = stride-1 big-image blocks (2b, 3b) on mbconv_rows_kernel (mkws_embed_rows.hip: depthwise output in registers, a wave per row tile); 0 = fuse_mid / front + back decide
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
   int fuse_chain = 1;              // depth-fused chains: 1 = blocks 4b..6a in ONE launch (mbconv_chain_kernel) and 6b..7a in ONE paired launch (mbconv_pair_chain_kernel); 2 / 3 = only the first / second; 0 = one launch per block
   mkws::BlockArgs* d_chain_tab = nullptr;   // device copy of every block's constants (BlockArgs without X / Y / dbg) for the chain kernels
@@ -4354,7 +4314,7 @@ static void wg_phase_report(const char* stage, size_t nblk, int nph) {
 #define MKWS_WG_TRACE_REPORT(s, stage, kernel, nblk)
 #endif
 
-void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B) {
+void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* sums, int B, int walk) {
   FrontArgs a;
   a.X = X; a.Cin = b.spec.in_ch; a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KC = b.expand.KC;
   a.NTtotE = b.expand.NTtot;
@@ -4374,7 +4334,9 @@ void launch_front(hipStream_t s, const char* stage, const BlockPlan& b, const fl
   if (G > B) G = B;
   a.G = G;
   const size_t lds = (((size_t)G * HW + 1) * (CC + 4) + 256 * 4 + (size_t)G * CC + (tiny ? 0 : (size_t)ks * ks * CC)) * sizeof(float);
-  const dim3 grid((B + G - 1) / G, (b.ce + CC - 1) / CC);
+  const int nblk_c = (b.ce + CC - 1) / CC;
+  a.ncb = (!tiny && walk && b.H == 25) ? nblk_c : 1;      // 2a: one workgroup walks the clip's three channel blocks (fuse_walk)
+  const dim3 grid((B + G - 1) / G, nblk_c / a.ncb);
   ProfScope ps(stage, std::string("mbconv_front_kernel<") + std::to_string(ks) + "," + std::to_string(st) + "," + std::to_string(CC) + "," +
                           (tiny ? "0," : std::to_string(kc) + ",") + std::to_string(b.H) + "," + std::to_string(b.W) + ">");
 #ifdef MKWS_FRONT_TIMING
@@ -4875,6 +4837,32 @@ int launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const float
   return launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 3, 512, 4, true>(s, stage, a);                             // 4a: the same
 }
 
+// Register-resident whole-block kernel (mkws_embed_rows.hip): the stride-1 big-image blocks 2b and 3b.
+int rows_variant(const BlockPlan& b) {
+  if (!b.has_expand || b.se.se > 10 || b.spec.stride != 1 || !b.residual) return -1;
+  const int ks = b.spec.kernel, ci = b.spec.in_ch, co = b.spec.out_ch;
+  if (b.H == 13 && b.W == 10 && ks == 3 && ci == 24 && co == 24 && b.ce == 144 && b.project.NTtot == 2) return kRows2b;
+  if (b.H == 7 && b.W == 5 && ks == 5 && ci == 40 && co == 40 && b.ce == 240 && b.project.NTtot == 3) return kRows3b;
+  return -1;
+}
+
+int launch_rows(hipStream_t s, const char* stage, const BlockPlan& b, int alt, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+  MidArgs a;
+  a.X = X; a.Cin = b.spec.in_ch;
+  a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.NTtotE = b.expand.NTtot;
+  a.Wd = b.dw.Wd; a.scD = b.dw.scale; a.shD = b.dw.shift;
+  a.Wr = b.se.Wr; a.br = b.se.br; a.We = b.se.We; a.be = b.se.be; a.se = b.se.se;
+  a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift;
+  a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
+  a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate; a.B = B;
+#ifdef MKWS_FRONT_TIMING
+  a.dbg_t = nullptr;
+#endif
+  const int v = rows_variant(b) + (alt ? 16 : 0);          // fuse_rows = 2: the A/B shapes of mkws_embed_rows.hip (clips per wave / workgroups per CU the other way round)
+  ProfScope ps(stage, rows_kernel_name(v));
+  return launch_rows_variant(s, v, a);
+}
+
 // Back half (SE + gated projection in one launch) for the blocks that keep mbconv_front_kernel: 2a, 2b, 3b.
 bool back_supported(const BlockPlan& b) {
   if (!b.has_expand || b.se.se > 10) return false;
@@ -5003,6 +4991,16 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       continue;
     }
     const bool want_expand_tap = stop && (p + "_expand") == stop;
+    if (em->fuse_rows && rows_variant(b) >= 0 && !want_expand_tap) {
+      // stride-1 big-image blocks: one launch, the depthwise output stays in registers; "_dw" / "_gate" taps come from the kernel's debug stores
+      const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
+      if (int rc = launch_rows(s, p.c_str(), b, em->fuse_rows == 2, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
+      if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
+      if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
+      if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;
+      float* t = cur; cur = nxt; nxt = t;
+      continue;
+    }
     if (mid_enabled(b, em->fuse_mid) && !want_expand_tap) {
       // big-image blocks: one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
@@ -5072,7 +5070,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       if (hit(p + "_expand", em->bufE, (size_t)Min * b.ce)) return MKWS_OK;
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else if (b.has_expand && front_supported(b)) {
-      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B);
+      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B, em->fuse_walk);
     } else if (b.has_expand) {
       launch_gemm(s, sw, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
@@ -5182,6 +5180,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // across the batch sizes one handle sees.
   em->fuse_block = 2;
   em->fuse_mid = 1;
+  em->fuse_rows = 0;       // measured slower than the mid / front + back kernels so far (profiles/r06_notes.md): an A/B option, not the plan
   em->fuse_back = 1;
   em->fuse_pair = pair_layout_ok() ? 1 : 0;
   // small-batch (live serving) handles: the tiny-image blocks on the 6-way cluster kernel, same dispatch-order premise as the pairs
@@ -5394,6 +5393,8 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_front") == 0) { em->fuse_front = value != 0; return MKWS_OK; }
   if (strcmp(name, "fuse_block") == 0) { em->fuse_block = value; return MKWS_OK; }
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_rows") == 0) { em->fuse_rows = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_walk") == 0) { em->fuse_walk = value; return MKWS_OK; }
   if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
   if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
   if (strcmp(name, "fuse_chain") == 0) { em->fuse_chain = value; return MKWS_OK; }
@@ -5427,6 +5428,8 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_front") == 0) return em->fuse_front ? 1 : 0;
   if (strcmp(name, "fuse_block") == 0) return em->fuse_block;
   if (strcmp(name, "fuse_mid") == 0) return em->fuse_mid;
+  if (strcmp(name, "fuse_rows") == 0) return em->fuse_rows;
+  if (strcmp(name, "fuse_walk") == 0) return em->fuse_walk;
   if (strcmp(name, "fuse_back") == 0) return em->fuse_back;
   if (strcmp(name, "fuse_pair") == 0) return em->fuse_pair;
   if (strcmp(name, "fuse_chain") == 0) return em->fuse_chain;

@@ -67,12 +67,14 @@ def test_execution_options_agree(ctx):
             ctx["em"].set_option("fuse_front", front)
             ctx["em"].set_option("fuse_block", block)
             ctx["em"].set_option("fuse_mid", mid)
+            ctx["em"].set_option("fuse_rows", combo & 1)           # 2b / 3b on the register-resident kernel, or left to fuse_mid / front + back
+            ctx["em"].set_option("fuse_walk", (combo >> 1) & 1)    # 2a's front kernel: one workgroup per clip walking the channel blocks, or one per block
             ctx["em"].set_option("fuse_back", 1 if mid != 2 else 0)
             ctx["em"].set_option("fuse_stem", front)
             ctx["em"].set_option("fuse_gap", front)
             assert _rel(ctx["em"].forward(x).cpu().numpy(), ref) < REL_TOL, (front, block, mid, pair)
             for name in ("stem", "block1a_dw", "block1a_gate", "block1a", "block2a_dw", "block2a_gate", "block2a", "block2b_dw", "block2b", "block3a_gate",
-                         "block3a", "block3b_dw", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6b", "block6c_dw", "block6c_gate", "block6d", "block7a_dw", "block7a", "top", "gap"):
+                         "block2b_gate", "block3a", "block3b_dw", "block3b_gate", "block3b", "block4a", "block4c_dw", "block4c", "block5b_dw", "block5b_gate", "block6a", "block6b", "block6c_dw", "block6c_gate", "block6d", "block7a_dw", "block7a", "top", "gap"):
                 taps = {}
                 ctx["oracle"].forward(spec[:3], taps)
                 got = ctx["em"].tap(x[:3], name).cpu().numpy().reshape(taps[name].shape)
@@ -83,9 +85,55 @@ def test_execution_options_agree(ctx):
         ctx["em"].set_option("fuse_front", 1)
         ctx["em"].set_option("fuse_block", 2)
         ctx["em"].set_option("fuse_mid", 1)
+        ctx["em"].set_option("fuse_rows", 0)
+        ctx["em"].set_option("fuse_walk", 1)
         ctx["em"].set_option("fuse_back", 1)
         ctx["em"].set_option("fuse_stem", 1)
         ctx["em"].set_option("fuse_gap", 1)
+
+
+@pytest.mark.parametrize("shape", [1, 2])
+def test_register_resident_block_kernel(ctx, shape):
+    """mbconv_rows_kernel (blocks 2b and 3b: a wave per 16-row tile, depthwise output in registers, SE sums by DPP rows): depthwise output,
+    gate and block output against the oracle for full, ragged (3b packs two clips per workgroup: odd batches leave a slot empty) and
+    single-clip batches; rows never interact (any sub-batch, any order: bit-identical); silent and loud clips at north_star's tolerance."""
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    em = ctx["em"]
+    em.set_option("fuse_rows", shape)           # 1 / 2: the two (clips per wave, workgroups per CU) shapes of each block
+    try:
+        rng = np.random.default_rng(33)
+        spec = _spec(rng, 37)
+        spec[5] = 0.0
+        spec[6] = (rng.integers(500, 671, size=(49, 40)) * np.float32(10 / 256))
+        x = torch.from_numpy(spec).to(ctx["dev"])
+        taps = {}
+        ctx["oracle"].forward(spec, taps)
+        ordinary = [i for i in range(37) if i not in (5, 6)]
+        full = {}
+        for name in ("block2b_dw", "block2b_gate", "block2b", "block3b_dw", "block3b_gate", "block3b"):
+            got = em.tap(x, name)
+            full[name] = got
+            g = got.cpu().numpy().reshape(taps[name].shape)
+            assert _rel(g[ordinary], taps[name][ordinary]) < REL_TOL, name
+            assert _rel(g, taps[name]) < 1e-3, name
+            assert _within(g[ordinary], taps[name][ordinary]), name
+        for b in (1, 2, 3, 4, 7, 36):
+            for name in ("block2b", "block3b_dw", "block3b_gate", "block3b"):
+                assert torch.equal(em.tap(x[:b], name), full[name].reshape(37, -1)[:b].reshape(-1)), (b, name)
+        perm = torch.randperm(37, device=ctx["dev"])
+        for name in ("block2b", "block3b"):
+            assert torch.equal(em.tap(x[perm], name).reshape(37, -1), full[name].reshape(37, -1)[perm]), name
+        # the same kernels in a live-serving handle (one clip) and with the option off: fp32 round-off apart, never more
+        small = EmbeddingModel(ctx["blob"], max_batch=1)
+        small.set_option("fuse_rows", shape)
+        for name in ("block2b", "block3b"):          # (another handle = another plan for the kernels in front: round-off, not bits)
+            assert _rel(small.tap(x[:1], name).cpu().numpy(), full[name].reshape(37, -1)[:1].reshape(-1).cpu().numpy()) < 1e-5, name
+        em.set_option("fuse_rows", 0)
+        for name in ("block2b", "block3b"):
+            other = em.tap(x, name).cpu().numpy().reshape(taps[name].shape)
+            assert _rel(other, full[name].cpu().numpy().reshape(taps[name].shape)) < 1e-5, name
+    finally:
+        em.set_option("fuse_rows", 0)
 
 
 def test_depth_fused_chain_is_bit_identical_to_the_single_block_kernels(ctx):
