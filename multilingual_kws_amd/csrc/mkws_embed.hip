@@ -4451,10 +4451,14 @@ int launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43,
     if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 3);
     else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 3);
     else MKWS_BLOCK(5, 2, 4, 3, 3);
-  } else if (b.H == 4 && b.W == 3) {
+  } else if (b.H == 4 && b.W == 3 && MT == 2) {
     if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 2);
     else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 2);
     else MKWS_BLOCK(5, 2, 4, 3, 2);
+  } else if (b.H == 4 && b.W == 3) {                     // one clip per workgroup (handles of <= 256 clips: a workgroup for every CU)
+    if (ks == 3 && st == 1) MKWS_BLOCK(3, 1, 4, 3, 1);
+    else if (ks == 5 && st == 1) MKWS_BLOCK(5, 1, 4, 3, 1);
+    else MKWS_BLOCK(5, 2, 4, 3, 1);
   } else {
     if (ks == 5) MKWS_BLOCK(5, 1, 2, 2, 1);
     else MKWS_BLOCK(3, 1, 2, 2, 1);
@@ -4527,9 +4531,12 @@ int launch_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const floa
   if (mt43 == 3) {
     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_chain_kernel<3, kBlockWaves>), 160 * 1024)) return rc_;
     hipLaunchKernelGGL((mbconv_chain_kernel<3, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, ca);
-  } else {
+  } else if (mt43 == 2) {
     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_chain_kernel<2, kBlockWaves>), 160 * 1024)) return rc_;
     hipLaunchKernelGGL((mbconv_chain_kernel<2, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, ca);
+  } else {
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_chain_kernel<1, kBlockWaves>), 160 * 1024)) return rc_;
+    hipLaunchKernelGGL((mbconv_chain_kernel<1, kBlockWaves>), grid, dim3(kBlockWaves * 64), lds, s, ca);
   }
 #ifdef MKWS_FRONT_TIMING
   if (ca.dbg_t) {
@@ -4568,6 +4575,14 @@ static int pair_count(int B, int mt) { const int G = 4 * mt; return ((B + G - 1)
 static size_t pair_ws_floats(int max_batch, int mt) { return (size_t)pair_count(max_batch, mt) * (2 * kPairXc1 + 2 * kPairXdAll * 2 * 256 + 4 + 4 * kPairChainMax); }   // exchange buffers (sized for the chain's all-tiles exchange) + flags of both kernels
 // Row tiles per pair for a handle: 8 clips per pair fill the chip from ~1024 clips up; smaller handles use 4-clip pairs so
 // that twice as many workgroups exist (512 clips: 256 instead of 128).  Per handle, like every other plan decision.
+// Row tiles per workgroup of the 4x3-image whole-block / chain kernels: 3 (4 clips), 2 (2 clips) or 1 (1 clip) -- the largest that still gives
+// every CU a workgroup (round 6: a 256-clip serving handle used to run 128 two-clip workgroups on 256 CUs).
+static int block43_row_tiles(int max_batch) {
+  const int cus = device_cu_count();
+  if ((max_batch + 3) / 4 >= cus) return 3;
+  if ((max_batch + 1) / 2 >= cus) return 2;
+  return (max_batch > cus / 2 && max_batch <= cus) ? 1 : 2;      // one clip per workgroup while that is still ONE round of workgroups and more than half a chip of them
+}
 static int pair_row_tiles(int max_batch) { return (2 * ((max_batch + 3) / 4) <= device_cu_count()) ? 1 : 2; }   // 4-clip pairs while they still fit in one round
 // The paired kernel wants blocks b and b ^ 8 on ONE XCD (their exchange goes through that XCD's L2 without agent-scope
 // cache maintenance).  True for the round-robin dispatch of an 8-XCD device in SPX mode; checked once per device instead of
@@ -5186,7 +5201,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // small-batch (live serving) handles: the tiny-image blocks on the 6-way cluster kernel, same dispatch-order premise as the pairs
   em->fuse_cluster = (max_batch <= kClusterMaxBatch && em->fuse_pair) ? 1 : 0;
   em->pair_mt = pair_row_tiles(max_batch);
-  em->block_mt43 = (em->pair_mt == 1) ? 2 : 3;
+  em->block_mt43 = block43_row_tiles(max_batch);
   (void)hipGetDevice(&em->device);
   Packer pk;
   std::vector<float> sc, sh;
@@ -5405,10 +5420,15 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "big_tiles") == 0) {      // A/B: 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (fewer, larger workgroups: the workspaces still fit)
-    if (value) { em->pair_mt = 2; em->block_mt43 = 3; } else { em->pair_mt = pair_row_tiles(em->max_batch); em->block_mt43 = (em->pair_mt == 1) ? 2 : 3; }
+    if (value) { em->pair_mt = 2; em->block_mt43 = 3; } else { em->pair_mt = pair_row_tiles(em->max_batch); em->block_mt43 = block43_row_tiles(em->max_batch); }
     return MKWS_OK;
   }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
+  if (strcmp(name, "block_tiles") == 0) {    // A/B: row tiles (3 / 2 / 1 = 4 / 2 / 1 clips) per workgroup of the 4x3-image kernels; 0 = the rule of the handle's max_batch
+    if (value < 0 || value > 3) return fail(MKWS_ERR_INVALID_ARG, "block_tiles is 0 (rule), 1, 2 or 3");
+    em->block_mt43 = value ? value : block43_row_tiles(em->max_batch);
+    return MKWS_OK;
+  }
   if (strcmp(name, "pair_fault") == 0) { em->pair_fault = value; return MKWS_OK; }     // test hook: forces the paired kernel's failure paths
   if (strcmp(name, "inject_exchange_error") == 0) {
     // test hook: the state a failed exchange of an EARLIER launch leaves behind (sticky device word + host-mapped word), without running
@@ -5437,6 +5457,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_cluster") == 0) return em->fuse_cluster;
   if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
   if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;
+  if (strcmp(name, "block_tiles") == 0) return em->block_mt43;
   if (strcmp(name, "pair_degraded") == 0) return em->pair_degraded;
   if (strcmp(name, "guard_floats") == 0) return (int)em->guard;
   if (strcmp(name, "guard_bands") == 0) return (int)em->guard_spans.size();

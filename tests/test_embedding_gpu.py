@@ -397,12 +397,31 @@ def test_serving_handle_plans(ctx, max_batch, plan):
     for b in sorted({1, n // 2, n - 1} - {0}):
         assert torch.equal(em.forward(x[:b]), out[:b]), b
     if max_batch == 256:
+        if plan not in ("multi-kernel",):
+            assert em.get_option("block_tiles") == 1        # round 6: one clip per workgroup of the 4x3-image chain (256 workgroups on 256 CUs, not 128)
         full = _spec(np.random.default_rng(7), 256)
         xf = torch.from_numpy(full).to(ctx["dev"])
         of = em.forward(xf)
         idx = np.arange(0, 256, 23)
         assert _rel(of[idx].cpu().numpy(), ctx["oracle"].forward(full[idx]).numpy()) < REL_TOL
         assert torch.equal(em.forward(xf[:n]), of[:n])
+        if plan not in ("multi-kernel",):
+            # every workgroup shape of the 4x3-image kernels on the same handle: depth-fused chain and single-block launches, against each other
+            # at fp32 round-off (another tile shape = another plan) and against the oracle
+            try:
+                for tiles in (2, 3, 1):
+                    em.set_option("block_tiles", tiles)
+                    for chain in (1, 0):
+                        em.set_option("fuse_chain", chain)
+                        o2 = em.forward(xf)
+                        assert _rel(o2.cpu().numpy(), of.cpu().numpy()) < 1e-5, (tiles, chain)
+                        for name in ("block4c", "block5b_dw", "block5b_gate", "block6a"):
+                            t2 = {}
+                            ctx["oracle"].forward(full[:5], t2)
+                            assert _rel(em.tap(xf[:5], name).cpu().numpy().reshape(t2[name].shape), t2[name]) < REL_TOL, (tiles, chain, name)
+            finally:
+                em.set_option("block_tiles", 0)
+                em.set_option("fuse_chain", 1)
 
 
 def test_cluster_kernel_taps_and_failure_contract(ctx):
