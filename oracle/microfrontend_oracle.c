@@ -18,10 +18,13 @@
  * routine it restates.  Types are followed exactly (int16 wrap, int32 products, uint64
  * accumulators, C float vs double evaluation in table construction).
  *
- * Pinning.  The reference has no tests or golden vectors for this path => PARITY IS UNPINNED BY THE
- * REFERENCE.  The restatement is instead pinned by upstream TensorFlow's own unit-test constants
+ * Pinning.  The reference has no tests for this path, but it holds one OUTPUT of the real op: the tutorial notebook's cell 13 renders
+ * input_data.file2spec (= TF's AudioMicrofrontend op with its defaults) for three clips whose WAV bytes the notebook embeds.  This
+ * restatement reproduces that rendering cell for cell (tests/test_tutorial_png_pin.py: all 5 880 cells carry the colour of the value
+ * computed here; one colour step ~ 2.5 raw integer units, and every wrong op default recolours cells) -- pinned to reference-held data
+ * at that resolution.  Below a colour step, bit-exactness rests on upstream TensorFlow's own unit-test constants
  * (window_test.cc, noise_reduction_test.cc, frontend_test.cc / audio_microfrontend_op_test.py:
- * the 4x2 known answer {{479,425},{436,378},{410,350},{391,325}}) and by the SURVEY.md Appendix D
+ * the 4x2 known answer {{479,425},{436,378},{410,350},{391,325}}) and on the SURVEY.md Appendix D
  * checksums; see tests/test_oracle_frontend.py and tests/golden/.
  */
 #include <math.h>
