@@ -197,6 +197,12 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 of a clip from the expand to the projection and the depthwise output stays in its registers (mbconv_rows_kernel,
  *                 csrc/mkws_embed_rows.hip: 43 / 57 KB of LDS per workgroup, so two or three workgroups share a CU); 0 = "fuse_mid" /
  *                 the front + back pair decide for those blocks as before round 6.
+ *   "fuse_walk" (default 1): block 2a's expand + depthwise kernel runs ONE workgroup per clip that walks the clip's three 32-channel blocks
+ *                 (the input is read from HBM once); 0 = one workgroup per (clip, channel block).  Bit-identical either way.
+ *   "block_tiles" (set: 0 = the rule of the handle's max_batch, 1 / 2 / 3 = one / two / four clips per workgroup; get: the value in force):
+ *                 row tiles per workgroup of the 4x3-image whole-block / chain kernels (blocks 4b..6a).  The rule picks the largest that
+ *                 still gives every CU a workgroup: 3 from 1 024 clips, 2 for 512, 1 for 129..256-clip handles (round 6).  Another tile shape
+ *                 = another summation order inside the SE sums: results agree at fp32 round-off, bit-identical per handle.
  *   "fuse_gap" (default 1): global average pool fused into the top conv epilogue (its [B*4,1280] output is never stored).
  *   "fuse_stem" (default 1): stem conv + the whole of block 1a in one kernel (persistent workgroups, one per CU, each walking
  *                 clips blockIdx, blockIdx + grid, ... with the next clip's spectrogram prefetched; both 25x20x32 activations stay

@@ -4834,7 +4834,7 @@ bool mid_enabled(const BlockPlan& b, int fuse_mid) {
   return (b.H == 13 && b.spec.kernel == 5) || (b.H == 7 && b.spec.stride == 2);
 }
 
-int launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+int launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, int one_clip, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
   MidArgs a;
   a.X = X; a.Cin = b.spec.in_ch;
   a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.NTtotE = b.expand.NTtot;
@@ -4849,6 +4849,7 @@ int launch_mid(hipStream_t s, const char* stage, const BlockPlan& b, const float
   if (b.H == 13 && ks == 3) return launch_mid_inst<3, 1, 2, 13, 10, 144, 48, 2, 1, 5, 1024, 4, true>(s, stage, a);     // 2b: pair strips of half an output row (67.1 vs 67.8 us with quad items; 512 threads: 71-74 us)
   if (b.H == 13) return launch_mid_inst<5, 2, 2, 13, 10, 144, 48, 3, 1, 5, 512, 4, true>(s, stage, a);            // 3a: pair strips of a whole output row
   if (st == 1) return launch_mid_inst<5, 1, 3, 7, 5, 240, 48, 3, 1, 1, 512, 4>(s, stage, a);                      // 3b
+  if (one_clip) return launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 1, 3, 512, 4, true>(s, stage, a);                // 4a on handles of <= 256 clips: a workgroup per clip (two-clip workgroups leave half the CUs idle there)
   return launch_mid_inst<3, 2, 3, 7, 5, 240, 48, 5, 2, 3, 512, 4, true>(s, stage, a);                             // 4a: the same
 }
 
@@ -5019,7 +5020,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
     if (mid_enabled(b, em->fuse_mid) && !want_expand_tap) {
       // big-image blocks: one launch for the whole block; "_dw" / "_gate" taps come from the kernel's debug stores
       const bool tap_dw = stop && (p + "_dw") == stop, tap_gate = stop && (p + "_gate") == stop;
-      if (int rc = launch_mid(s, p.c_str(), b, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
+      if (int rc = launch_mid(s, p.c_str(), b, em->block_mt43 == 1, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
       if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
       if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
       if (hit(p, nxt, (size_t)Mout * b.spec.out_ch)) return MKWS_OK;

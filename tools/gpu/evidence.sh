@@ -10,7 +10,7 @@ for c in embed frontend finetune stream; do
 done
 fi
 export TMPDIR=/tmp
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --sustain-s 0 > $GRAFT_REPO_ROOT/$O/stats.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch -o f -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_fetch.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $GRAFT_REPO_ROOT/$O/pmc_write -o w -- python $GRAFT_REPO_ROOT/tools/one_fwd.py > $GRAFT_REPO_ROOT/$O/pmc_write.log 2>&1 )
 for BS in 3072 512 256; do
