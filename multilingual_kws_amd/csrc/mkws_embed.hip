@@ -4157,6 +4157,15 @@ TileChoice pick_tile(int M, int NTtot, int KC) {
   // layers against 170 us with 2 x 4 (+ 1 x 2 for dense_2) once the K loop was free of VALU instructions (tools/gpu/sweep1024.sh)
   if (NTtot >= 64 && KC >= 64 && M >= 1024 && M < 2048 && waves(1, 4, 1) >= 1024) return {1, 4, 1};
   if (NTtot >= 64 && KC >= 64 && waves(2, 4, 1) >= 1024) return {2, 4, 1};
+  // dense layers of 129..1023-clip handles (round 6, `tools/gpu/r6_gemm256.sh`: eleven forced shapes per layer at 256 and 512 clips): the winner is
+  // the widest 1 x NT tile that still puts ONE wave on every SIMD (1 024 waves) WITHOUT splitting K -- 256 clips: 1 x 2 (20.3 / 27.6 us against
+  // 26.0 / 33.6 for 1 x 2 over two K slices + the fold launch), 512 clips: 1 x 4 (28.7 / 38.2 against 33.1 / 48.0) and 1 x 2 for dense_2 (27.5
+  // against 32.7) -- and two K slices only where even 1 x 2 leaves half the SIMDs empty (dense_2 at 256 clips: 22.3 against 27.3 unsplit)
+  if (NTtot >= 64 && KC >= 64 && M > 128) {
+    if (waves(1, 4, 1) >= 1024) return {1, 4, 1};
+    if (waves(1, 2, 1) >= 1024) return {1, 2, 1};
+    if (waves(1, 2, 2) >= 1024) return {1, 2, 2};
+  }
   if (waves(2, 2, 1) >= kWantWaves) return {2, 2, 1};
   if (waves(1, 2, 1) >= kWantWaves) return {1, 2, 1};
   if (KC >= 32 && waves(1, 2, 2) >= kWantWaves) return {1, 2, 2};
