@@ -197,6 +197,9 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 of a clip from the expand to the projection and the depthwise output stays in its registers (mbconv_rows_kernel,
  *                 csrc/mkws_embed_rows.hip: 43 / 57 KB of LDS per workgroup, so two or three workgroups share a CU); 0 = "fuse_mid" /
  *                 the front + back pair decide for those blocks as before round 6.
+ *   "fuse_gemv" (default 1): handles planned for at most 4 rows (live serving: max_batch <= 4 for the dense layers, a one-clip handle for the
+ *                 top conv + pool) run those layers as matrix-vector products, ONE launch per layer (a 16-wave workgroup per 16-column tile,
+ *                 K split over its waves, partial columns folded in LDS in a fixed order); 0 = the MFMA GEMM + split-K fold launches.
  *   "fuse_walk" (default 1): block 2a's expand + depthwise kernel runs ONE workgroup per clip that walks the clip's three 32-channel blocks
  *                 (the input is read from HBM once); 0 = one workgroup per (clip, channel block).  Bit-identical either way.
  *   "block_tiles" (set: 0 = the rule of the handle's max_batch, 1 / 2 / 3 = one / two / four clips per workgroup; get: the value in force):

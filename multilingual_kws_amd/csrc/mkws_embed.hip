@@ -564,6 +564,72 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs a) {
 }
 
 // split-K epilogue: Y = act(sum_z part[z] * scale + shift) + R, one float4 per thread
+// ------------------------------------------------------------------------------------------------
+// Matrix-vector form of the dense tail for live-serving handles (at most 4 rows: dense / dense_1 / dense_2 of a one-clip handle, and its top
+// conv over the clip's 2x2 pixels with the average pool).  With one row the MFMA tile is 1/16 full and the work is the weight stream:
+// pw_gemm_kernel + its split-K fold took 4 x 5.7 + 3 x 4.5 us of a 354 us window (profiles/r06_latency_stats.txt).  Here ONE workgroup of 16
+// waves owns one 16-column tile and splits K sixteen ways: every wave requests ALL its weight fragments (at most NJ, 1 KB each, the packed
+// layout the GEMMs read) and row fragments before the first multiply -- one memory round trip per layer -- and the sixteen partial columns
+// meet in LDS, folded in (wave, lane group) order by the lanes that own the outputs: no second launch, fixed order.
+// Epilogue as pw_gemm_kernel / splitk_reduce_kernel: acc * scale + shift, activation, (pool: ((r0 + r1) + (r2 + r3)) * 0.25), poison.
+template <int ROWS, int NJ>
+__global__ __launch_bounds__(1024) void gemv_kernel(GemmArgs a) {
+  __shared__ float s_part[16][ROWS][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int t = blockIdx.x;
+  const float* wl = a.Wp + ((size_t)t * 64 + lane) * 4;          // + j * NTtot * 256
+  f32x4 w[NJ], x[ROWS][NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = wave + 16 * i, jc = j < a.KC ? j : a.KC - 1;    // past the end: a harmless reload, masked below
+    w[i] = *reinterpret_cast<const f32x4*>(wl + (size_t)jc * a.NTtot * 256);
+    const int k = (16 * jc + 4 * g < a.K - 4) ? 16 * jc + 4 * g : a.K - 4;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) x[r][i] = *reinterpret_cast<const f32x4*>(a.X + (size_t)(r < a.M ? r : 0) * a.ldx + k);
+  }
+  float acc[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const bool live = wave + 16 * i < a.KC && 16 * (wave + 16 * i) + 4 * g < a.K;      // (rows of W past K are zero in the packed layout; the row fragment was clamped)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[r] += live ? w[i][s4] * x[r][i][s4] : 0.0f;
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) s_part[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int n = 16 * t + c;
+    if (n < a.N) {
+      const float sc = a.scale[n], sh = a.shift[n];
+      const bool poisoned = a.poison != nullptr && *a.poison != 0;
+      float y[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        float v = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < 16; ++wv)
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) v += s_part[wv][r][16 * gg + c];
+        y[r] = apply_act(v * sc + sh, a.act);
+        if (poisoned) y[r] = __builtin_nanf("");
+      }
+      if (a.pool4) {
+        if (ROWS == 4) a.Y[n] = ((y[0] + y[ROWS > 1 ? 1 : 0]) + (y[ROWS > 2 ? 2 : 0] + y[ROWS > 3 ? 3 : 0])) * 0.25f;
+      } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+          if (r < a.M) a.Y[(size_t)r * a.ldy + n] = y[r];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splitk, int M, int N, int ldp,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                             const float* __restrict__ R, int ldr, float* __restrict__ Y, int ldy,
@@ -3992,6 +4058,7 @@ struct mkws_embed {
   int fuse_stem = 1;               // 1: stem + whole block 1a in one kernel (stem_block1a_kernel); 0: separate kernels (parity taps)
   int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 2b, 3a and 4a (where it measured faster), 2 = 2a..4a, 3 = 3a and 4a only, 0 = never
+  int fuse_gemv = 1;               // handles of at most 4 planned rows (one clip): dense layers and top conv on gemv_kernel (one launch per layer, K split inside the workgroup); 0 = pw_gemm_kernel + split-K fold
   int fuse_walk = 1;               // block 2a's front kernel: one workgroup walks the clip's three channel blocks (input read from HBM once); 0 = three workgroups per clip
   int fuse_rows = 0;               // 1 = stride-1 big-image blocks (2b, 3b) on mbconv_rows_kernel (mkws_embed_rows.hip: depthwise output in registers, a wave per row tile); 0 = fuse_mid / front + back decide
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
@@ -4129,7 +4196,7 @@ int pick_cqb(int cq) {   // largest divisor of cq that is <= 64
 }
 
 // split-K workspace: part of the handle's own workspace, handed to every launch_gemm of its forward
-struct SplitWs { float* p = nullptr; size_t floats = 0; const int* poison = nullptr; };   // poison: see GemmArgs (set for the LAST layer only)
+struct SplitWs { float* p = nullptr; size_t floats = 0; const int* poison = nullptr; int gemv = 0; };   // poison: see GemmArgs (set for the LAST layer only)
 
 template <int MT, bool GATE>
 void launch_gemm_nt(int NT, dim3 grid, hipStream_t s, const GemmArgs& a) {
@@ -4180,6 +4247,27 @@ void launch_gemm(hipStream_t s, const SplitWs& sw, const char* stage, const Gemm
   a.poison = sw.poison;
   a.X = X; a.ldx = ldx; a.Wp = L.Wp; a.scale = L.scale; a.shift = L.shift; a.gate = gate; a.HW = HW > 0 ? HW : 1;
   a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy; a.M = M; a.K = L.K; a.N = L.N; a.KC = L.KC; a.NTtot = L.NTtot; a.act = act;
+  // live-serving handles (planned for at most 4 rows): the matrix-vector kernel, one launch per layer (decided on the planned rows: every batch
+  // size of a handle takes the same path)
+  if (sw.gemv && Mplan <= 4 && !gate && !R && L.KC <= 128 && L.NTtot >= 32 && L.K % 4 == 0 && (!pool4 || (Mplan == 4 && M == 4))) {
+    a.splitk = 1; a.part = nullptr; a.ldp = 0;
+#ifdef MKWS_FRONT_TIMING
+    a.dbg_clk = nullptr;
+#endif
+    const int rows = Mplan <= 1 ? 1 : 4, nj = (L.KC + 15) / 16;
+    ProfScope ps(stage, std::string("gemv_kernel<") + std::to_string(rows) + "," + std::to_string(nj <= 2 ? 2 : nj <= 5 ? 5 : 8) + ">");
+    const dim3 grid(L.NTtot), block(1024);     // (two / four workgroups per tile, by columns, so that every CU streams: measured, no faster -- a launch of this size is ~6 us whatever it does)
+    if (rows == 1) {
+      if (nj <= 2) hipLaunchKernelGGL((gemv_kernel<1, 2>), grid, block, 0, s, a);
+      else if (nj <= 5) hipLaunchKernelGGL((gemv_kernel<1, 5>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemv_kernel<1, 8>), grid, block, 0, s, a);
+    } else {
+      if (nj <= 2) hipLaunchKernelGGL((gemv_kernel<4, 2>), grid, block, 0, s, a);
+      else if (nj <= 5) hipLaunchKernelGGL((gemv_kernel<4, 5>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemv_kernel<4, 8>), grid, block, 0, s, a);
+    }
+    return;
+  }
   TileChoice tc = pick_tile(Mplan, L.NTtot, L.KC);
   if (pool4) tc.splitk = 1;                 // the fused average pool lives in the direct epilogue only
   if (const char* f = getenv("MKWS_GEMM_FORCE")) {       // experiment hook: "Mmax,MT,NT,SK" applies to layers with Mplan <= Mmax
@@ -4972,7 +5060,7 @@ int check_pair_health(mkws_embed* em, hipStream_t s) {
 // the buffer holding that stage's output.
 int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStream_t s, const char* stop,
                 const float** tap_src, size_t* tap_count) {
-  SplitWs sw; sw.p = em->splitk_ws; sw.floats = em->splitk_floats;
+  SplitWs sw; sw.p = em->splitk_ws; sw.floats = em->splitk_floats; sw.gemv = em->fuse_gemv;
   auto hit = [&](const std::string& name, const float* p, size_t n) {
     if (stop && name == stop) { *tap_src = p; *tap_count = n; return true; }
     return false;
@@ -5095,7 +5183,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
       if (hit(p + "_expand", em->bufE, (size_t)Min * b.ce)) return MKWS_OK;
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
     } else if (b.has_expand && front_supported(b)) {
-      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B, em->fuse_walk);
+      launch_front(s, (p + "_dw").c_str(), b, cur, em->bufD, em->sums, B, em->fuse_walk && em->max_batch >= 128);   // (small handles keep one workgroup per channel block: three CUs per clip instead of one)
     } else if (b.has_expand) {
       launch_gemm(s, sw, (p + "_expand").c_str(), b.expand, cur, b.spec.in_ch, Min, em->max_batch * b.H * b.W, ACT_SWISH, nullptr, 0, nullptr, 0, em->bufE, b.ce);
       launch_dw(s, (p + "_dw").c_str(), b, em->bufE, em->bufD, em->sums, B);
@@ -5420,6 +5508,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
   if (strcmp(name, "fuse_rows") == 0) { em->fuse_rows = value; return MKWS_OK; }
   if (strcmp(name, "fuse_walk") == 0) { em->fuse_walk = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_gemv") == 0) { em->fuse_gemv = value; return MKWS_OK; }
   if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
   if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
   if (strcmp(name, "fuse_chain") == 0) { em->fuse_chain = value; return MKWS_OK; }
@@ -5460,6 +5549,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_mid") == 0) return em->fuse_mid;
   if (strcmp(name, "fuse_rows") == 0) return em->fuse_rows;
   if (strcmp(name, "fuse_walk") == 0) return em->fuse_walk;
+  if (strcmp(name, "fuse_gemv") == 0) return em->fuse_gemv;
   if (strcmp(name, "fuse_back") == 0) return em->fuse_back;
   if (strcmp(name, "fuse_pair") == 0) return em->fuse_pair;
   if (strcmp(name, "fuse_chain") == 0) return em->fuse_chain;

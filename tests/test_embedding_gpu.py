@@ -396,6 +396,20 @@ def test_serving_handle_plans(ctx, max_batch, plan):
     assert _rel(out.cpu().numpy(), ref) < REL_TOL and np.array_equal(out.cpu().numpy().argmax(1), ref.argmax(1))
     for b in sorted({1, n // 2, n - 1} - {0}):
         assert torch.equal(em.forward(x[:b]), out[:b]), b
+    if max_batch <= 4:
+        # round 6: the dense tail (and, for a one-clip handle, the top conv + pool) of live-serving handles runs on gemv_kernel: one launch per
+        # layer, K split inside the workgroup.  Against the MFMA GEMM + split-K fold it replaces: another summation order, fp32 round-off
+        assert em.get_option("fuse_gemv") == 1
+        xs = x[:max_batch]
+        for name in ("gap", "dense", "dense_1", "dense_2"):
+            t = {}
+            ctx["oracle"].forward(spec[:max_batch], t)
+            assert _rel(em.tap(xs, name).cpu().numpy().reshape(t[name].shape), t[name]) < REL_TOL, name
+        em.set_option("fuse_gemv", 0)
+        try:
+            assert _rel(em.forward(x).cpu().numpy(), out.cpu().numpy()) < 1e-5
+        finally:
+            em.set_option("fuse_gemv", 1)
     if max_batch == 256:
         if plan not in ("multi-kernel",):
             assert em.get_option("block_tiles") == 1        # round 6: one clip per workgroup of the 4x3-image chain (256 workgroups on 256 CUs, not 128)
