@@ -457,23 +457,23 @@ def main():
         nwin = len(bsa.window_offsets(stream.shape[0], 16000, 320))
         units_per_step, unit = nwin, "windows/s"
 
-        lanes = int(os.environ.get("MKWS_SERVING_LANES", bsa.SERVING_LANES))
+        lanes = bsa.SERVING_LANES = int(os.environ.get("MKWS_SERVING_LANES", bsa.SERVING_LANES))
 
         def step():
-            # = batch_streaming_analysis.streaming_inferences without the final device-to-host copy: full batches replay a captured
-            # hipGraph (embedding + 50 heads), `lanes` independent batches per replay; the ragged last batch runs launch by launch
-            specs = bsa.stream_spectrograms(ms, stream, 16000, 320)
-            nfull, s = specs.shape[0] // B, 0
-            while s < specs.shape[0]:
-                left = nfull - s // B
-                if left > 0:
-                    n = min(lanes, left)
-                    bsa._BatchGraph.get(em, heads, B, n).run([specs[s + i * B:s + (i + 1) * B] for i in range(n)])
-                    s += n * B
-                else:
-                    Head.forward_many(heads, em.forward(specs[s:s + B]))
-                    s += B
+            # = batch_streaming_analysis.streaming_inferences without the final device-to-host copy: full batches replay captured hipGraphs
+            # (embedding + 50 heads), `lanes` of them side by side on their own streams; the ragged last batch runs launch by launch beside them
+            bsa.serve_spectrograms(em, heads, bsa.stream_spectrograms(ms, stream, 16000, 320), B)
         extra_out["serving_lanes"] = lanes
+
+        def stream_check():
+            # outside the timed region: the probabilities of one more pass are finite and no handle recorded a failed exchange (a graph replay
+            # returns no code: a poisoned run must not become a bench line)
+            p = bsa.serve_spectrograms(em, heads, bsa.stream_spectrograms(ms, stream, 16000, 320), B)
+            torch.cuda.synchronize()
+            bad = [e for e in [em] + list(em._replicas) if e.get_option("exchange_error") or e.get_option("pair_degraded")]
+            if not bool(torch.isfinite(p).all()) or bad or tuple(p.shape) != (len(heads), nwin, 3):
+                raise SystemExit("bench.py --config stream: the serving lanes returned non-finite probabilities or a handle left the exchange kernels")
+            extra_out["serving_lanes_used"] = max([g.lanes for g in bsa._BatchGraph._cache.values()] or [1])
 
     def fence():
         torch.cuda.synchronize()
@@ -505,6 +505,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    if cfg == "stream":
+        stream_check()
     value = world * units_per_step * args.steps / elapsed
     if cfg == "embed":
         def timed(fn, min_s, min_steps):

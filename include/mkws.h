@@ -212,7 +212,14 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 in LDS); 0 = separate kernels.
  *   "pair_fault" / "inject_exchange_error" (test hooks): force the exchange kernels' failure paths / leave the error words as a failed
  *                 exchange of an earlier launch would (tests/test_embedding_gpu.py, tests/test_streaming.py).
- *   "big_tiles" (A/B aid, default 0): 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (what handles above 512 clips use). */
+ *   "big_tiles" (A/B aid, default 0): 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (what handles above 512 clips use).
+ *   "plan_batch" (default max_batch; set: a clip count >= max_batch, 0 = back to max_batch): the workgroup shapes of the tiny-image kernels
+ *                 (blocks 4b..7a: clips per workgroup / per pair) are those of a handle of this many clips.  For callers that run L handles
+ *                 CONCURRENTLY on L streams (serving lanes): pass the clips they hold together and each of those launches takes 1 / L of the chip
+ *                 instead of one clip per CU -- four 256-clip handles on four hardware queues then serve 1.03 M clips/s where one handle serves
+ *                 0.56 M (profiles/r06_notes.md section 8).  A lone call on such a handle is SLOWER (0.46 -> 0.64 ms at 256 clips): leave the
+ *                 option alone on handles that run by themselves.  The caller keeps lanes x 2 x ceil(max_batch / 8) within the CU count: the paired
+ *                 kernels hold their CU while they wait for their partner (failure contract below).  Results: as "block_tiles". */
 int mkws_embed_set_option(mkws_embed* em, const char* name, int value);
 /* Current value of an option above, of "exchange_error" (see the failure contract), or of "pair_degraded" (times the handle left the paired kernel after a failed exchange) /
  * "max_batch"; negative mkws_status for an unknown name.  ("pair_fault" is a write-only test hook that forces those failures.)

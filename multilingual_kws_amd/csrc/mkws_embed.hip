@@ -4035,6 +4035,8 @@ constexpr uint32_t kGuardCanary = 0x7FC00BADu;      // a quiet NaN with a recogn
 
 struct mkws_embed {
   int max_batch = 0;
+  int plan_batch = 0;             // the batch size whose WORKGROUP SHAPES the tiny-image kernels of this handle use: max_batch, or -- option "plan_batch" -- the clips
+                                  // that L handles running concurrently on L streams hold together (serving lanes: each of those launches then takes 1 / L of the chip)
   int device = 0;
   float* d_weights = nullptr;     // packed device weights
   float* d_ws = nullptr;          // workspace
@@ -5284,6 +5286,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   mkws_embed* em = new (std::nothrow) mkws_embed();
   if (!em) return fail(MKWS_ERR_ALLOC, "out of host memory");
   em->max_batch = max_batch;
+  em->plan_batch = max_batch;
   // Plan: whole-block kernels (+ the paired kernel where the device's dispatch order passed the probe) for EVERY handle size.
   // Round 2 gave handles below 384 clips the multi-kernel path (a whole-block kernel re-streams a block's weights once per 4
   // clips, and with launch-by-launch calls that lost below ~300 clips).  Since the serving paths replay hipGraphs the count of
@@ -5519,13 +5522,25 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "big_tiles") == 0) {      // A/B: 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (fewer, larger workgroups: the workspaces still fit)
-    if (value) { em->pair_mt = 2; em->block_mt43 = 3; } else { em->pair_mt = pair_row_tiles(em->max_batch); em->block_mt43 = block43_row_tiles(em->max_batch); }
+    if (value) { em->pair_mt = 2; em->block_mt43 = 3; } else { em->pair_mt = pair_row_tiles(em->plan_batch); em->block_mt43 = block43_row_tiles(em->plan_batch); }
+    return MKWS_OK;
+  }
+  if (strcmp(name, "plan_batch") == 0) {
+    // Plan for `value` clips (0 = back to max_batch): the caller runs several handles CONCURRENTLY on separate streams (serving lanes) and passes
+    // the clips they hold together, so that the tiny-image launches (blocks 4a..7a: 60 % of a forward pass) of a 256-clip lane take a quarter of the
+    // chip each -- the 1024-clip plan's workgroup shapes: 4-clip workgroups, 8-clip pairs -- instead of spreading one clip per CU and queueing behind the
+    // other lanes.  The GEMM tiles stay those of max_batch (measured: the 1024-clip tiles on 256 rows are a few long workgroups, 1.58 vs 0.99 ms per
+    // 4 x 256 clips, profiles/r06_notes.md section 8).  Per-clip arithmetic does not depend on the shapes beyond the documented round-off between them;
+    // workspaces are sized by max_batch and larger shapes need less of them.
+    if (value != 0 && value < em->max_batch) return fail(MKWS_ERR_INVALID_ARG, "plan_batch %d is below the handle's max_batch %d", value, em->max_batch);
+    em->plan_batch = value ? value : em->max_batch;
+    em->pair_mt = pair_row_tiles(em->plan_batch); em->block_mt43 = block43_row_tiles(em->plan_batch);
     return MKWS_OK;
   }
   if (strcmp(name, "fuse_gap") == 0) { em->fuse_gap = value; return MKWS_OK; }
   if (strcmp(name, "block_tiles") == 0) {    // A/B: row tiles (3 / 2 / 1 = 4 / 2 / 1 clips) per workgroup of the 4x3-image kernels; 0 = the rule of the handle's max_batch
     if (value < 0 || value > 3) return fail(MKWS_ERR_INVALID_ARG, "block_tiles is 0 (rule), 1, 2 or 3");
-    em->block_mt43 = value ? value : block43_row_tiles(em->max_batch);
+    em->block_mt43 = value ? value : block43_row_tiles(em->plan_batch);
     return MKWS_OK;
   }
   if (strcmp(name, "pair_fault") == 0) { em->pair_fault = value; return MKWS_OK; }     // test hook: forces the paired kernel's failure paths
@@ -5567,6 +5582,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   // poll -- a replay does not pass through mkws_embed_forward, so "pair_degraded" cannot move under it.
   if (strcmp(name, "exchange_error") == 0) return em->pair_err_host ? *reinterpret_cast<volatile int*>(em->pair_err_host) : 0;
   if (strcmp(name, "max_batch") == 0) return em->max_batch;
+  if (strcmp(name, "plan_batch") == 0) return em->plan_batch;
   return fail(MKWS_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

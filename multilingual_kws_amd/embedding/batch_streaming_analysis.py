@@ -15,6 +15,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import input_data
+from ..streams import concurrent_streams
 from .single_target_recognize_commands import RecognizeResult, SingleTargetRecognizeCommands
 
 
@@ -79,50 +80,57 @@ def stream_spectrograms(model_settings, audio, clip_duration_samples, clip_strid
 
 
 class _BatchGraph:
-    """embedding.forward + every head over `lanes` FULL batches of `batch` spectrograms as ONE hipGraph replay (static inputs /
-    outputs); cached per (embedding handle, head handles, batch, lanes).
+    """embedding.forward + every head over `lanes` FULL batches of `batch` spectrograms, one captured hipGraph PER LANE, each replayed on its
+    own HIP stream (static inputs / outputs); cached per (embedding handle, head handles, batch, lanes).
 
-    Why lanes: at 256 windows the embedding is ~60 small dependent launches, and the GPU sits mostly idle between and inside them
-    (each uses a fraction of the 256 CUs).  The batches of a stream are independent, so the graph forks into `lanes` branches --
-    one embedding handle (= one workspace) per branch, the heads are read-only and shared -- which the hardware queues run
-    concurrently.  Every branch is the same launches on the same plan as an eager call: results are bit-identical."""
+    Why lanes: at 256 windows every launch of the embedding is latency-bound -- one clip per workgroup, each workgroup streaming the whole
+    block's weights -- and a 256-clip batch costs about half of what a 1024-clip batch costs.  The batches of a stream are independent: `lanes`
+    of them run side by side, every lane on a replica handle (= its own workspace; the heads are read-only and shared) that runs the PLAN of
+    lanes x batch clips (4-clip workgroups, 8-clip pairs: a quarter of the chip per launch at four lanes; EmbeddingModel.serving_lanes).
+    Round 6: the lanes used to be the branches of ONE forked hipGraph, which this HIP runtime replays one branch after the other (649 k clips/s
+    at 4 x 256 where four graphs on four streams give 1.03 M; profiles/r06_notes.md section 8).  One lane = the caller's own handle and plan,
+    the same launches as an eager call, bit for bit."""
     _cache = {}
 
     def __init__(self, embedding, heads, batch, lanes=1):
         import torch
         dev = embedding.device
-        ems = embedding.replicas(lanes)
-        self.keep = (ems, list(heads))                               # the graph holds raw handles: keep their owners alive
+        ems = embedding.serving_lanes(lanes, max(lanes, SERVING_LANES) * batch) if lanes > 1 else [embedding]
+        self.keep = (ems, list(heads))                               # the graphs hold raw handles: keep their owners alive
+        self.owner = embedding
         self.lanes = lanes
         self.heals = 0                                               # re-captures after a failed exchange (run)
         self.generation = (embedding.generation, tuple(h.generation for h in heads))
         self.specs = [torch.zeros((batch, 49, 40), dtype=torch.float32, device=dev) for _ in range(lanes)]
+        # one stream per lane, each on a hardware queue of its own (measured, not assumed: streams.py); a single lane runs on the caller's stream
+        self.side = concurrent_streams(lanes, dev) if lanes > 1 else [None]
+        assert len(self.side) == lanes, "serve_spectrograms asks for no more lanes than concurrent_streams() finds"
         self._capture()
 
     def _capture(self):
         import torch
         from ..head import Head
         ems, heads = self.keep
-        lanes, dev = self.lanes, ems[0].device
+        lanes, dev, side = self.lanes, ems[0].device, self.side
 
         def chain(i):
             return Head.forward_many(heads, ems[i].forward(self.specs[i]))
-        side = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        warm = [torch.cuda.Stream(device=dev)] if lanes == 1 else side
         for i in range(lanes):                                       # eager warm-up on side streams (lazy init outside the capture); a
-            side[i].wait_stream(torch.cuda.current_stream(dev))      # handle with a recorded exchange failure is healed here (the wrapper
-            with torch.cuda.stream(side[i]):                         # repeats the call that returns MKWS_ERR_EXCHANGE)
+            warm[i].wait_stream(torch.cuda.current_stream(dev))      # handle with a recorded exchange failure is healed here (the wrapper
+            with torch.cuda.stream(warm[i]):                         # repeats the call that returns MKWS_ERR_EXCHANGE)
                 chain(i)
-            torch.cuda.current_stream(dev).wait_stream(side[i])
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            main = torch.cuda.current_stream(dev)
-            self.probs = [chain(0)]
-            for i in range(1, lanes):                                # fork: branch i starts where the capture stream is now
-                side[i].wait_stream(main)
-                with torch.cuda.stream(side[i]):
+            torch.cuda.current_stream(dev).wait_stream(warm[i])
+        self.graphs, self.probs = [], []
+        for i in range(lanes):
+            g = torch.cuda.CUDAGraph()
+            if lanes == 1:
+                with torch.cuda.graph(g):
                     self.probs.append(chain(i))
-            for i in range(1, lanes):                                # join
-                main.wait_stream(side[i])
+            else:
+                with torch.cuda.graph(g, stream=side[i]):
+                    self.probs.append(chain(i))
+            self.graphs.append(g)
 
     @classmethod
     def get(cls, embedding, heads, batch, lanes=1):
@@ -142,26 +150,109 @@ class _BatchGraph:
     @classmethod
     def forget(cls, obj):
         """Drop every cached graph that captured `obj` (an EmbeddingModel or Head being closed)."""
-        for k in [k for k, g in cls._cache.items() if any(obj is e for e in g.keep[0]) or any(obj is h for h in g.keep[1])]:
+        for k in [k for k, g in cls._cache.items() if obj is g.owner or any(obj is e for e in g.keep[0]) or any(obj is h for h in g.keep[1])]:
             del cls._cache[k]
 
     def exchange_failed(self):
         return any(e.get_option("exchange_error") for e in self.keep[0])
 
     def run(self, parts):
-        """parts: `lanes` tensors [batch,49,40] -> list of [n_heads, batch, 3] (views of the static outputs)."""
+        """parts: `lanes` tensors [batch,49,40] -> list of [n_heads, batch, 3] (views of the static outputs).  Asynchronous: the results are
+        ordered behind the caller's current stream, like any other launch on it."""
+        import torch
         if self.exchange_failed():
             # an earlier replay ran a failed pair / cluster exchange (its results were NaN): the captured launches would poison every
-            # later batch too.  Heal the handles (eager pass) and capture again -- the new graph holds the single-workgroup kernels
+            # later batch too.  Heal the handles (eager pass) and capture again -- the new graphs hold the single-workgroup kernels
             self._capture()
             self.heals += 1
-        for dst, src in zip(self.specs, parts):
-            dst.copy_(src)
-        self.graph.replay()
+        if self.lanes == 1:
+            self.specs[0].copy_(parts[0])
+            self.graphs[0].replay()
+            return self.probs
+        main = torch.cuda.current_stream(self.owner.device)
+        for i in range(self.lanes):                                  # fork: lane i starts where the caller's stream is now (its input is ready there) ...
+            self.side[i].wait_stream(main)
+            with torch.cuda.stream(self.side[i]):
+                self.specs[i].copy_(parts[i])
+                self.graphs[i].replay()
+        for i in range(self.lanes):                                  # ... and the caller's stream continues behind every lane
+            main.wait_stream(self.side[i])
         return self.probs
 
+    def run_all(self, specs, nfull, tail=None):
+        """The first `nfull` FULL batches of specs [windows, 49, 40] -> [n_heads, nfull * batch, 3] on the caller's stream.  Batch j runs on lane
+        j % lanes; a lane works through its batches back to back on its own stream (copy in, replay, copy out) and the caller's stream joins the
+        lanes ONCE, after `tail()` (the eager pass over a ragged last batch, which so runs beside the lanes).  A join after every round of
+        `lanes` batches costs a third of the throughput: the lanes drift apart and every round then waits for its slowest (0.99 -> 1.34 ms per
+        4 x 256 clips, profiles/r06_notes.md section 8)."""
+        import torch
+        if self.exchange_failed():
+            self._capture()
+            self.heals += 1
+        bw = self.specs[0].shape[0]
+        dev = self.owner.device
+        out = torch.empty((len(self.keep[1]), nfull * bw, 3), dtype=torch.float32, device=dev)       # the caller's stream owns the result
+        main = torch.cuda.current_stream(dev)
+        if self.lanes == 1:
+            for j in range(nfull):
+                self.specs[0].copy_(specs[j * bw:(j + 1) * bw])
+                self.graphs[0].replay()
+                out[:, j * bw:(j + 1) * bw].copy_(self.probs[0])
+            return out, (tail() if tail is not None else None)
+        for i in range(min(self.lanes, nfull)):
+            self.side[i].wait_stream(main)
+        for j in range(nfull):                                        # issued round-robin so that every lane has work queued early
+            i = j % self.lanes
+            with torch.cuda.stream(self.side[i]):
+                self.specs[i].copy_(specs[j * bw:(j + 1) * bw])
+                self.graphs[i].replay()
+                out[:, j * bw:(j + 1) * bw].copy_(self.probs[i])
+        t = tail() if tail is not None else None
+        for i in range(min(self.lanes, nfull)):
+            main.wait_stream(self.side[i])
+        return out, t
 
-SERVING_LANES = 4      # concurrent batches per graph replay in streaming_inferences
+
+SERVING_LANES = 4      # batches in flight side by side in serve_spectrograms / streaming_inferences (at most: see lane_budget)
+
+
+def lane_budget(batch, device=None):
+    """How many lanes of `batch` clips may run side by side.  The paired kernels of the 2x2-image blocks hold their CU while they wait for their
+    partner workgroup (include/mkws.h, failure contract): all lanes' pairs TOGETHER must fit the chip -- 2 workgroups per 8 clips -- or halves
+    of different lanes can fill the CUs their partners are waiting for (six lanes of 256 clips: 384 such workgroups for 256 CUs measured 23 ms
+    per 2950 windows instead of 3.7, every wait running into the kernels' timeout; profiles/r06_notes.md section 8)."""
+    import torch
+    cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    return max(1, cus // (2 * ((int(batch) + 7) // 8)))
+
+
+def serve_spectrograms(emb_model, heads, specs, batch_windows=4096, use_graph=True, graphs_used=None):
+    """CUDA spectrograms [windows, 49, 40] -> CUDA softmax outputs [n_heads, windows, 3]: the embedding in batches of
+    min(batch_windows, max_batch) windows, every head on every batch.  Asynchronous on the caller's current stream (no host copy, no
+    synchronisation): what streaming_inferences runs per chunk and what `bench.py --config stream` times."""
+    import torch
+    from ..head import Head
+    bw = min(batch_windows, emb_model.max_batch)
+    nwin = specs.shape[0]
+    nfull = nwin // bw if (use_graph and tuple(specs.shape[1:]) == (49, 40)) else 0
+
+    def eager_from(s0):                                       # launch by launch on the caller's own handle: [N, windows, 3] per batch
+        return [Head.forward_many(heads, emb_model.forward(specs[s:s + bw])) for s in range(s0, nwin, bw)]
+    if nfull == 0:
+        parts = eager_from(0)
+        return torch.cat(parts, dim=1) if parts else torch.zeros((len(heads), 0, 3), dtype=torch.float32, device=emb_model.device)
+    # full batches replay captured graphs, up to SERVING_LANES of them side by side (see _BatchGraph); one lane = the same launches on
+    # the same plan as the eager path, bit for bit; several lanes = the workgroup shapes of the clips they hold together
+    # (the cluster kernel of small handles spins on up to 14 co-resident members per launch: concurrent lanes could starve
+    # each other of CUs, include/mkws.h -- such handles replay one batch at a time)
+    lanes = 1 if emb_model.get_option("fuse_cluster") else min(SERVING_LANES, nfull, lane_budget(bw, emb_model.device))
+    if lanes > 1:
+        lanes = len(concurrent_streams(lanes, emb_model.device))     # (fewer when the runtime has fewer hardware queues to give)
+    bg = _BatchGraph.get(emb_model, heads, bw, lanes)
+    if graphs_used is not None:
+        graphs_used.setdefault(bg, bg.heals)
+    full, rest = bg.run_all(specs, nfull, (lambda: eager_from(nfull * bw)) if nfull * bw < nwin else None)
+    return torch.cat([full] + list(rest), dim=1) if rest else full
 
 
 def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_duration_ms=1000, clip_stride_ms=20,
@@ -187,29 +278,9 @@ def streaming_inferences(models, model_settings, audio, sample_rate=16000, clip_
     for chunk in chunk_audio(audio_arr, max_chunk):
         specs = stream_spectrograms(model_settings, chunk, clip, stride)
         heads = [m.head for m in mlist]
-        bw = min(batch_windows, emb_model.max_batch)
-        nfull = specs.shape[0] // bw if (use_graph and tuple(specs.shape[1:]) == (49, 40)) else 0
-        s = 0
-        while s < specs.shape[0]:
-            left = nfull - s // bw
-            if left > 0:
-                # full batches replay a captured graph, up to SERVING_LANES of them concurrently (see _BatchGraph); same launches on
-                # the same plan as the eager path, so the results equal it bit for bit
-                # (the cluster kernel of small handles spins on up to 14 co-resident members per launch: concurrent lanes could starve
-                # each other of CUs, include/mkws.h -- such handles replay one batch at a time)
-                lanes = 1 if emb_model.get_option("fuse_cluster") else min(SERVING_LANES, left)
-                bg = _BatchGraph.get(emb_model, heads, bw, lanes)
-                graphs_used.setdefault(bg, bg.heals)
-                got = bg.run([specs[s + i * bw:s + (i + 1) * bw] for i in range(lanes)])
-                for probs in got:
-                    for k in range(len(mlist)):
-                        outs[k].append(probs[k].clone())
-                s += lanes * bw
-            else:
-                probs = Head.forward_many(heads, emb_model.forward(specs[s:s + bw]))     # ragged tail: [N, windows, 3] in one launch
-                for k in range(len(mlist)):
-                    outs[k].append(probs[k])
-                s += bw
+        probs = serve_spectrograms(emb_model, heads, specs, batch_windows, use_graph, graphs_used)
+        for k in range(len(mlist)):
+            outs[k].append(probs[k])
     if graphs_used:
         # a failed exchange inside a replay leaves NaN rows and no return code: look at the handles once everything has run, and redo
         # the stream on the healed handles (the first run() of the repeat re-captures; a healed handle cannot fail again).  A heal in

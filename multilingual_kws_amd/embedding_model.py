@@ -41,6 +41,15 @@ class EmbeddingModel:
             self._replicas.append(EmbeddingModel(self._blob, self.max_batch, self.device, self.output))
         return [self] + self._replicas[:n - 1]
 
+    def serving_lanes(self, n, plan_batch):
+        """n handles for n batches in flight on n streams -- replicas only, never `self`: they run the PLAN of `plan_batch` clips (the clips the
+        lanes hold together; option "plan_batch", include/mkws.h), which would slow down a lone eager call on the caller's own handle."""
+        lanes = self.replicas(n + 1)[1:]
+        for r in lanes:
+            if r.get_option("plan_batch") != max(plan_batch, r.max_batch):
+                r.set_option("plan_batch", max(plan_batch, r.max_batch))
+        return lanes
+
     def close(self):
         for r in getattr(self, "_replicas", []):
             r.close()

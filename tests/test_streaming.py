@@ -214,22 +214,22 @@ def test_graph_serving_recovers_from_a_failed_exchange(batch, tmp_path):
     ref = bsa.streaming_inferences(models2, ms, audio, batch_windows=min(batch, 32))
     for e in emb2.replicas(1 if emb2.get_option("fuse_cluster") else bsa.SERVING_LANES):
         e.set_option("fuse_pair", 1)
-    orig_run, state = bsa._BatchGraph.run, {"calls": 0}
+    orig_run, state = bsa._BatchGraph.run_all, {"calls": 0}
 
-    def run_then_fail(self, parts):                             # the exchange "fails" after the first replay of the stream
-        out = orig_run(self, parts)
+    def run_then_fail(self, *args):                             # the exchange "fails" after the first chunk's replays
+        out = orig_run(self, *args)
         state["calls"] += 1
         if state["calls"] == 1:
-            emb2.set_option("inject_exchange_error", 1)
+            self.keep[0][0].set_option("inject_exchange_error", 1)   # (lane 0: the caller's handle, or its first serving replica)
         return out
-    bsa._BatchGraph.run = run_then_fail
+    bsa._BatchGraph.run_all = run_then_fail
     try:
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             got = bsa.streaming_inferences(models2, ms, audio, batch_windows=min(batch, 32))
     finally:
-        bsa._BatchGraph.run = orig_run
-    assert emb2.get_option("exchange_error") == 0 and emb2.get_option("pair_degraded") == 1
+        bsa._BatchGraph.run_all = orig_run
+    assert emb2.get_option("exchange_error") == 0 and sum(e.get_option("pair_degraded") for e in [emb2] + list(emb2._replicas)) == 1
     assert any("repeating the stream" in str(x.message) for x in w)
     for r, g in zip(ref, got):
         assert np.isfinite(g).all() and np.allclose(g, r, rtol=1e-4, atol=1e-6) and np.array_equal(g.argmax(1), r.argmax(1))
@@ -253,13 +253,13 @@ def test_offline_stream_raises_when_the_repeat_fails_too(tmp_path):
     pcm = np.concatenate([tone_clip(500 + 200 * k, rng, n=8000) for k in range(8)])
     audio = pcm.astype(np.float32) / 32768
     ref = bsa.streaming_inferences(models, ms, audio, batch_windows=32)
-    orig_run = bsa._BatchGraph.run
+    orig_run = bsa._BatchGraph.run_all
 
-    def always_fail(self, parts):                               # every replay leaves the error word set, as a failed exchange would
-        out = orig_run(self, parts)
+    def always_fail(self, *args):                               # every chunk's replays leave the error word set, as a failed exchange would
+        out = orig_run(self, *args)
         self.keep[0][0].set_option("inject_exchange_error", 1)
         return out
-    bsa._BatchGraph.run = always_fail
+    bsa._BatchGraph.run_all = always_fail
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
@@ -267,7 +267,7 @@ def test_offline_stream_raises_when_the_repeat_fails_too(tmp_path):
                 bsa.streaming_inferences(models, ms, audio, batch_windows=32)
         assert ei.value.code == _lib.MKWS_ERR_EXCHANGE
     finally:
-        bsa._BatchGraph.run = orig_run
+        bsa._BatchGraph.run_all = orig_run
     # every handle of the stream left the exchange kernels before the repeat; the stream runs clean again afterwards
     reps = [emb] + list(emb._replicas)
     assert all(e.get_option("fuse_pair") == 0 and e.get_option("fuse_cluster") == 0 for e in reps)
@@ -277,3 +277,35 @@ def test_offline_stream_raises_when_the_repeat_fails_too(tmp_path):
     again = bsa.streaming_inferences(models, ms, audio, batch_windows=32)
     for r, g in zip(ref, again):
         assert np.isfinite(g).all() and np.allclose(g, r, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_serving_lanes_run_side_by_side_and_agree_with_the_eager_path(monkeypatch):
+    """serve_spectrograms with several lanes: every full batch on a replica handle with the workgroup shapes of lanes x batch clips (option
+    "plan_batch"), one captured graph per lane on its own stream, ONE join per call, the ragged tail launched eagerly beside the lanes.  The
+    result must be the eager path's up to the round-off between workgroup shapes (labels exact), equal from call to call, and -- with one lane,
+    i.e. the caller's own handle and plan -- equal to the eager path bit for bit.  The caller's handle keeps its own plan."""
+    torch = pytest.importorskip("torch")
+    from multilingual_kws_amd.embedding import transfer_learning as tl
+    from multilingual_kws_amd.head import Head
+    emb, _ = tl.load_base_model("synthetic", max_batch=256)
+    heads = [Head(max_batch=256, seed=40 + s) for s in range(3)]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    specs = (torch.rand((5 * 256 + 77, 49, 40), generator=g) * 26).cuda()
+    ref = bsa.serve_spectrograms(emb, heads, specs, 256, use_graph=False)
+    assert tuple(ref.shape) == (3, 5 * 256 + 77, 3)
+    monkeypatch.setattr(bsa, "SERVING_LANES", 4)
+    got = bsa.serve_spectrograms(emb, heads, specs, 256).clone()
+    again = bsa.serve_spectrograms(emb, heads, specs, 256)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6) and torch.equal(got.argmax(-1), ref.argmax(-1))
+    assert torch.equal(got[:, 5 * 256:], ref[:, 5 * 256:])                    # the ragged tail ran on the caller's handle
+    assert emb.get_option("plan_batch") == 256 and len(emb._replicas) == 4
+    assert all(r.get_option("plan_batch") == 1024 and r.get_option("block_tiles") == 3 for r in emb._replicas)
+    monkeypatch.setattr(bsa, "SERVING_LANES", 1)
+    one = bsa.serve_spectrograms(emb, heads, specs, 256)
+    torch.cuda.synchronize()
+    assert torch.equal(one, ref)
+    with pytest.raises(Exception):
+        emb.set_option("plan_batch", 128)                                     # below max_batch
