@@ -200,6 +200,10 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *   "fuse_gemv" (default 1): handles planned for at most 4 rows (live serving: max_batch <= 4 for the dense layers, a one-clip handle for the
  *                 top conv + pool) run those layers as matrix-vector products, ONE launch per layer (a 16-wave workgroup per 16-column tile,
  *                 K split over its waves, partial columns folded in LDS in a fixed order); 0 = the MFMA GEMM + split-K fold launches.
+ *   "fuse_se4" (default 1): the 4x3-image blocks (4b..6a, whole-block and chain kernels) run their squeeze-excite FCs on the 4x4x1 matrix
+ *                 instruction -- a workgroup's 4 clips are exactly its N -- and the lanes that compute a gate multiply the clip's depthwise rows
+ *                 by it on the spot (no gate buffer, no gate pass); 0 = the 16x16x4 weight streams (clips = 4 of 16 columns) + a gate pass.
+ *                 Another summation order inside the two FCs: results agree at fp32 round-off (1e-6 of the block outputs), bit-identical per setting.
  *   "fuse_walk" (default 1): block 2a's expand + depthwise kernel runs ONE workgroup per clip that walks the clip's three 32-channel blocks
  *                 (the input is read from HBM once); 0 = one workgroup per (clip, channel block).  Bit-identical either way.
  *   "block_tiles" (set: 0 = the rule of the handle's max_batch, 1 / 2 / 3 = one / two / four clips per workgroup; get: the value in force):

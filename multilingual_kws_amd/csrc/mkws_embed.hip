@@ -1774,10 +1774,114 @@ struct BlockArgs {
   float* Y; int Cout; int residual;
   float* dbg_dw; float* dbg_gate;
   int B, Cexp, se;
+  // squeeze-excite on the 4x4x1 matrix instruction (4x3-image blocks, see Se4 below): null / 0 = the 16x16x4 streams above
+  const float* WrQ; const float* We2Q; int seT0, seNQ;
 #ifdef MKWS_FRONT_TIMING
   unsigned long long* dbg_t;
 #endif
 };
+
+// ------------------------------------------------------------------------------------------------
+// Squeeze-excite FCs of a 4x3-image workgroup on v_mfma_f32_4x4x1_16b_f32 (round 6).
+// A workgroup holds G <= 4 clips, so both FCs are [4 x K] . [K x N] products.  On the 16x16x4 instruction the clips were 4 of 16 columns
+// (and a 20 / 28-unit reduce FC 2 of 3 streamed tiles): 72 + 48 MFMAs per wave and block at 1 / 6 and 1 / 4 of their work useful -- 2 us of
+// matrix issue per SIMD in C1 alone, which nothing overlaps (an fp32 MFMA blocks its SIMD's vector issue: tools/microbench/issue_costs.hip).
+// The 4x4x1 form is 16 independent 4x4 outer products per instruction (lane l = 4 blk + r: A = a(i = r, blk), B = b(j = r, blk),
+// D VGPR v = d(i = v, j = r, blk); checked by tools/microbench/mfma_4x4.hip, 5.1 ns per instruction) with j = the clip:
+//   C1 (reduce)  i = 4 SE units, blocks = 8 unit groups x 2 channel halves: one instruction = 2 channels x 32 units x 4 clips.  Wave w owns channels
+//                [w cpw, (w + 1) cpw), cpw = Cexp / 8; its lanes 32..63 (half 1) take the LAST T0 = 4 ceil(cpw / 8) of them, lanes 0..31 the first
+//                cpw - T0 (their last T0 - (cpw - T0) instructions multiply zero weights against the other half's means).  A comes from WrQ
+//                [wave][T0 / 4][lane][4] (the lane's weights of four consecutive instructions in one dwordx4), B from the means in LDS
+//                (a float4 = four consecutive channels of clip l & 3).  32 / 44 instructions per wave for Cexp = 480 / 672 (was 72 x 14 ns).
+//                Halves are added through ds_bpermute (half 0 + half 1), waves through LDS in wave order: a fixed order.
+//   C2 (expand)  i = 4 channels, blocks = 16 channel quads: one instruction = 64 channels x 4 clips x 1 unit, A from We2Q
+//                [group of 64 channels][ceil(se / 4)][lane][4], B = r[clip][unit] from LDS.  The lane that ends up with the gate of channels
+//                4 blk .. + 3 of clip j multiplies the clip's HoWo depthwise rows by it on the spot: the gate never goes to LDS and the
+//                separate gate pass (a phase and a barrier of 1.9-2.6 us per block) is gone.
+// Both kernels that run these blocks (mbconv_block_kernel, mbconv_chain_kernel's chain_block) call the same functions: bit-identical.
+constexpr int kSe4MaxTQ = 11, kSe4MaxNQ = 7, kSe4MaxGroups = 2;
+__device__ __forceinline__ f32x4 mfma4x4_(const f32x4& a, const f32x4& b, f32x4 acc) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], b[e], acc, 0, 0, 0);
+  return acc;
+}
+// requests wave `wave`'s reduce weights.  The packing is padded with zero weights to kSe4MaxTQ dwordx4 per lane whatever T0 is, and the
+// loops below run that fixed count (straight-line code: a bound taken from the block table made every step its own basic block with its
+// own s_waitcnt); the padding steps multiply zero weights against the slice's last four means (address clamped: finite).
+__device__ __forceinline__ void se4_request_c1(f32x4 (&wq)[kSe4MaxTQ], const float* WrQ, int wave, int lane) {
+  const WBuf w(WrQ + (size_t)wave * kSe4MaxTQ * 256, (unsigned)lane * 4u);
+#pragma unroll
+  for (int q = 0; q < kSe4MaxTQ; ++q) wq[q] = w.ld((size_t)q * 256);
+}
+// partial r[clip][unit] of this wave's channels -> s_P[wave][G][32]
+template <int G, int NWAVES>
+__device__ __forceinline__ void se4_c1(const f32x4 (&wq)[kSe4MaxTQ], int T0, int Cexp, const float* s_S, float* s_P, int wave, int lane) {
+  const int TQ = T0 >> 2, cpw = Cexp / NWAVES;
+  const int j = lane & 3, ug = (lane >> 2) & 7, kh = lane >> 5;
+  const float* mrow = s_S + (size_t)(j < G ? j : G - 1) * Cexp + wave * cpw + (kh ? cpw - T0 : 0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < kSe4MaxTQ; ++q) acc = mfma4x4_(wq[q], *reinterpret_cast<const f32x4*>(mrow + 4 * (q < TQ ? q : TQ - 1)), acc);
+  // the other half's partial, component by component through named scalars: hipcc (ROCm 7.2) folds the loop form
+  // `other[r] = bit_cast<float>(ds_bpermute(idx, bit_cast<int>(acc[r])))` into ONE ds_bpermute of acc[0] that feeds all four components
+  // (units 4 ug + 1..3 wrong, unit 4 ug right: tools/microbench/se4_unit.hip found it)
+  const int px = (lane ^ 32) << 2;
+  const float a0 = acc.x, a1 = acc.y, a2 = acc.z, a3 = acc.w;
+  f32x4 other;
+  other.x = __int_as_float(__builtin_amdgcn_ds_bpermute(px, __float_as_int(a0)));
+  other.y = __int_as_float(__builtin_amdgcn_ds_bpermute(px, __float_as_int(a1)));
+  other.z = __int_as_float(__builtin_amdgcn_ds_bpermute(px, __float_as_int(a2)));
+  other.w = __int_as_float(__builtin_amdgcn_ds_bpermute(px, __float_as_int(a3)));
+  if (lane < 32 && j < G) *reinterpret_cast<f32x4*>(s_P + ((size_t)(wave * G + j) * 32 + 4 * ug)) = acc + other;
+}
+// r[clip][unit] = swish(sum over waves + br) -> s_R[clip][LDR]; thread = (clip, unit); br_pre = this thread's bias (0 past se)
+template <int G, int NWAVES, int LDR>
+__device__ __forceinline__ void se4_fold(const float* s_P, float* s_R, int se, float br_pre, int tid) {
+  if (tid < 32 * G) {
+    const int clip = tid >> 5, n = tid & 31;
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) v += s_P[(size_t)(w * G + clip) * 32 + n];
+    s_R[clip * LDR + n] = (n < se) ? swishf_(v + br_pre) : 0.0f;
+  }
+}
+// requests the expand weights of this wave's channel groups (wave, wave + NWAVES); kSe4MaxNQ dwordx4 per lane and group, zero padded like the reduce weights
+template <int NWAVES>
+__device__ __forceinline__ void se4_request_c2(f32x4 (&wq)[kSe4MaxGroups][kSe4MaxNQ], const float* We2Q, int Cexp, int wave, int lane) {
+  const int NG = (Cexp + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < kSe4MaxGroups; ++k) {
+    const int gq = wave + k * NWAVES;
+    const WBuf w(We2Q + (size_t)(gq < NG ? gq : NG - 1) * kSe4MaxNQ * 256, (unsigned)lane * 4u);
+#pragma unroll
+    for (int q = 0; q < kSe4MaxNQ; ++q) wq[k][q] = w.ld((size_t)q * 256);
+  }
+}
+// gate = sigmoid(r . We2 + be) for this wave's channel groups, applied to the clips' depthwise rows in place (rows clip * HW + o, o < HoWo)
+template <int G, int HW, int HoWo, int NWAVES, int LDR>
+__device__ __forceinline__ void se4_c2_gate(const f32x4 (&wq)[kSe4MaxGroups][kSe4MaxNQ], int Cexp, const float* s_R, const float* s_be, float* s_E,
+                                            int wave, int lane, float* dbg_gate_clip0, int gvalid) {
+  const int NG = (Cexp + 63) >> 6, LDE = Cexp + 4;
+  const int j = lane & 3;
+  f32x4 rb[kSe4MaxNQ];
+#pragma unroll
+  for (int q = 0; q < kSe4MaxNQ; ++q) rb[q] = *reinterpret_cast<const f32x4*>(s_R + (j < G ? j : 0) * LDR + 4 * q);      // (units < 28: written by the fold)
+#pragma unroll
+  for (int k = 0; k < kSe4MaxGroups; ++k) {
+    const int gq = wave + k * NWAVES;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < kSe4MaxNQ; ++q) acc = mfma4x4_(wq[k][q], rb[q], acc);
+    const int ch = 64 * gq + 4 * (lane >> 2);
+    if (gq < NG && j < G && ch < Cexp) {
+      const f32x4 y = sigmoid4_(acc + *reinterpret_cast<const f32x4*>(s_be + ch));
+      float* e0 = s_E + (size_t)(j * HW) * LDE + ch;
+#pragma unroll
+      for (int o = 0; o < HoWo; ++o) *reinterpret_cast<f32x4*>(e0 + (size_t)o * LDE) = *reinterpret_cast<const f32x4*>(e0 + (size_t)o * LDE) * y;
+      if (dbg_gate_clip0 && j < gvalid) *reinterpret_cast<f32x4*>(dbg_gate_clip0 + (size_t)j * Cexp + ch) = y;
+    }
+  }
+}
 
 // Flattened variant of stream_mfma for MANY short accumulation runs (phase A, SE expand): run r = tiles
 // [tile_of(r), +NTW), each KC chunks long.  The weight ring keeps DEPTH chunks in flight ACROSS runs, so a
@@ -2010,7 +2114,16 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   const int c1_kc = (c1_j0 + c1_per <= KCx) ? c1_per : (KCx > c1_j0 ? KCx - c1_j0 : 0);
   const WBuf c1_w(a.WrP + (size_t)c1_j0 * a.NTR * 256, loff);
   f32x4 wq1[3][3];
-  stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  // 4x3 images: squeeze-excite on the 4x4x1 instruction when the block carries that packing (Se4 above; same calls as chain_block: bit-identical)
+  constexpr bool kSe4 = (HW == 12);
+  const bool se4 = kSe4 && a.WrQ != nullptr;
+  constexpr bool kWq4Early = (KS == 3);                        // (5x5: behind the depthwise loop, whose 12 + 12 + 25 float4 leave no room for 11 more)
+  f32x4 wq4[kSe4 ? kSe4MaxTQ : 1];
+  if (se4) {
+    if constexpr (kSe4 && kWq4Early) se4_request_c1(wq4, a.WrQ, wave, lane);
+  } else {
+    stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  }
   {
     const int Q = Cexp / 4;
     for (int task = tid; task < G * Q; task += NTHR) {
@@ -2060,6 +2173,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
       *reinterpret_cast<f32x4*>(s_S + (size_t)gi * Cexp + q4) = ssum * (1.0f / (float)HoWo);
     }
   }
+  if constexpr (kSe4 && !kWq4Early) {
+    if (se4) se4_request_c1(wq4, a.WrQ, wave, lane);
+  }
   __syncthreads();
 
 #ifdef MKWS_FRONT_TIMING
@@ -2071,35 +2187,47 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
   auto c2_tile_of = [&](int r) { return (wave + NWAVES * r) * NTW2; };
   f32x4 wq2[3][NTW2];
-  {
-    f32x4 acc[3][1];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* srow = s_S + (size_t)(c < G ? c : 0) * Cexp + 16 * c1_j0 + 4 * g;      // columns c >= G are don't-care
-    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
-    auto xmake = [](const f32x4& v) { return v; };
-    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
-    stream_mfma_runs_prefetch<NTW2, 3>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);   // C2's stream
-    if (c < G) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+  f32x4 wg4[kSe4 ? kSe4MaxGroups : 1][kSe4 ? kSe4MaxNQ : 1];
+  if (se4) {
+    if constexpr (kSe4) {
+      se4_c1<G, NWAVES>(wq4, a.seT0, Cexp, s_S, s_P, wave, lane);
+      se4_request_c2<NWAVES>(wg4, a.We2Q, Cexp, wave, lane);
+      const float br4 = (tid < 32 * G && (tid & 31) < a.se) ? a.br[tid & 31] : 0.0f;
+      __syncthreads();
+      se4_fold<G, NWAVES, LDR>(s_P, s_R, a.se, br4, tid);
+      __syncthreads();
     }
-  }
-  const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;     // requested before the barrier (48*G <= NTHR)
-  __syncthreads();
-  for (int t = tid; t < 48 * G; t += NTHR) {
-    const int n = t / G, clip = t - n * G;
-    float v = 0.0f;
-    if (n < a.se) {
-#pragma unroll
-      for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * G + clip];
-      v = swishf_(v + br_pre);
+  } else {
+    {
+      f32x4 acc[3][1];
+  #pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* srow = s_S + (size_t)(c < G ? c : 0) * Cexp + 16 * c1_j0 + 4 * g;      // columns c >= G are don't-care
+      auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
+      auto xmake = [](const f32x4& v) { return v; };
+      if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
+      stream_mfma_runs_prefetch<NTW2, 3>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);   // C2's stream
+      if (c < G) {
+  #pragma unroll
+        for (int q = 0; q < 3; ++q)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+      }
     }
-    s_R[clip * LDR + n] = v;
+    const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;     // requested before the barrier (48*G <= NTHR)
+    __syncthreads();
+    for (int t = tid; t < 48 * G; t += NTHR) {
+      const int n = t / G, clip = t - n * G;
+      float v = 0.0f;
+      if (n < a.se) {
+  #pragma unroll
+        for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * G + clip];
+        v = swishf_(v + br_pre);
+      }
+      s_R[clip * LDR + n] = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 #ifdef MKWS_FRONT_TIMING
   if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
 #endif
@@ -2114,41 +2242,51 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   const WBuf d_w(a.WpP, loff);
   f32x4 wqd[4][3];
   if (d_ntw > 0 || d_row >= 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);   // (tiles past NTp clamp to the last one)
-  {
-    const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
-    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
-    auto xmake = [](const f32x4& v) { return v; };
-    auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
-#pragma unroll
-      for (int q = 0; q < NTW2; ++q) {
-        const int n = (t0 + q) * 16 + 4 * g;
-        if (t0 + q < KCx && c < G) {
-          f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
-          y = sigmoid4_(y);
-          *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
-          if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + n) = y;
-        }
-      }
-    };
-    stream_mfma_runs<NTW2, 3, 1, true>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
-  }
-  __syncthreads();
-
+  if (se4) {
+    if constexpr (kSe4) {
+      se4_c2_gate<G, HW, HoWo, NWAVES, LDR>(wg4, Cexp, s_R, s_be, s_E, wave, lane, a.dbg_gate ? a.dbg_gate + (size_t)b0 * Cexp : nullptr, gvalid);
+      __syncthreads();
 #ifdef MKWS_FRONT_TIMING
-  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
+      if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
 #endif
-  // ---- gate the depthwise output in place, once: phase D then reads ONE operand fragment per row tile and chunk
-  //      (the gate as a second LDS operand plus a multiply per fragment cost the projection's MFMA issue) ----
-  {
-    const int Q = Cexp / 4;
-    for (int i = tid; i < G * HoWo * Q; i += NTHR) {
-      const int ro = i / Q, q4 = (i - ro * Q) * 4;
-      const int clip = ro / HoWo;
-      float* e = s_E + (size_t)(clip * HW + (ro - clip * HoWo)) * LDE + q4;
-      *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)clip * Cexp + q4);
     }
+  } else {
+    {
+      const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
+      auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+      auto xmake = [](const f32x4& v) { return v; };
+      auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
+  #pragma unroll
+        for (int q = 0; q < NTW2; ++q) {
+          const int n = (t0 + q) * 16 + 4 * g;
+          if (t0 + q < KCx && c < G) {
+            f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
+            y = sigmoid4_(y);
+            *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
+            if (a.dbg_gate && c < gvalid) *reinterpret_cast<f32x4*>(a.dbg_gate + (size_t)(b0 + c) * Cexp + n) = y;
+          }
+        }
+      };
+      stream_mfma_runs<NTW2, 3, 1, true>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
+    }
+    __syncthreads();
+
+  #ifdef MKWS_FRONT_TIMING
+    if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
+  #endif
+    // ---- gate the depthwise output in place, once: phase D then reads ONE operand fragment per row tile and chunk
+    //      (the gate as a second LDS operand plus a multiply per fragment cost the projection's MFMA issue) ----
+    {
+      const int Q = Cexp / 4;
+      for (int i = tid; i < G * HoWo * Q; i += NTHR) {
+        const int ro = i / Q, q4 = (i - ro * Q) * 4;
+        const int clip = ro / HoWo;
+        float* e = s_E + (size_t)(clip * HW + (ro - clip * HoWo)) * LDE + q4;
+        *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)clip * Cexp + q4);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // ---- phase D: gated project (+ residual): output row r = 16m + c lives in E row (r / HoWo)*HW + r % HoWo ----
   {
     const size_t cstride = (size_t)a.NTp * 256;
@@ -2237,6 +2375,7 @@ struct ChainArgs {
   const float* X; float* Y;   // the chain's input and its last block's output
   int B;
   int ldsU, ldsE;             // LDS carve in floats, the maximum over the chain's blocks (Z follows E)
+  int se4;                    // 0: squeeze-excite on the 16x16x4 streams even where the table holds 4x4x1 weights (option "fuse_se4" = 0)
 #ifdef MKWS_FRONT_TIMING
   unsigned long long* dbg_t;  // [workgroups][kChainMax][8] wall_clock64 stamps
 #endif
@@ -2265,6 +2404,7 @@ __device__ __forceinline__ BlockArgs sgpr_block_args(const BlockArgs& t) {
   a.Y = nullptr; a.Cout = sgpr_(t.Cout); a.residual = sgpr_(t.residual);
   a.dbg_dw = nullptr; a.dbg_gate = nullptr;
   a.B = 0; a.Cexp = sgpr_(t.Cexp); a.se = sgpr_(t.se);
+  a.WrQ = sgpr_(t.WrQ); a.We2Q = sgpr_(t.We2Q); a.seT0 = sgpr_(t.seT0); a.seNQ = sgpr_(t.seNQ);
 #ifdef MKWS_FRONT_TIMING
   a.dbg_t = nullptr;
 #endif
@@ -2354,7 +2494,12 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   // (5x5: a thread holds 12 inputs + 12 outputs + 25 taps -- 196 registers; C1's ring is requested behind the depthwise loop there,
   // where waves that own one round of tasks wait for those that own two)
   constexpr bool kWq1Early = (KS == 3);                        // (requested in front of the 5x5 depthwise as well: measured, no difference)
-  if (kWq1Early) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  const bool se4 = a.WrQ != nullptr;                           // squeeze-excite on the 4x4x1 instruction (Se4 above); uniform
+  f32x4 wq4[kSe4MaxTQ];
+  if (kWq1Early) {
+    if (se4) se4_request_c1(wq4, a.WrQ, wave, lane);
+    else stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  }
   {
     const int Q = Cexp / 4;
     for (int task = tid; task < G * Q; task += NTHR) {
@@ -2421,7 +2566,10 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
       *reinterpret_cast<f32x4*>(s_S + (size_t)gi * Cexp + q4) = ssum * (1.0f / (float)HoWo);
     }
   }
-  if (!kWq1Early) stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  if (!kWq1Early) {
+    if (se4) se4_request_c1(wq4, a.WrQ, wave, lane);
+    else stream_mfma_prefetch<3, 3>(wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc);
+  }
   __syncthreads();
 
 #ifdef MKWS_FRONT_TIMING
@@ -2445,36 +2593,46 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   const int c2_runs = (c2_groups > wave) ? (c2_groups - wave + NWAVES - 1) / NWAVES : 0;
   auto c2_tile_of = [&](int r) { return (wave + NWAVES * r) * NTW2; };
   f32x4 wq2[3][NTW2];
-  {
-    f32x4 acc[3][1];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* srow = s_S + (size_t)(c < G ? c : 0) * Cexp + 16 * c1_j0 + 4 * g;
-    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
-    auto xmake = [](const f32x4& v) { return v; };
-    if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
-    stream_mfma_runs_prefetch<NTW2, 3>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);
-    if (c < G) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+  f32x4 wg4[kSe4MaxGroups][kSe4MaxNQ];
+  if (se4) {
+    se4_c1<G, NWAVES>(wq4, a.seT0, Cexp, s_S, s_P, wave, lane);
+    se4_request_c2<NWAVES>(wg4, a.We2Q, Cexp, wave, lane);                     // C2's weights: in flight across the fold
+    const float br4 = (tid < 32 * G && (tid & 31) < a.se) ? a.br[tid & 31] : 0.0f;
+    __syncthreads();
+    se4_fold<G, NWAVES, LDR>(s_P, s_R, a.se, br4, tid);
+    __syncthreads();
+  } else {
+    {
+      f32x4 acc[3][1];
+  #pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* srow = s_S + (size_t)(c < G ? c : 0) * Cexp + 16 * c1_j0 + 4 * g;
+      auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(srow + 16 * j); };
+      auto xmake = [](const f32x4& v) { return v; };
+      if (c1_kc > 0) stream_mfma<3, 3, 1, true>(acc, wq1, c1_w, (size_t)a.NTR * 256, 0, 1, a.NTR, c1_kc, xload, xmake);
+      stream_mfma_runs_prefetch<NTW2, 3>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of);
+      if (c < G) {
+  #pragma unroll
+        for (int q = 0; q < 3; ++q)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) s_P[((wave * 3 + q) * 16 + 4 * g + r) * G + c] = acc[q][0][r];
+      }
     }
-  }
-  const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
-  __syncthreads();
-  for (int t = tid; t < 48 * G; t += NTHR) {
-    const int n = t / G, clip = t - n * G;
-    float v = 0.0f;
-    if (n < a.se) {
-#pragma unroll
-      for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * G + clip];
-      v = swishf_(v + br_pre);
+    const float br_pre = (tid < 48 * G && tid / G < a.se) ? a.br[tid / G] : 0.0f;
+    __syncthreads();
+    for (int t = tid; t < 48 * G; t += NTHR) {
+      const int n = t / G, clip = t - n * G;
+      float v = 0.0f;
+      if (n < a.se) {
+  #pragma unroll
+        for (int w = 0; w < NWAVES; ++w) v += s_P[(w * 48 + n) * G + clip];
+        v = swishf_(v + br_pre);
+      }
+      s_R[clip * LDR + n] = v;
     }
-    s_R[clip * LDR + n] = v;
-  }
-  __syncthreads();
+    __syncthreads();
 
+  }
 #ifdef MKWS_FRONT_TIMING
   if (dbg_t && threadIdx.x == 0) dbg_t[3] = wall_clock64();
 #endif
@@ -2485,46 +2643,63 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   const WBuf d_w(a.WpP, loff);
   f32x4 wqd[4][3];
   if (d_ntw > 0 || d_row >= 0) stream_mfma_prefetch<3, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NWAVES, a.NTp, KCx);
-  {
-    const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
-    auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
-    auto xmake = [](const f32x4& v) { return v; };
-    auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
-#pragma unroll
-      for (int q = 0; q < NTW2; ++q) {
-        const int n = (t0 + q) * 16 + 4 * g;
-        if (t0 + q < KCx && c < G) {
-          f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
-          y = sigmoid4_(y);
-          *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
-        }
-      }
-    };
-    stream_mfma_runs<NTW2, 3, 1, true>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
-  }
-  __syncthreads();
-
+  if (se4) {
+    // gate computed and applied by the same lanes (no gate buffer, no gate pass); Z (r, be) is read until the barrier below, so the NEXT block's
+    // expand BN constants go there behind it, in front of phase D's multiply-adds (phase A of the next block reads them behind D's closing barrier)
+    se4_c2_gate<G, HW, HoWo, NWAVES, LDR>(wg4, Cexp, s_R, s_be, s_E, wave, lane, nullptr, gvalid);
+    __syncthreads();
 #ifdef MKWS_FRONT_TIMING
   if (dbg_t && threadIdx.x == 0) dbg_t[4] = wall_clock64();
 #endif
-  // ---- gate the depthwise output in place; the NEXT block's expand BN constants (requested in C1) go to Z, free from here on ----
-  {
-    const int Q = Cexp / 4;
-    for (int i = tid; i < G * HoWo * Q; i += NTHR) {
-      const int ro = i / Q, q4 = (i - ro * Q) * 4;
-      const int clip = ro / HoWo;
-      float* e = s_E + (size_t)(clip * HW + (ro - clip * HoWo)) * LDE + q4;
-      *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)clip * Cexp + q4);
+    if (nx) {
+  #pragma unroll
+      for (int k = 0; k < NCST; ++k) {
+        const int i = tid + k * NTHR;
+        if (i < nxCexp) { s_scE[i] = nsc[k]; s_scE[nxCexp + i] = nsh[k]; }
+      }
     }
-  }
-  if (nx) {
-#pragma unroll
-    for (int k = 0; k < NCST; ++k) {
-      const int i = tid + k * NTHR;
-      if (i < nxCexp) { s_scE[i] = nsc[k]; s_scE[nxCexp + i] = nsh[k]; }
+  } else {
+    {
+      const float* rrow = s_R + (c < G ? c : 0) * LDR + 4 * g;
+      auto xload = [&](int j, int) { return *reinterpret_cast<const f32x4*>(rrow + 16 * j); };
+      auto xmake = [](const f32x4& v) { return v; };
+      auto epi = [&](int t0, const f32x4 (&acc)[NTW2][1]) {
+  #pragma unroll
+        for (int q = 0; q < NTW2; ++q) {
+          const int n = (t0 + q) * 16 + 4 * g;
+          if (t0 + q < KCx && c < G) {
+            f32x4 y = acc[q][0] + *reinterpret_cast<const f32x4*>(s_be + n);
+            y = sigmoid4_(y);
+            *reinterpret_cast<f32x4*>(s_G + (size_t)c * Cexp + n) = y;
+          }
+        }
+      };
+      stream_mfma_runs<NTW2, 3, 1, true>(wq2, WBuf(a.We2P, loff), (size_t)KCx * 256, KCx, c2_runs, a.NTR, c2_tile_of, xload, xmake, epi);
     }
+    __syncthreads();
+
+  #ifdef MKWS_FRONT_TIMING
+    if (dbg_t && threadIdx.x == 0) dbg_t[4] = wall_clock64();
+  #endif
+    // ---- gate the depthwise output in place; the NEXT block's expand BN constants (requested in C1) go to Z, free from here on ----
+    {
+      const int Q = Cexp / 4;
+      for (int i = tid; i < G * HoWo * Q; i += NTHR) {
+        const int ro = i / Q, q4 = (i - ro * Q) * 4;
+        const int clip = ro / HoWo;
+        float* e = s_E + (size_t)(clip * HW + (ro - clip * HoWo)) * LDE + q4;
+        *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) * *reinterpret_cast<const f32x4*>(s_G + (size_t)clip * Cexp + q4);
+      }
+    }
+    if (nx) {
+  #pragma unroll
+      for (int k = 0; k < NCST; ++k) {
+        const int i = tid + k * NTHR;
+        if (i < nxCexp) { s_scE[i] = nsc[k]; s_scE[nxCexp + i] = nsh[k]; }
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
 #ifdef MKWS_FRONT_TIMING
   if (dbg_t && threadIdx.x == 0) dbg_t[5] = wall_clock64();
@@ -2636,6 +2811,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_chain_kernel(ChainArgs ca)
   for (int i = 0; i < ca.n; ++i) {
     BlockArgs a = sgpr_block_args(tab[i]);
     const bool last = (i + 1 == ca.n);
+    if (!ca.se4) a.WrQ = nullptr;
     a.X = ca.X; a.Y = ca.Y; a.B = ca.B;                       // X is read by the first block only (residual), Y written by the last                // ("_dw" / "_gate" taps of a block run mbconv_block_kernel: the launcher ends the chain in front of it)
     const BlockArgs* nxp = last ? tab + i : tab + i + 1;
     const unsigned kind = (ca.kinds >> (2 * i)) & 3u;
@@ -4016,7 +4192,8 @@ struct GemmLayer {   // device pointers into the weight blob
   int K = 0, N = 0, KC = 0, NTtot = 0;
 };
 struct DwLayer { const float* Wd = nullptr; const float* scale = nullptr; const float* shift = nullptr; };
-struct SeLayer { const float* Wr = nullptr; const float* We = nullptr; const float* WrP = nullptr; const float* br = nullptr; const float* WeP = nullptr; const float* be = nullptr; int se = 0, KCr = 0, NTR = 0, NTe = 0; };
+struct SeLayer { const float* Wr = nullptr; const float* We = nullptr; const float* WrP = nullptr; const float* br = nullptr; const float* WeP = nullptr; const float* be = nullptr; int se = 0, KCr = 0, NTR = 0, NTe = 0;
+                 const float* WrQ = nullptr; const float* WeQ = nullptr; int T0 = 0, NQ = 0; };   // 4x4x1-instruction packing (Se4), 4x3-image blocks only
 
 struct BlockPlan {
   MBConvSpec spec;
@@ -4061,6 +4238,7 @@ struct mkws_embed {
   int fuse_back = 1;               // blocks that keep mbconv_front_kernel (2a, 2b, 3b): SE + gated projection in one launch (mbconv_back_kernel)
   int fuse_mid = 1;                // whole-block kernel for big-image blocks (mbconv_mid_kernel): 1 = 2b, 3a and 4a (where it measured faster), 2 = 2a..4a, 3 = 3a and 4a only, 0 = never
   int fuse_gemv = 1;               // handles of at most 4 planned rows (one clip): dense layers and top conv on gemv_kernel (one launch per layer, K split inside the workgroup); 0 = pw_gemm_kernel + split-K fold
+  int fuse_se4 = 1;                // 4x3-image blocks: squeeze-excite FCs on the 4x4x1 matrix instruction + gate applied by the lanes that compute it (Se4); 0 = 16x16x4 streams + gate pass
   int fuse_walk = 1;               // block 2a's front kernel: one workgroup walks the clip's three channel blocks (input read from HBM once); 0 = three workgroups per clip
   int fuse_rows = 0;               // 1 = stride-1 big-image blocks (2b, 3b) on mbconv_rows_kernel (mkws_embed_rows.hip: depthwise output in registers, a wave per row tile); 0 = fuse_mid / front + back decide
   int fuse_block = 2;              // whole MBConv block in one kernel (mbconv_block_kernel): 1 = 2x2 images only, 2 = 2x2 and 4x3
@@ -4523,7 +4701,7 @@ bool block_supported(const BlockPlan& b, int mode) {
   return (ks == 5 && st == 1) || (ks == 3 && st == 1);
 }
 
-int launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B) {
+int launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43, const float* X, float* Y, float* dbg_dw, float* dbg_gate, int B, bool se4 = true) {
   BlockArgs a;
   a.X = X; a.Cin = b.spec.in_ch;
   a.WpE = b.expand.Wp; a.scE = b.expand.scale; a.shE = b.expand.shift; a.KCe = b.expand.KC; a.NTe = b.expand.NTtot;
@@ -4533,6 +4711,7 @@ int launch_block(hipStream_t s, const char* stage, const BlockPlan& b, int mt43,
   a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
   a.dbg_dw = dbg_dw; a.dbg_gate = dbg_gate;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
+  a.WrQ = se4 ? b.se.WrQ : nullptr; a.We2Q = b.se.WeQ; a.seT0 = b.se.T0; a.seNQ = b.se.NQ;
   const int HW = b.H * b.W, MT = block_row_tiles(b, mt43), G = MT * 16 / HW;
   const size_t lds = block_lds_bytes(b, mt43);
   const dim3 grid((B + G - 1) / G);
@@ -4579,6 +4758,7 @@ static void fill_block_args(BlockArgs& a, const BlockPlan& b, int B) {
   a.Y = nullptr; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0;
   a.dbg_dw = nullptr; a.dbg_gate = nullptr;
   a.B = B; a.Cexp = b.ce; a.se = b.se.se;
+  a.WrQ = b.se.WrQ; a.We2Q = b.se.WeQ; a.seT0 = b.se.T0; a.seNQ = b.se.NQ;
 #ifdef MKWS_FRONT_TIMING
   a.dbg_t = nullptr;
 #endif
@@ -4603,7 +4783,7 @@ int launch_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, const floa
   const int n = i1 - i0 + 1, mt43 = em->block_mt43;
   if (!em->d_chain_tab) return fail(MKWS_ERR_UNSUPPORTED, "chain: no block table");
   ca.tab = em->d_chain_tab; ca.i0 = i0; ca.n = n; ca.kinds = 0; ca.ldsU = ca.ldsE = 0;
-  ca.X = X; ca.Y = Y; ca.B = B;
+  ca.X = X; ca.Y = Y; ca.B = B; ca.se4 = em->fuse_se4;
   int ldsZ = 0;
   std::string names;
   for (int k = 0; k < n; ++k) {
@@ -5171,7 +5351,7 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
         pw.err_dev = em->pair_err_dev; pw.err_host = em->pair_err_host; pw.fault = em->pair_fault;
         if (int rc = launch_pair(s, p.c_str(), b, pw, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
       } else {
-        if (int rc = launch_block(s, p.c_str(), b, em->block_mt43, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B)) return rc;
+        if (int rc = launch_block(s, p.c_str(), b, em->block_mt43, cur, nxt, tap_dw ? em->bufD : nullptr, tap_gate ? em->gate : nullptr, B, em->fuse_se4 != 0)) return rc;
       }
       if (hit(p + "_dw", em->bufD, (size_t)Mout * b.ce)) return MKWS_OK;
       if (hit(p + "_gate", em->gate, (size_t)B * b.ce)) return MKWS_OK;
@@ -5317,7 +5497,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   fold_bn(T("stem_bn/gamma"), T("stem_bn/beta"), T("stem_bn/moving_mean"), T("stem_bn/moving_variance"), kStemCh, &sc, &sh);
   const size_t o_stem_sc = pk.add(sc.data(), kStemCh), o_stem_sh = pk.add(sh.data(), kStemCh);
 
-  struct BlockOff { GemmOff expand, project, se_r, se_e; size_t dw_w, dw_sc, dw_sh, se_wr, se_we; } bo[kNumBlocks];
+  struct BlockOff { GemmOff expand, project, se_r, se_e; size_t dw_w, dw_sc, dw_sh, se_wr, se_we, se_q_r = 0, se_q_e = 0; int T0 = 0, NQ = 0; } bo[kNumBlocks];
   int H = 25, W = 20;
   for (int i = 0; i < kNumBlocks; ++i) {
     BlockPlan& b = em->blocks[i];
@@ -5355,6 +5535,32 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
       std::vector<float> one_e(b.ce, 1.0f), bias_e(T(p + "_se_expand/bias"), T(p + "_se_expand/bias") + b.ce);
       bo[i].se_e = pack_gemm(pk, T(p + "_se_expand/kernel"), se, b.ce, one_e, bias_e);
       if (bo[i].se_r.NTtot > 3) { delete em; return fail(MKWS_ERR_UNSUPPORTED, "SE width %d > 48", se); }
+      // 4x4x1-instruction packing of both FCs for the 4x3-image blocks (Se4 in the kernel section: lane l of instruction 4 q + e reads float e of
+      // dwordx4 (q, l)).  Reduce: wave w, half kh = l / 32, unit l % 32; channel w cpw + t (half 0, t < cpw - T0) or w cpw + cpw - T0 + t (half 1).
+      // Expand: group of 64 channels, channel 64 group + l, unit 4 q + e.  Zero where a channel / unit does not exist.
+      const int cpw = b.ce / kBlockWaves, T0 = 4 * ((cpw + 7) / 8), NQ = (se + 3) / 4, NG = (b.ce + 63) / 64;
+      if (H == 4 && W == 3 && b.has_expand && b.ce % (4 * kBlockWaves) == 0 && se <= 32 && T0 / 4 <= kSe4MaxTQ && NQ <= kSe4MaxNQ && NG <= kSe4MaxGroups * kBlockWaves &&
+          kBlockWaves * 4 * 32 <= 4 * b.ce) {      // (the wave partials [8][G][32] live where the gate used to: G * Cexp floats)
+        const float* wr = T(p + "_se_reduce/kernel");      // [C][se]
+        const float* we = T(p + "_se_expand/kernel");      // [se][C]
+        std::vector<float> qr((size_t)kBlockWaves * kSe4MaxTQ * 256, 0.0f), qe((size_t)NG * kSe4MaxNQ * 256, 0.0f);      // (zero padded to the kernels' fixed step counts)
+        for (int w = 0; w < kBlockWaves; ++w)
+          for (int t = 0; t < T0; ++t)
+            for (int l = 0; l < 64; ++l) {
+              const int kh = l / 32, n = l % 32;
+              const int ch = w * cpw + (kh ? cpw - T0 + t : t);
+              const bool ok = n < se && (kh || t < cpw - T0);
+              qr[(((size_t)w * kSe4MaxTQ + t / 4) * 64 + l) * 4 + t % 4] = ok ? wr[(size_t)ch * se + n] : 0.0f;
+            }
+        for (int gq = 0; gq < NG; ++gq)
+          for (int n = 0; n < 4 * NQ; ++n)
+            for (int l = 0; l < 64; ++l) {
+              const int ch = 64 * gq + l;
+              qe[(((size_t)gq * kSe4MaxNQ + n / 4) * 64 + l) * 4 + n % 4] = (n < se && ch < b.ce) ? we[(size_t)n * b.ce + ch] : 0.0f;
+            }
+        bo[i].se_q_r = pk.add(qr.data(), qr.size()); bo[i].se_q_e = pk.add(qe.data(), qe.size());
+        bo[i].T0 = T0; bo[i].NQ = NQ;
+      }
     }
     fold_bn(T(p + "_project_bn/gamma"), T(p + "_project_bn/beta"), T(p + "_project_bn/moving_mean"), T(p + "_project_bn/moving_variance"), b.spec.out_ch, &sc, &sh);
     bo[i].project = pack_gemm(pk, T(p + "_project_conv/kernel"), b.ce, b.spec.out_ch, sc, sh);
@@ -5387,6 +5593,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
     b.dw.Wd = d + bo[i].dw_w; b.dw.scale = d + bo[i].dw_sc; b.dw.shift = d + bo[i].dw_sh;
     b.se.Wr = d + bo[i].se_wr; b.se.We = d + bo[i].se_we; b.se.WrP = d + bo[i].se_r.Wp; b.se.br = d + bo[i].se_r.shift; b.se.WeP = d + bo[i].se_e.Wp; b.se.be = d + bo[i].se_e.shift;
     b.se.KCr = bo[i].se_r.KC; b.se.NTR = bo[i].se_r.NTtot; b.se.NTe = bo[i].se_e.NTtot;
+    if (bo[i].T0) { b.se.WrQ = d + bo[i].se_q_r; b.se.WeQ = d + bo[i].se_q_e; b.se.T0 = bo[i].T0; b.se.NQ = bo[i].NQ; }
     // the expand FC's K (= se) is padded to NTR*16 by pack_gemm: KC of se_e == NTR by construction
   }
   em->top = G(o_top); em->dense0 = G(o_d0); em->dense1 = G(o_d1); em->dense2 = G(o_d2);
@@ -5511,6 +5718,7 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
   if (strcmp(name, "fuse_mid") == 0) { em->fuse_mid = value; return MKWS_OK; }
   if (strcmp(name, "fuse_rows") == 0) { em->fuse_rows = value; return MKWS_OK; }
   if (strcmp(name, "fuse_walk") == 0) { em->fuse_walk = value; return MKWS_OK; }
+  if (strcmp(name, "fuse_se4") == 0) { em->fuse_se4 = value ? 1 : 0; return MKWS_OK; }
   if (strcmp(name, "fuse_gemv") == 0) { em->fuse_gemv = value; return MKWS_OK; }
   if (strcmp(name, "fuse_back") == 0) { em->fuse_back = value; return MKWS_OK; }
   if (strcmp(name, "fuse_pair") == 0) { em->fuse_pair = value; return MKWS_OK; }
@@ -5564,6 +5772,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_mid") == 0) return em->fuse_mid;
   if (strcmp(name, "fuse_rows") == 0) return em->fuse_rows;
   if (strcmp(name, "fuse_walk") == 0) return em->fuse_walk;
+  if (strcmp(name, "fuse_se4") == 0) return em->fuse_se4;
   if (strcmp(name, "fuse_gemv") == 0) return em->fuse_gemv;
   if (strcmp(name, "fuse_back") == 0) return em->fuse_back;
   if (strcmp(name, "fuse_pair") == 0) return em->fuse_pair;

@@ -52,3 +52,4 @@ def concurrent_streams(n, device=None):
         if len(have) < n:
             _exhausted.add(key)
     return have[:n]
+

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q -x > gpurun_out/r6_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/r6_pytest_gpu.log
+O=gpurun_out; mkdir -p $O
+timeout 3000 python -m pytest tests/ -m gpu -q 2>&1 | tail -25 | tee $O/r6_pytest_gpu.log
