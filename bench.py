@@ -494,12 +494,22 @@ def main():
             torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    if cfg == "finetune":
+        # every ft.G-th optimizer step launches the next group's forward chain: the timed region starts ON a group boundary (every rank runs
+        # the same count: the trainers step in lockstep) and the line says how many forward chains fell inside it, so that K not being a
+        # multiple of G cannot shift the figure unseen
+        while ft.j < ft.g:
+            step()
+        fwd0 = ft.forwards
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if cfg == "finetune":
+        extra_out["forward_chains_in_timed_region"] = ft.forwards - fwd0
+        extra_out["timed_steps_are_whole_groups"] = bool(args.steps % ft.G == 0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
