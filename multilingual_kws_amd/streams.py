@@ -35,6 +35,10 @@ def concurrent_streams(n, device=None):
     have = _cache.setdefault(key, [])
     if len(have) >= n or key in _exhausted:
         return have[:n]
+    if not hasattr(torch.cuda, "_sleep"):                                         # no spin kernel in this torch build: fresh streams, unmeasured
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=dev))
+        return have[:n]
     with torch.cuda.device(dev):
         first = have[0] if have else torch.cuda.Stream(device=dev)
         _spin_all(torch, [first], dev)                                        # (first launch of the spin kernel: module load)
