@@ -5475,7 +5475,9 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   // The multi-kernel path stays behind mkws_embed_set_option (A/B, parity taps).  Per handle, so results stay bit-identical
   // across the batch sizes one handle sees.
   em->fuse_block = 2;
-  em->fuse_mid = 1;
+  // (one-clip handles = live windows: the split front / back kernels put a clip's channel blocks on several CUs where the whole-block
+  //  kernel is ONE workgroup: 0.3056 -> 0.3023-0.3041 ms per window, tools/latency_ab.py fuse_mid, two rounds)
+  em->fuse_mid = (max_batch == 1) ? 0 : 1;
   em->fuse_rows = 0;       // measured slower than the mid / front + back kernels so far (profiles/r06_notes.md): an A/B option, not the plan
   em->fuse_back = 1;
   em->fuse_pair = pair_layout_ok() ? 1 : 0;
