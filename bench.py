@@ -450,7 +450,8 @@ def main():
         from multilingual_kws_amd.embedding import batch_streaming_analysis as bsa, input_data
         metric = "windows/sec streaming inference, 50 keywords on one shared embedding, 20 ms hop, batch 256"
         workload = ("configs[4]: 60 s synthetic stream -> 2950 one-second windows (20 ms hop, frame-sharing micro-frontend) -> EfficientNet-B0 "
-                    "embedding in batches of 256 windows -> 50 few-shot heads in one launch; batch-1 latency reported beside it")
+                    "embedding in batches of 256 windows, up to 4 batches side by side (one captured graph per batch lane, each lane on a HIP stream with a "
+                    "hardware queue of its own) -> 50 few-shot heads in one launch per batch; batch-1 latency reported beside it")
         ms = input_data.standard_microspeech_model_settings(3)
         stream = torch.from_numpy(np.concatenate([synth.clips_float32(1, first_clip=60 * rank + i)[0] for i in range(60)])).to(dev)
         heads = [Head(max_batch=B, seed=2000 + k, device=dev) for k in range(50)]
@@ -622,7 +623,7 @@ def main():
                 keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup") if k in d}
                 keep["whole_step_frac"] = d["roofline"].get("whole_step_frac")
                 keep["dominant"] = {k: d["roofline"].get(k) for k in ("kernel", "bound", "frac", "avg_launch_ms")}
-                for k in ("latency_ms_batch1", "latency_ms_batch1_eager", "serving_lanes", "steps_per_forward", "windows_per_stream"):
+                for k in ("latency_ms_batch1", "latency_ms_batch1_eager", "serving_lanes", "serving_lanes_used", "steps_per_forward", "windows_per_stream"):
                     if k in d:
                         keep[k] = d[k]
                 keep["workload"] = d["config"]["workload"]
