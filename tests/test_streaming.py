@@ -309,3 +309,11 @@ def test_serving_lanes_run_side_by_side_and_agree_with_the_eager_path(monkeypatc
     assert torch.equal(one, ref)
     with pytest.raises(Exception):
         emb.set_option("plan_batch", 128)                                     # below max_batch
+    # the lanes' streams were measured to overlap pairwise (one hardware queue each) and are handed out again; the lane count respects the
+    # paired kernels' budget: lanes x 2 x ceil(batch / 8) workgroups that hold their CU while they wait must fit the chip
+    from multilingual_kws_amd import streams
+    got4 = streams.concurrent_streams(4, emb.device)
+    assert 1 <= len(got4) <= 4 and len({s_.cuda_stream for s_ in got4}) == len(got4)
+    assert [s_.cuda_stream for s_ in streams.concurrent_streams(2, emb.device)] == [s_.cuda_stream for s_ in got4[:2]]
+    cus = torch.cuda.get_device_properties(emb.device).multi_processor_count
+    assert bsa.lane_budget(256, emb.device) == max(1, cus // 64) and bsa.lane_budget(1024, emb.device) == max(1, cus // 256)
