@@ -2015,6 +2015,9 @@ __host__ __device__ inline BlockLds block_lds(int KCe, int Cexp, int MT, int G, 
 // MT = 16-row activation tiles per workgroup: 1 for 2x2 images (4 clips), 3 for 4x3 images (4 clips = 48 rows;
 // every streamed weight fragment then feeds 3 MFMAs per n-tile instead of 1); 2 for 4x3 images in handles of at most 512
 // clips (2 clips = 24 of 32 rows: twice the workgroups, so that every CU still gets one).
+#ifndef MKWS_DW_CLIP_MINOR
+#define MKWS_DW_CLIP_MINOR 1
+#endif
 template <int KS, int S, int HT, int WT, int MT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_blk[];
@@ -2127,7 +2130,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mbconv_block_kernel(BlockArgs a) 
   {
     const int Q = Cexp / 4;
     for (int task = tid; task < G * Q; task += NTHR) {
-      const int gi = task / Q, q4 = (task - gi * Q) * 4;
+      // clip-minor task order: the G lanes that hold the G clips of one channel quad sit next to each other and ask for the SAME depthwise taps /
+      // BN constants -- the texture unit fetches a line once per instruction, so the workgroup pulls the block's taps from L2 once instead of once
+      // per clip (5b: 269 -> 67 KB per workgroup; chain 217.6 -> 216.7 us, the PAIRED kernels lose 2 us with it and keep clip-major; r06_notes.md section 12).  LDS: a 16-lane pass covers G clips x
+      // 16 / G quads, and the clips' row offsets (12 LDE resp. 4 LDE floats) are multiples of 16 banks apart.  Same arithmetic per task: bit-identical.
+      const int gi = MKWS_DW_CLIP_MINOR ? task % G : task / Q, q4 = (MKWS_DW_CLIP_MINOR ? task / G : task - gi * Q) * 4;
       float* Eg = s_E + (size_t)gi * HW * LDE + q4;
       f32x4 ein[HW];
 #pragma unroll
@@ -2503,7 +2510,11 @@ __device__ __forceinline__ void chain_block(const BlockArgs& a, const BlockArgs*
   {
     const int Q = Cexp / 4;
     for (int task = tid; task < G * Q; task += NTHR) {
-      const int gi = task / Q, q4 = (task - gi * Q) * 4;
+      // clip-minor task order: the G lanes that hold the G clips of one channel quad sit next to each other and ask for the SAME depthwise taps /
+      // BN constants -- the texture unit fetches a line once per instruction, so the workgroup pulls the block's taps from L2 once instead of once
+      // per clip (5b: 269 -> 67 KB per workgroup; chain 217.6 -> 216.7 us, the PAIRED kernels lose 2 us with it and keep clip-major; r06_notes.md section 12).  LDS: a 16-lane pass covers G clips x
+      // 16 / G quads, and the clips' row offsets (12 LDE resp. 4 LDE floats) are multiples of 16 banks apart.  Same arithmetic per task: bit-identical.
+      const int gi = MKWS_DW_CLIP_MINOR ? task % G : task / Q, q4 = (MKWS_DW_CLIP_MINOR ? task / G : task - gi * Q) * 4;
       float* Eg = s_E + (size_t)gi * HW * LDE + q4;
       // The taps are requested in SOURCE order ahead of their use (hipcc leaves this region in source order: with "load a tap, use it"
       // the phase ran one L2 latency per tap; mbconv_block_kernel's scheduler hoists all 25 loads by itself, but here 12 inputs + 12
@@ -3736,15 +3747,42 @@ __device__ __forceinline__ int cluster_signal_wait(int* row, int p, int P, int g
   }
 }
 
-template <int KS, int S, int HT, int WT>
-__global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
+// Write-through (sc1) 16-byte accesses through a buffer descriptor: the hand-over of a block's output to the NEXT block's members inside one
+// launch (mbconv_cluster_chain_kernel).  aux 16 = sc1: the store leaves the XCD's L2 for memory, the load bypasses the CU's L1 (Guideline 16, R1).
+// The base must be wave-uniform.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct XBuf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit XBuf(const float* base) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)) {}
+  __device__ __forceinline__ f32x4 ld(size_t idx) const { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(idx * 4u), 0, 16)); }
+  __device__ __forceinline__ void st(size_t idx, const f32x4& v) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (unsigned)(idx * 4u), 0, 16); }
+};
+
+// Wave 0 of a chained member: lanes q < P poll the previous block's `done` generations (one relaxed agent-scope load each).  0 = ok, 1 = timed out.
+__device__ __forceinline__ int cluster_wait_done(int* row, int P, int gen) {
+  const int lane = threadIdx.x & 63;
+  int spins = 0;
+  while (true) {
+    const int v = (lane < P) ? __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gen;
+    if (__builtin_amdgcn_ballot_w64(v != gen) == 0) return 0;
+    __builtin_amdgcn_s_sleep(4);
+    if (++spins > (1 << 20)) return 1;
+  }
+}
+
+// One block of one cluster member.  CHAINED = false: the body of mbconv_cluster_kernel (one launch per block).  CHAINED = true: the body of
+// mbconv_cluster_chain_kernel, where the members of ALL of a live window's tiny-image blocks start together: a member requests every weight it
+// will need (expand ring, SE weights, taps, the whole projection ring) and parks the SE weights / taps in LDS BEFORE it waits for the previous
+// block's `done` generations (wait_row, wait_P members), then reads the block input with L1-bypassing loads; its finishers store the output
+// write-through (sc1) and every member publishes its `done` generation (done_row) -- Guideline 16's R1 form, valid for any XCD placement.
+template <int KS, int S, int HT, int WT, bool CHAINED>
+__device__ __forceinline__ void cluster_block(const ClusterArgs& ca, const int cl, const int p, float* s_cl, int& s_bad, int* wait_row, int wait_P, int* done_row) {
   constexpr int NTHR = 256, NW = 4;
   constexpr int HW = HT * WT, G = 16 / HW;                       // clips per cluster: 1 (4x3) or 4 (2x2)
   const int P = ca.P;
   constexpr int HoT = (S == 1) ? HT : (HT == 4 ? 2 : 1), WoT = (S == 1) ? WT : (WT == 3 ? 2 : 1), HoWo = HoT * WoT;
   constexpr int PT = (S == 1) ? KS / 2 : KS / 2 - (1 - HT % 2), PLF = (S == 1) ? KS / 2 : KS / 2 - (1 - WT % 2);
   constexpr int CHMAX = kClusterChMax, LDEMAX = CHMAX + 4, LDR = 52;
-  extern __shared__ __attribute__((aligned(16))) float s_cl[];    // kClusterLdsFloats, carved for the largest block (CH = 192, 12 K chunks)
   float* s_X = s_cl;                                             // block input as B-operand fragments [KCe][64 lanes][4]
   float* s_E = s_X + 12 * 256;                                   // this member's expanded channels [16 rows][CH + 4]
   float* s_S = s_E + 16 * LDEMAX;                                // SE means [G][CH], later the gate
@@ -3754,9 +3792,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   float* s_Wr = s_sh + CHMAX;                                    // the member's rows of the SE-reduce weights, TRANSPOSED: [se][CH + 4]
   float* s_We = s_Wr + 48 * (CHMAX + 4);                         // its columns of the SE-expand weights [se][CH]
   float* s_Wd = s_We + 48 * CHMAX;                               // depthwise taps of its channels [KS*KS][CH], then BN scale [CH], shift [CH]
-  __shared__ int s_bad;
   const BlockArgs& a = ca.b;
-  const int cl = (blockIdx.x / (8 * P)) * 8 + (blockIdx.x & 7), p = (blockIdx.x >> 3) % P;
   const int b0 = cl * G;
   if (b0 >= a.B) return;                                         // all members of a padding cluster leave together
   const int Cexp = a.Cexp, CH = Cexp / P, KH = CH / 16, chan0 = p * CH, LDE = CH + 4;
@@ -3778,10 +3814,13 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   // this launch's generations = the member's own last ones + 1 (uniform scalar loads; used by wave 0 at the exchanges)
   const int gen0 = __hip_atomic_load(frow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   const int gen1 = __hip_atomic_load(frow + kClFlagRow + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  // chained: the hand-over generation.  Every chain launch runs every member of every block, so all `done` words of a handle agree between launches
+  int genH = 0;
+  if constexpr (CHAINED) genH = __hip_atomic_load(done_row + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
 #ifdef MKWS_FRONT_TIMING
   const long long dbg_c0 = clock64();
-  if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
-#define MKWS_CL_STAMP(k) if (threadIdx.x == 0) a.dbg_t[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();
+  if (threadIdx.x == 0 && a.dbg_t) a.dbg_t[(size_t)blockIdx.x * 8 + 0] = wall_clock64();
+#define MKWS_CL_STAMP(k) if (threadIdx.x == 0 && a.dbg_t) a.dbg_t[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();
 #else
 #define MKWS_CL_STAMP(k)
 #endif
@@ -3798,13 +3837,46 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
   const int a_nruns = (a_ngroups > wave) ? (a_ngroups - wave + NW - 1) / NW : 0;
   auto a_tile_of = [&](int r) { return p * KH + (wave + NW * r) * NTWA; };
   f32x4 wqa[12][NTWA];                                             // the whole run (<= 12 chunks x NTWA fragments) in flight: one latency
+  // phase D's weight ring: chained members hold their WHOLE K slice (KH = 3 chunks for Cexp / P = 48, 6 for 96) from before the wait
+  constexpr int DD = CHAINED ? ((HW == 4) ? 6 : 3) : 4;
+  f32x4 wqd[DD][5];
+  const WBuf d_w(a.WpP + (size_t)(p * KH) * a.NTp * 256, loff);
+  const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NW - 1) / NW : 0;
+  // the SE weights / depthwise taps requested below go to LDS: after phase A (they travel under the expand), or -- chained -- before the wait
+  auto park = [&]() {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {                                    // Wr [CH][se] -> transposed [se][CH + 4]; float4 = 4 units of one channel (se % 4 == 0)
+      const int i = tid + NTHR * k;
+      if (i < nWr) {
+        const int ch = (4 * i) / a.se, n = 4 * i - ch * a.se;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_Wr[(n + q) * LDW + ch] = rr[k][q];
+      }
+    }
+    if ((a.se & 3) != 0)
+      for (int i = tid; i < CH * a.se; i += NTHR) { const int ch = i / a.se, n = i - ch * a.se; s_Wr[n * LDW + ch] = ca.Wr[(size_t)chan0 * a.se + i]; }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = tid + NTHR * k;
+      if (i < nWe) { const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = re[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const int i = tid + NTHR * k;
+      if (i < nWd) { const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_Wd + (size_t)t * CH + q4) = rd[k]; }
+    }
+    // phase D's weight stream (K = the member's KH chunks, tiles wave, wave + 4, ...) is requested now: it lands under phases B and C
+    if (d_ntw > 0) stream_mfma_prefetch<5, DD>(wqd, d_w, (size_t)a.NTp * 256, wave, NW, a.NTp, KH);
+  };
   {
     f32x4 rx[NX];
+    if constexpr (!CHAINED) {
 #pragma unroll
-    for (int k = 0; k < NX; ++k) {
-      const int j = wave + NW * k;
-      rx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (j < a.KCe && c < rows_in && 16 * j + 4 * g < a.Cin) rx[k] = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
+      for (int k = 0; k < NX; ++k) {
+        const int j = wave + NW * k;
+        rx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < a.KCe && c < rows_in && 16 * j + 4 * g < a.Cin) rx[k] = *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + 16 * j + 4 * g);
+      }
     }
     float sce = 0.0f, she = 0.0f;
     if (tid < CH) { sce = a.scE[chan0 + tid]; she = a.shE[chan0 + tid]; }       // CH <= 192 < NTHR
@@ -3828,6 +3900,27 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
       }
     }
     if (tid < CH) { s_sc[tid] = sce; s_sh[tid] = she; }
+    if constexpr (CHAINED) {
+      // every weight of the block is requested; the SE weights / taps wait in LDS, the two rings in registers.  Now the block input: published by
+      // ALL members of the previous block (its finishers stored the tiles write-through before their `done` word)
+      park();
+      __syncthreads();                                               // (s_bad is set)
+      if (wait_row != nullptr) {
+        if (wave == 0 && s_bad == 0) {
+          const int to = cluster_wait_done(wait_row, wait_P, genH);
+          if (to && lane == 0) { s_bad = 1; pair_report(ca.err_dev, ca.err_host, kPairErrTimeout); }
+        }
+        __syncthreads();
+      }
+      MKWS_CL_STAMP(7)
+      const XBuf xin(a.X);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        const int j = wave + NW * k;
+        rx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < a.KCe && c < rows_in && 16 * j + 4 * g < a.Cin) rx[k] = xin.ld((row0_in + c) * a.Cin + 16 * j + 4 * g);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NX; ++k) { const int j = wave + NW * k; if (j < a.KCe) *reinterpret_cast<f32x4*>(s_X + ((size_t)j * 64 + lane) * 4) = rx[k]; }
   }
@@ -3853,33 +3946,8 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
     };
     stream_mfma_runs<NTWA, 12, 1, true>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, a_nruns, a.KCe, a_tile_of, xload, xmake, epi);
   }
-  // the SE weights / depthwise taps requested before phase A go to LDS now
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {                                    // Wr [CH][se] -> transposed [se][CH + 4]; float4 = 4 units of one channel (se % 4 == 0)
-    const int i = tid + NTHR * k;
-    if (i < nWr) {
-      const int ch = (4 * i) / a.se, n = 4 * i - ch * a.se;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s_Wr[(n + q) * LDW + ch] = rr[k][q];
-    }
-  }
-  if ((a.se & 3) != 0)
-    for (int i = tid; i < CH * a.se; i += NTHR) { const int ch = i / a.se, n = i - ch * a.se; s_Wr[n * LDW + ch] = ca.Wr[(size_t)chan0 * a.se + i]; }
-#pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const int i = tid + NTHR * k;
-    if (i < nWe) { const int n = i / (CH / 4), q4 = (i - n * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_We + (size_t)n * CH + q4) = re[k]; }
-  }
-#pragma unroll
-  for (int k = 0; k < ND; ++k) {
-    const int i = tid + NTHR * k;
-    if (i < nWd) { const int t = i / (CH / 4), q4 = (i - t * (CH / 4)) * 4; *reinterpret_cast<f32x4*>(s_Wd + (size_t)t * CH + q4) = rd[k]; }
-  }
-  // phase D's weight stream (K = the member's KH chunks, tiles wave, wave + 4, ...) is requested now: it lands under phases B and C
-  const WBuf d_w(a.WpP + (size_t)(p * KH) * a.NTp * 256, loff);
-  const int d_ntw = (a.NTp > wave) ? (a.NTp - wave + NW - 1) / NW : 0;
-  f32x4 wqd[4][5];
-  if (d_ntw > 0) stream_mfma_prefetch<5, 4>(wqd, d_w, (size_t)a.NTp * 256, wave, NW, a.NTp, KH);
+  // the SE weights / depthwise taps requested before phase A go to LDS now (chained members parked them before the wait)
+  if constexpr (!CHAINED) park();
   __syncthreads();
   MKWS_CL_STAMP(2)
   // ---- B: depthwise + BN + swish in place, SE means (thread = clip x channel quad of the member's slice) ----
@@ -4013,7 +4081,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
       f32x4 acc[NTW][1];
 #pragma unroll
       for (int q = 0; q < NTW; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      stream_mfma<NTW, 4, 1, true>(acc, wqd, d_w, cstride, wave, NW, a.NTp, KH, xload, xmake);
+      stream_mfma<NTW, DD, 1, true>(acc, wqd, d_w, cstride, wave, NW, a.NTp, KH, xload, xmake);
 #pragma unroll
       for (int q = 0; q < NTW; ++q) {
         const int t = wave + NW * q;
@@ -4046,17 +4114,102 @@ __global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
       const int n = t * 16 + 4 * g;
       if (c < rows_out) {
         f32x4 y = v * *reinterpret_cast<const f32x4*>(a.scP + n) + *reinterpret_cast<const f32x4*>(a.shP + n);
-        if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + n);
-        if (bad) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-        *reinterpret_cast<f32x4*>(a.Y + (row0_out + c) * a.Cout + n) = y;
+        if constexpr (CHAINED) {
+          if (a.residual) y += XBuf(a.X).ld((row0_in + c) * a.Cin + n);
+          if (bad) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+          XBuf(a.Y).st((row0_out + c) * a.Cout + n, y);
+        } else {
+          if (a.residual) y += *reinterpret_cast<const f32x4*>(a.X + (row0_in + c) * a.Cin + n);
+          if (bad) y = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+          *reinterpret_cast<f32x4*>(a.Y + (row0_out + c) * a.Cout + n) = y;
+        }
       }
     }
   }
+  if constexpr (CHAINED) {
+    // publish: every storing wave drains its write-through stores, then ONE lane shows this member's generation (members without a tile to
+    // finish publish too: the next block waits for all P words, which also tells it that nobody still reads the exchange buffers)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done_row + p, genH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef MKWS_FRONT_TIMING
   __syncthreads();
-  if (threadIdx.x == 0) { a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64(); a.dbg_t[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - dbg_c0); }
+  if (threadIdx.x == 0 && a.dbg_t) { a.dbg_t[(size_t)blockIdx.x * 8 + 6] = wall_clock64(); if (!CHAINED) a.dbg_t[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - dbg_c0); }
 #endif
 #undef MKWS_CL_STAMP
+}
+
+template <int KS, int S, int HT, int WT>
+__global__ __launch_bounds__(256) void mbconv_cluster_kernel(ClusterArgs ca) {
+  extern __shared__ __attribute__((aligned(16))) float s_cl[];    // kClusterLdsFloats, carved for the largest block (CH = 192, 12 K chunks)
+  __shared__ int s_bad;
+  const int P = ca.P;
+  const int cl = (blockIdx.x / (8 * P)) * 8 + (blockIdx.x & 7), p = (blockIdx.x >> 3) % P;
+  cluster_block<KS, S, HT, WT, false>(ca, cl, p, s_cl, s_bad, nullptr, 0, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The tiny-image blocks 4b .. 7a of ONE live window as one launch (one-clip handles, option "fuse_cluster_chain").  Launch by launch, every
+// block's 10-14 members spend the first 4-7 us of their 13-23 us waiting for ~200 KB of weights each (one CU pulls lines that miss L2 at
+// ~13 GB/s, whatever the order), and only one block's members pull at a time.  Here the members of ALL ten blocks (120 workgroups on 120 CUs)
+// start together and request everything they will need at once -- 12 MB arrive over 120 CUs while the first block computes -- and a block
+// starts on resident operands the moment the previous one publishes its output (cluster_block<CHAINED>).
+// Placement: block k's members sit on XCD k % 8 (ids base[k] + 8 m + k % 8 under the round-robin dispatch probed at create; the other ids
+// of the range leave at once), so that a block's two exchanges stay inside one L2; the hand-over between blocks is write-through and
+// placement-free.  A member only ever waits for workgroups with LOWER ids or of its own block: the in-order dispatch cannot deadlock a lone
+// launch.  (Several chain launches at once on a crowded chip can starve each other; the waits are bounded and end in the exchange-failure
+// contract of the paired kernels: NaN output, sticky error word, the handle leaves the cluster plan.)
+constexpr int kClusterChainMax = 10;
+struct ClusterChainArgs {
+  const BlockArgs* tab;                // device table of the plan's block constants (see ChainArgs)
+  int i0, n;                           // blocks i0 .. i0 + n - 1
+  unsigned kinds;                      // 3 bits per position: 0 = <3,1,4,3>, 1 = <5,1,4,3>, 2 = <5,2,4,3>, 3 = <5,1,2,2>, 4 = <3,1,2,2>
+  float* buf0; float* buf1;            // block j reads buf[j & 1] and writes buf[(j + 1) & 1]
+  const float* Wr[kClusterChainMax];   // plain SE weights of every block
+  const float* We[kClusterChainMax];
+  int base[kClusterChainMax + 1];      // first workgroup id of every block (multiples of 8)
+  signed char P[kClusterChainMax];
+  float* xc1; float* xd;               // exchange buffers of cluster 0 (the blocks use them one after the other)
+  int* flags; int flag_stride;         // per-block flag region (ints): rows 0 / 1 of cluster slot 0 = the exchanges, row 0 of slot 1 = `done`
+  int* err_dev; int* err_host; int fault;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* dbg_t;
+#endif
+};
+
+__global__ __launch_bounds__(256) void mbconv_cluster_chain_kernel(ClusterChainArgs cc) {
+  extern __shared__ __attribute__((aligned(16))) float s_cl[];
+  __shared__ int s_bad;
+  int k = 0;
+  while (k + 1 < cc.n && (int)blockIdx.x >= cc.base[k + 1]) ++k;
+  const int r = (int)blockIdx.x - cc.base[k];
+  if ((r & 7) != (k & 7)) return;                                  // not on this block's XCD
+  const int p = r >> 3;
+  ClusterArgs ca;
+  ca.b = sgpr_block_args(cc.tab[cc.i0 + k]);
+  ca.b.X = (k & 1) ? cc.buf1 : cc.buf0;
+  ca.b.Y = (k & 1) ? cc.buf0 : cc.buf1;
+  ca.b.B = 1;
+  ca.b.dbg_dw = nullptr; ca.b.dbg_gate = nullptr;
+#ifdef MKWS_FRONT_TIMING
+  ca.b.dbg_t = cc.dbg_t;
+#endif
+  ca.Wr = cc.Wr[k]; ca.We = cc.We[k];
+  ca.xc1 = cc.xc1; ca.xd = cc.xd;
+  ca.flags = cc.flags + (size_t)(cc.i0 + k) * cc.flag_stride;
+  ca.err_dev = cc.err_dev; ca.err_host = cc.err_host; ca.fault = cc.fault;
+  ca.P = cc.P[k];
+  int* done = ca.flags + 2 * kClFlagRow;                           // cluster slot 1, row 0 (a one-clip handle only ever runs cluster 0)
+  int* wait = (k > 0) ? cc.flags + (size_t)(cc.i0 + k - 1) * cc.flag_stride + 2 * kClFlagRow : nullptr;
+  const int wait_P = (k > 0) ? cc.P[k - 1] : 0;
+  switch ((cc.kinds >> (3 * k)) & 7u) {
+    case 0: cluster_block<3, 1, 4, 3, true>(ca, 0, p, s_cl, s_bad, wait, wait_P, done); break;
+    case 1: cluster_block<5, 1, 4, 3, true>(ca, 0, p, s_cl, s_bad, wait, wait_P, done); break;
+    case 2: cluster_block<5, 2, 4, 3, true>(ca, 0, p, s_cl, s_bad, wait, wait_P, done); break;
+    case 3: cluster_block<5, 1, 2, 2, true>(ca, 0, p, s_cl, s_bad, wait, wait_P, done); break;
+    default: cluster_block<3, 1, 2, 2, true>(ca, 0, p, s_cl, s_bad, wait, wait_P, done); break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4255,6 +4408,7 @@ struct mkws_embed {
   int pair_degraded = 0;           // how many times this handle left the paired kernel because an exchange failed
   int fuse_cluster = 0;            // small-batch handles: tiny-image blocks on mbconv_cluster_kernel (6 workgroups per 16-row tile split the channels)
   float* cl_xc1 = nullptr; float* cl_xd = nullptr; int* cl_flags = nullptr; size_t cl_flag_count = 0;   // its exchange buffers / generation flags
+  int fuse_cluster_chain = 0;      // one-clip handles: blocks 4b .. 7a as ONE launch (mbconv_cluster_chain_kernel: every member requests its weights at the start)
   int pair_mt = 2;                 // row tiles per pair (2 = 8 clips, 1 = 4 clips): pair_row_tiles(max_batch)
   int block_mt43 = 3;              // row tiles per workgroup of the 4x3 whole-block kernels (3 = 4 clips, 2 = 2 clips): same rule
   BlockPlan blocks[kNumBlocks];
@@ -5061,6 +5215,78 @@ int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, int blo
   return MKWS_OK;
 }
 
+// Blocks i0 .. i1 (all cluster_supported, one clip) as ONE launch: see mbconv_cluster_chain_kernel.  The last block's output lands in
+// buf0 when the chain has an even number of blocks, in buf1 otherwise (the blocks ping-pong like the launch-by-launch plan).
+int cluster_chain_kind(const BlockPlan& b) {
+  const int ks = b.spec.kernel, st = b.spec.stride;
+  if (b.H == 4 && b.W == 3) return (ks == 3 && st == 1) ? 0 : (ks == 5 && st == 1) ? 1 : (ks == 5 && st == 2) ? 2 : -1;
+  if (b.H == 2 && b.W == 2) return (ks == 5 && st == 1) ? 3 : (ks == 3 && st == 1) ? 4 : -1;
+  return -1;
+}
+bool cluster_chain_ok(const mkws_embed* em, int i0, int i1) {
+  if (!em->fuse_cluster_chain || !em->fuse_cluster || !em->cl_flags || !em->d_chain_tab || em->max_batch != 1) return false;
+  if (i1 - i0 + 1 > kClusterChainMax || i1 - i0 + 1 < 2 || em->cl_flag_count / kNumBlocks < 4 * (size_t)kClFlagRow) return false;
+  for (int i = i0; i <= i1; ++i) {
+    const BlockPlan& b = em->blocks[i];
+    if (!cluster_supported(b) || cluster_chain_kind(b) < 0 || (b.se.se & 3) != 0) return false;
+    const int P = cluster_members(b.ce), KH = b.ce / P / 16;
+    if (KH != ((b.H * b.W == 4) ? 6 : 3)) return false;              // the chained members hold their whole projection slice in a ring of that depth
+    if (i > i0 && (em->blocks[i - 1].spec.out_ch != b.spec.in_ch || em->blocks[i - 1].Ho != b.H || em->blocks[i - 1].Wo != b.W)) return false;
+  }
+  return true;
+}
+int launch_cluster_chain(hipStream_t s, const mkws_embed* em, int i0, int i1, float* buf0, float* buf1) {
+  ClusterChainArgs cc;
+  memset(static_cast<void*>(&cc), 0, sizeof(cc));
+  cc.tab = em->d_chain_tab; cc.i0 = i0; cc.n = i1 - i0 + 1; cc.kinds = 0;
+  cc.buf0 = buf0; cc.buf1 = buf1;
+  std::string names;
+  int base = 0;
+  for (int k = 0; k < cc.n; ++k) {
+    const BlockPlan& b = em->blocks[i0 + k];
+    cc.kinds |= (unsigned)cluster_chain_kind(b) << (3 * k);
+    cc.Wr[k] = b.se.Wr; cc.We[k] = b.se.We;
+    cc.P[k] = (signed char)cluster_members(b.ce);
+    cc.base[k] = base;
+    base += 8 * cc.P[k];
+    names += (k ? "," : "") + std::string(b.spec.name);
+  }
+  cc.base[cc.n] = base;
+  cc.xc1 = em->cl_xc1; cc.xd = em->cl_xd;
+  cc.flags = em->cl_flags; cc.flag_stride = (int)(em->cl_flag_count / kNumBlocks);
+  cc.err_dev = em->pair_err_dev; cc.err_host = em->pair_err_host; cc.fault = em->pair_fault;
+  const size_t lds = (size_t)kClusterLdsFloats * sizeof(float);
+  ProfScope ps("chain:" + names, "mbconv_cluster_chain_kernel");
+  if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mbconv_cluster_chain_kernel), (int)lds)) return rc_;
+#ifdef MKWS_FRONT_TIMING
+  unsigned long long* d_bt = block_timing_buffer();
+  (void)hipMemsetAsync(d_bt, 0, sizeof(unsigned long long) * 8 * 4096, s);
+  cc.dbg_t = d_bt;
+#endif
+  hipLaunchKernelGGL(mbconv_cluster_chain_kernel, dim3(base), dim3(256), lds, s, cc);
+#ifdef MKWS_FRONT_TIMING
+  {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)base * 8);
+    (void)hipMemcpy(h.data(), d_bt, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (int i = 0; i < base; ++i) if (h[8 * (size_t)i + 6] != 0 && h[8 * (size_t)i] < t0) t0 = h[8 * (size_t)i];
+    for (int k = 0; k < cc.n; ++k) {
+      // per block, over its members: latest start, latest end of the wait, then the phases from there
+      double st[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nm = 0;
+      for (int i = cc.base[k]; i < cc.base[k + 1]; ++i) {
+        if (h[8 * (size_t)i + 6] == 0) continue;
+        for (int q = 0; q < 8; ++q) st[q] = std::max(st[q], (double)(h[8 * (size_t)i + q] - t0) / 100.0);
+        ++nm;
+      }
+      fprintf(stderr, "[cluster-chain] %-3s members %2d: started %6.2f  wait over %6.2f | input staged %6.2f  A %6.2f  B %6.2f  C1+x1 %6.2f  C2 %6.2f  D+x2+publish %6.2f us (latest member, since the launch's first stamp)\n",
+              em->blocks[i0 + k].spec.name, nm, st[0], st[7], st[1], st[2], st[3], st[4], st[5], st[6]);
+    }
+  }
+#endif
+  return MKWS_OK;
+}
+
 // Whole-block kernel for the big-image blocks 2a..4a (mbconv_mid_kernel): one instance per layer geometry.
 bool mid_supported(const BlockPlan& b) {
   if (!b.has_expand || b.se.se > 10) return false;
@@ -5158,11 +5384,14 @@ int launch_rows(hipStream_t s, const char* stage, const BlockPlan& b, int alt, c
   return launch_rows_variant(s, v, a);
 }
 
-// Back half (SE + gated projection in one launch) for the blocks that keep mbconv_front_kernel: 2a, 2b, 3b.
+// Back half (SE + gated projection in one launch) for the blocks that keep mbconv_front_kernel: 2a, 2b, 3b -- and 3a / 4a where the whole-block
+// (mid) kernel is not taken: one-clip serving handles split those blocks into front + back so that several CUs work on the window, and the back
+// launch replaces se_reduce + se_expand + the gated projection GEMM (three dependent launches, 14.5 us of a live window, by one of ~7).
 bool back_supported(const BlockPlan& b) {
   if (!b.has_expand || b.se.se > 10) return false;
   const int hw = b.Ho * b.Wo;
-  return (hw == 130 && b.ce == 96 && b.spec.out_ch == 24) || (hw == 130 && b.ce == 144 && b.spec.out_ch == 24) || (hw == 35 && b.ce == 240 && b.spec.out_ch == 40);
+  return (hw == 130 && b.ce == 96 && b.spec.out_ch == 24) || (hw == 130 && b.ce == 144 && b.spec.out_ch == 24) || (hw == 35 && b.ce == 240 && b.spec.out_ch == 40) ||
+         (hw == 35 && b.ce == 144 && b.spec.out_ch == 40) || (hw == 12 && b.ce == 240 && b.spec.out_ch == 80);
 }
 
 template <int HOWO, int CEXP, int NTP, int RS, int NTHR, int WPE>
@@ -5185,8 +5414,11 @@ int launch_back(hipStream_t s, const char* stage, const BlockPlan& b, const floa
   a.WpP = b.project.Wp; a.scP = b.project.scale; a.shP = b.project.shift;
   a.Y = Y; a.Cout = b.spec.out_ch; a.residual = b.residual ? 1 : 0; a.dbg_gate = dbg_gate; a.B = B;
   //                          HOWO CEXP NTP RS NTHR WPE
+  const int hw = b.Ho * b.Wo;
   if (b.ce == 96) return launch_back_inst<130, 96, 2, 8, 512, 4>(s, stage, a);   // 2a: 52 KB of LDS -> 3 workgroups per CU
-  if (b.ce == 144) return launch_back_inst<130, 144, 2, 4, 512, 4>(s, stage, a);  // 2b: 80.5 KB -> 2 per CU
+  if (b.ce == 144 && hw == 130) return launch_back_inst<130, 144, 2, 4, 512, 4>(s, stage, a);  // 2b: 80.5 KB -> 2 per CU
+  if (b.ce == 144) return launch_back_inst<35, 144, 3, 4, 512, 4>(s, stage, a);   // 3a (handles without the mid kernel): 22 KB
+  if (hw == 12) return launch_back_inst<12, 240, 5, 4, 512, 4>(s, stage, a);      // 4a (the same): 15 KB; five n-tiles on five of the eight waves
   return launch_back_inst<35, 240, 3, 4, 512, 4>(s, stage, a);                    // 3b: 39 KB -> 4 per CU by LDS; 91 VGPRs keep it at 2 (6 waves per SIMD spills 37 registers: tried in round 4)
 }
 
@@ -5227,6 +5459,7 @@ int check_pair_health(mkws_embed* em, hipStream_t s) {
   if (code == 0) return MKWS_OK;
   em->fuse_pair = 0;
   em->fuse_cluster = 0;
+  em->fuse_cluster_chain = 0;
   em->pair_fault = 0;
   ++em->pair_degraded;
   *reinterpret_cast<volatile int*>(em->pair_err_host) = 0;
@@ -5337,6 +5570,17 @@ int run_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb, hipStr
         top_done = with_top;
         if (hit(std::string("block") + bl.spec.name, nxt, (size_t)B * bl.Ho * bl.Wo * bl.spec.out_ch)) return MKWS_OK;
         float* t = cur; cur = nxt; nxt = t;
+        i = e;
+        continue;
+      }
+    }
+    if (B == 1 && em->fuse_block && em->fuse_cluster_chain && cluster_supported(b) && !stop) {
+      // a live window's tiny-image blocks from here to the top conv as ONE launch (no taps inside: those run launch by launch below)
+      int e = i;
+      while (e + 1 < kNumBlocks && e + 1 - i < kClusterChainMax && cluster_supported(em->blocks[e + 1])) ++e;
+      if (cluster_chain_ok(em, i, e)) {
+        if (int rc = launch_cluster_chain(s, em, i, e, cur, nxt)) return rc;
+        if (((e - i + 1) & 1) != 0) { float* t = cur; cur = nxt; nxt = t; }       // (an even number of blocks ends in the buffer it started from)
         i = e;
         continue;
       }
@@ -5483,6 +5727,7 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   em->fuse_pair = pair_layout_ok() ? 1 : 0;
   // small-batch (live serving) handles: the tiny-image blocks on the 6-way cluster kernel, same dispatch-order premise as the pairs
   em->fuse_cluster = (max_batch <= kClusterMaxBatch && em->fuse_pair) ? 1 : 0;
+  em->fuse_cluster_chain = (max_batch == 1 && em->fuse_cluster) ? 1 : 0;
   em->pair_mt = pair_row_tiles(max_batch);
   em->block_mt43 = block43_row_tiles(max_batch);
   (void)hipGetDevice(&em->device);
@@ -5730,6 +5975,10 @@ int mkws_embed_set_option(mkws_embed* em, const char* name, int value) {
     if (value && !em->cl_flags) return fail(MKWS_ERR_UNSUPPORTED, "fuse_cluster needs a handle of at most 64 clips (max_batch = %d)", em->max_batch);
     em->fuse_cluster = value; return MKWS_OK;
   }
+  if (strcmp(name, "fuse_cluster_chain") == 0) {
+    if (value && (em->max_batch != 1 || !em->cl_flags)) return fail(MKWS_ERR_UNSUPPORTED, "fuse_cluster_chain is the plan of one-clip handles (max_batch = %d)", em->max_batch);
+    em->fuse_cluster_chain = value; return MKWS_OK;
+  }
   if (strcmp(name, "fuse_stem") == 0) { em->fuse_stem = value; return MKWS_OK; }
   if (strcmp(name, "big_tiles") == 0) {      // A/B: 8-clip pairs and 4-clip 4x3 workgroups whatever max_batch is (fewer, larger workgroups: the workspaces still fit)
     if (value) { em->pair_mt = 2; em->block_mt43 = 3; } else { em->pair_mt = pair_row_tiles(em->plan_batch); em->block_mt43 = block43_row_tiles(em->plan_batch); }
@@ -5781,6 +6030,7 @@ int mkws_embed_get_option(const mkws_embed* em, const char* name) {
   if (strcmp(name, "fuse_chain") == 0) return em->fuse_chain;
   if (strcmp(name, "fuse_top") == 0) return em->fuse_top;
   if (strcmp(name, "fuse_cluster") == 0) return em->fuse_cluster;
+  if (strcmp(name, "fuse_cluster_chain") == 0) return em->fuse_cluster_chain;
   if (strcmp(name, "fuse_stem") == 0) return em->fuse_stem;
   if (strcmp(name, "fuse_gap") == 0) return em->fuse_gap;
   if (strcmp(name, "block_tiles") == 0) return em->block_mt43;

@@ -486,3 +486,67 @@ def test_cluster_kernel_taps_and_failure_contract(ctx):
     big = EmbeddingModel(ctx["blob"], max_batch=128)
     with pytest.raises(_lib.MkwsError):
         big.set_option("fuse_cluster", 1)                                      # no exchange buffers above 64 clips
+
+
+def test_cluster_chain_plan_of_one_clip_handles(ctx):
+    """mbconv_cluster_chain_kernel (round 6): a live window's blocks 4b .. 7a as ONE launch -- the members of all ten blocks request their
+    weights together and a block starts when the previous one has published its output (write-through stores, generation words).  Same
+    arithmetic in the same order as the launch-by-launch cluster plan: bit-identical to it, on many windows in a row (stale-line / generation
+    bugs show as a mismatch on a later call), replayed from a hipGraph, against the oracle, and the shared failure contract."""
+    from multilingual_kws_amd import _lib
+    from multilingual_kws_amd.embedding_model import EmbeddingModel
+    rng = np.random.default_rng(91)
+    specs = _spec(rng, 24)
+    em = EmbeddingModel(ctx["blob"], max_batch=1)
+    if em.get_option("fuse_cluster") != 1:
+        pytest.skip("dispatch probe failed on this device: the cluster kernels are not in use")
+    assert em.get_option("fuse_cluster_chain") == 1
+    ref = ctx["oracle"].forward(specs).numpy()
+    xs = torch.from_numpy(specs).to(ctx["dev"])
+    chained = torch.stack([em.forward(xs[i:i + 1])[0].clone() for i in range(24)])
+    em.set_option("fuse_cluster_chain", 0)
+    single = torch.stack([em.forward(xs[i:i + 1])[0].clone() for i in range(24)])
+    em.set_option("fuse_cluster_chain", 1)
+    assert torch.equal(chained, single)
+    assert _rel(chained.cpu().numpy(), ref) < REL_TOL and np.array_equal(chained.cpu().numpy().argmax(1), ref.argmax(1))
+    # alternating inputs, back to back without a synchronisation: window i must never see window i - 1's activations
+    for rep in range(50):
+        i = rep % 24
+        assert torch.equal(em.forward(xs[i:i + 1])[0], chained[i]), rep
+    # taps inside the chain's range run launch by launch and agree with the oracle; the forward after them is unchanged
+    taps = {}
+    ctx["oracle"].forward(specs[:1], taps)
+    for name in ("block4b", "block5b_gate", "block6a", "block6c_dw", "block7a"):
+        assert _rel(em.tap(xs[:1], name).cpu().numpy().reshape(taps[name].shape), taps[name]) < REL_TOL, name
+    assert torch.equal(em.forward(xs[:1])[0], chained[0])
+    # hipGraph replay (the serving path): generation words, no per-launch arguments
+    xin = xs[3:4].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        em.forward(xin)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_g = em.forward(xin)
+    for i in (3, 7, 11, 3):
+        xin.copy_(xs[i:i + 1])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g[0], chained[i]), i
+    # a larger handle does not take the option
+    with pytest.raises(_lib.MkwsError):
+        EmbeddingModel(ctx["blob"], max_batch=2).set_option("fuse_cluster_chain", 1)
+    # failure contract: a member that never arrives (fault 2) / a wrong XCC id (fault 1) poison the window, the next call reports and degrades
+    for fault in (1, 2):
+        emf = EmbeddingModel(ctx["blob"], max_batch=1)
+        emf.set_option("pair_fault", fault)
+        bad = emf.forward(xs[:1])
+        torch.cuda.synchronize()
+        assert torch.isnan(bad).all()
+        emf.set_option("pair_fault", 0)
+        emb = torch.empty((1, 1024), device=ctx["dev"])
+        rc = emf.L.mkws_embed_forward(emf.h, xs[:1].data_ptr(), 1, emb.data_ptr(), _lib.current_stream_ptr())
+        assert rc == _lib.MKWS_ERR_EXCHANGE and emf.get_option("fuse_cluster_chain") == 0 and emf.get_option("fuse_cluster") == 0
+        again = emf.forward(xs[:1])
+        assert torch.isfinite(again).all() and _rel(again.cpu().numpy(), ref[:1]) < REL_TOL
