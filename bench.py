@@ -580,7 +580,10 @@ def main():
             roof["whole_step_frac"] = round(units_per_step * arch.EMBED_FLOPS_PER_CLIP / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
         if cfg == "stream":
             one = audio[:1].contiguous()
-            em1 = EmbeddingModel(blob, max_batch=1, device=dev)          # small-batch handles plan the multi-kernel path
+            # a one-clip handle plans a live window: split front / back kernels for blocks 2a .. 4a, blocks 4b .. 7a as ONE cluster-chain launch
+            # (mbconv_cluster_chain_kernel), gemv_kernel for the top conv and the dense tail
+            em1 = EmbeddingModel(blob, max_batch=1, device=dev)
+            extra_out["latency_plan"] = {k: em1.get_option(k) for k in ("fuse_cluster", "fuse_cluster_chain", "fuse_mid", "fuse_back", "fuse_gemv")}
 
             def latency(fn, n=200):
                 for _ in range(20):
@@ -623,7 +626,7 @@ def main():
                 keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup") if k in d}
                 keep["whole_step_frac"] = d["roofline"].get("whole_step_frac")
                 keep["dominant"] = {k: d["roofline"].get(k) for k in ("kernel", "bound", "frac", "avg_launch_ms")}
-                for k in ("latency_ms_batch1", "latency_ms_batch1_eager", "serving_lanes", "serving_lanes_used", "steps_per_forward", "windows_per_stream"):
+                for k in ("latency_ms_batch1", "latency_ms_batch1_eager", "latency_plan", "serving_lanes", "serving_lanes_used", "steps_per_forward", "windows_per_stream"):
                     if k in d:
                         keep[k] = d[k]
                 keep["workload"] = d["config"]["workload"]

@@ -4170,7 +4170,9 @@ struct ClusterChainArgs {
   const float* We[kClusterChainMax];
   int base[kClusterChainMax + 1];      // first workgroup id of every block (multiples of 8)
   signed char P[kClusterChainMax];
-  float* xc1; float* xd;               // exchange buffers of cluster 0 (the blocks use them one after the other)
+  float* xc1; float* xd;               // exchange buffers: block k uses cluster slot k -- NOT one slot for all: the blocks sit on different XCDs, and two
+                                       // L2s holding dirty copies of one line write them back in any order (seen as silently wrong windows beside a second
+                                       // handle's traffic, tools/chain_concurrency_probe.py)
   int* flags; int flag_stride;         // per-block flag region (ints): rows 0 / 1 of cluster slot 0 = the exchanges, row 0 of slot 1 = `done`
   int* err_dev; int* err_host; int fault;
 #ifdef MKWS_FRONT_TIMING
@@ -4196,7 +4198,7 @@ __global__ __launch_bounds__(256) void mbconv_cluster_chain_kernel(ClusterChainA
   ca.b.dbg_t = cc.dbg_t;
 #endif
   ca.Wr = cc.Wr[k]; ca.We = cc.We[k];
-  ca.xc1 = cc.xc1; ca.xd = cc.xd;
+  ca.xc1 = cc.xc1 + (size_t)k * kClusterPMax * kClXc1; ca.xd = cc.xd + (size_t)k * kClusterPMax * kClMaxTiles * 256;
   ca.flags = cc.flags + (size_t)(cc.i0 + k) * cc.flag_stride;
   ca.err_dev = cc.err_dev; ca.err_host = cc.err_host; ca.fault = cc.fault;
   ca.P = cc.P[k];
@@ -5226,6 +5228,7 @@ int cluster_chain_kind(const BlockPlan& b) {
 bool cluster_chain_ok(const mkws_embed* em, int i0, int i1) {
   if (!em->fuse_cluster_chain || !em->fuse_cluster || !em->cl_flags || !em->d_chain_tab || em->max_batch != 1) return false;
   if (i1 - i0 + 1 > kClusterChainMax || i1 - i0 + 1 < 2 || em->cl_flag_count / kNumBlocks < 4 * (size_t)kClFlagRow) return false;
+  if (em->cl_flag_count / ((size_t)2 * kClFlagRow * kNumBlocks) < (size_t)(i1 - i0 + 1)) return false;      // an exchange slot per block
   for (int i = i0; i <= i1; ++i) {
     const BlockPlan& b = em->blocks[i];
     if (!cluster_supported(b) || cluster_chain_kind(b) < 0 || (b.se.se & 3) != 0) return false;
@@ -5860,7 +5863,8 @@ int mkws_embed_create(const float* h, size_t n_floats, int max_batch, mkws_embed
   const size_t per_clip = 16000 * 2 + 48000 + 18720 + 1152 * 2 + 1280 + 2048 * 2 + 20480 + 9 * 48;
   const size_t pair_floats = pair_ws_floats(max_batch, em->pair_mt);
   // cluster exchange buffers exist for handles that may ever use the kernel (the option can be set after create up to 64 clips)
-  const size_t ncl = (max_batch <= 64) ? (size_t)cluster_count(max_batch, 1) : 0;
+  // (a one-clip handle's chain launch gives every block an exchange slot of its own: blocks on different XCDs must never hold dirty copies of one line)
+  const size_t ncl = (max_batch == 1) ? 16 : (max_batch <= 64) ? (size_t)cluster_count(max_batch, 1) : 0;
   const size_t cluster_floats = ncl * ((size_t)kClusterPMax * kClXc1 + (size_t)kClusterPMax * kClMaxTiles * 256 + (size_t)kNumBlocks * 2 * kClFlagRow);
   {
     const char* g = getenv("MKWS_EMBED_GUARD");
