@@ -187,7 +187,16 @@ int mkws_embed_forward(mkws_embed* em, const float* d_spec, int B, float* d_emb,
  *                 clip of a 4x3 image, four of a 2x2 image) and split the block's expanded channels, so that a single live window no
  *                 longer waits for one CU to pull a whole block's weights (batch-1 embedding 0.44 -> 0.30 ms); two in-kernel exchanges
  *                 with generation flags (graph-replayable).  Same failure contract as the paired kernel (above).
- *   "fuse_back" (default 1): blocks 2a, 2b, 3b run squeeze-excite + gated projection as
+ *   "fuse_cluster_chain" (default 1 for one-clip handles, max_batch == 1, that run "fuse_cluster"; refused on larger handles): a live window's
+ *                 blocks 4b..7a run as ONE launch of the cluster kernel's body: the 120 members of all ten blocks (block k on XCD k % 8) start
+ *                 together and request every weight they will need, then wait for the previous block's `done` generations; a block hands its
+ *                 output on with write-through stores + one generation word per member, the next reads it with L1-bypassing loads (placement-
+ *                 free); every block owns an exchange slot.  Bit-identical to one cluster launch per block (0); batch-1 embedding 0.283 ->
+ *                 0.255 ms.  Taps inside the range run launch by launch.  Same failure contract; several one-clip handles may run at once
+ *                 (measured up to six on six streams), but on a chip crowded by OTHER kernels members can wait for CUs until the bounded
+ *                 polls give up -- then the contract above applies.
+ *   "fuse_back" (default 1): blocks 2a, 2b, 3b (and 3a / 4a on handles that do not run them on the whole-block kernel: one-clip handles,
+ *                 "fuse_mid" = 0) run squeeze-excite + gated projection as
  *                 ONE kernel behind the fused expand+depthwise kernel (the clip's depthwise output is staged in LDS once);
  *                 0 = se_reduce + se_expand + projection GEMM launches.
  *   "fuse_mid" (default 1): blocks with big images run expand -> depthwise -> SE ->

@@ -537,6 +537,21 @@ def test_cluster_chain_plan_of_one_clip_handles(ctx):
     # a larger handle does not take the option
     with pytest.raises(_lib.MkwsError):
         EmbeddingModel(ctx["blob"], max_batch=2).set_option("fuse_cluster_chain", 1)
+    # three handles at once, a stream each (uneven load on the L2s: the first build of the kernel let blocks on different XCDs share one
+    # exchange slot and returned silently wrong windows here, never alone): every window identical to the lone result, nothing degraded
+    others = [em] + [EmbeddingModel(ctx["blob"], max_batch=1) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in others]
+    torch.cuda.synchronize()
+    outs = [[torch.empty((1, 1024), device=ctx["dev"]) for _ in range(60)] for _ in others]
+    for w in range(60):
+        for k, (e, st) in enumerate(zip(others, streams)):
+            with torch.cuda.stream(st):
+                e.forward(xs[(w + 5 * k) % 24:(w + 5 * k) % 24 + 1], out=outs[k][w])
+    torch.cuda.synchronize()
+    for k, e in enumerate(others):
+        assert e.get_option("pair_degraded") == 0 and e.get_option("fuse_cluster_chain") == 1
+        for w in range(60):
+            assert torch.equal(outs[k][w][0], chained[(w + 5 * k) % 24]), (k, w)
     # failure contract: a member that never arrives (fault 2) / a wrong XCC id (fault 1) poison the window, the next call reports and degrades
     for fault in (1, 2):
         emf = EmbeddingModel(ctx["blob"], max_batch=1)
