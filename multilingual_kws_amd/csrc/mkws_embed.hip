@@ -3902,8 +3902,9 @@ __device__ __forceinline__ void cluster_block(const ClusterArgs& ca, const int c
     if (tid < CH) { s_sc[tid] = sce; s_sh[tid] = she; }
     if constexpr (CHAINED) {
       // every weight of the block is requested; the SE weights / taps wait in LDS, the two rings in registers.  Now the block input: published by
-      // ALL members of the previous block (its finishers stored the tiles write-through before their `done` word)
-      park();
+      // ALL members of the previous block (its finishers stored the tiles write-through before their `done` word).  The chain's FIRST block has
+      // nobody to wait for and its weights are on the critical path: it keeps the per-block kernel's order (input first, park behind the expand)
+      if (wait_row != nullptr) park();
       __syncthreads();                                               // (s_bad is set)
       if (wait_row != nullptr) {
         if (wave == 0 && s_bad == 0) {
@@ -3944,10 +3945,33 @@ __device__ __forceinline__ void cluster_block(const ClusterArgs& ca, const int c
         }
       }
     };
-    stream_mfma_runs<NTWA, 12, 1, true>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, a_nruns, a.KCe, a_tile_of, xload, xmake, epi);
+    if (HW == 4 && a.KCe == 12) {
+      // 2x2 blocks (Cin = 192): ONE run per wave whose whole K sits in the ring -- straight-line code.  The general helper walks run-time
+      // (run, chunk) cursors with a conditional epilogue behind every ring slot: ~30 scalar / accumulator-shuffle instructions per 8 MFMAs
+      // (ISA, round 6), which a one-clip window cannot hide.  Same accumulation order per tile: bit-identical.
+      if (a_nruns == 1) {
+        f32x4 acc[NTWA][1];
+#pragma unroll
+        for (int q = 0; q < NTWA; ++q) acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 xr = xload(0, 0);
+#pragma unroll
+        for (int d = 0; d < 12; ++d) {
+          const f32x4 xn = xload(d + 1 < 12 ? d + 1 : d, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int q = 0; q < NTWA; ++q) acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wqa[d][q][s4], xr[s4], acc[q][0], 0, 0, 0);
+          xr = xn;
+        }
+        epi(a_tile_of(0), acc);
+      }
+    } else {
+      stream_mfma_runs<NTWA, 12, 1, true>(wqa, WBuf(a.WpE, loff), (size_t)a.NTe * 256, a.NTe, a_nruns, a.KCe, a_tile_of, xload, xmake, epi);
+    }
   }
   // the SE weights / depthwise taps requested before phase A go to LDS now (chained members parked them before the wait)
-  if constexpr (!CHAINED) park();
+  if (!CHAINED || wait_row == nullptr) park();
   __syncthreads();
   MKWS_CL_STAMP(2)
   // ---- B: depthwise + BN + swish in place, SE means (thread = clip x channel quad of the member's slice) ----
@@ -5202,16 +5226,17 @@ int launch_cluster(hipStream_t s, const char* stage, const BlockPlan& b, int blo
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> h((size_t)grid.x * 8);
     (void)hipMemcpy(h.data(), d_bt, h.size() * 8, hipMemcpyDeviceToHost);
-    double ph[6] = {0, 0, 0, 0, 0, 0}; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+    double ph[6] = {0, 0, 0, 0, 0, 0}; int n = 0; unsigned long long t0 = ~0ull, t1 = 0; double clk = 0;
     for (size_t i = 0; i < grid.x; ++i) {
       if (h[8 * i + 6] == 0) continue;
+      clk += (double)h[8 * i + 7] / ((double)(h[8 * i + 6] - h[8 * i]) / 100.0);      // shader-clock ticks per us of wall clock = MHz
       for (int k = 0; k < 6; ++k) ph[k] += (double)(h[8 * i + k + 1] - h[8 * i + k]);
       if (h[8 * i] < t0) t0 = h[8 * i];
       if (h[8 * i + 6] > t1) t1 = h[8 * i + 6];
       ++n;
     }
-    if (n) fprintf(stderr, "[cluster-timing] %s%s members %d: stage %.2f  A %.2f  B %.2f  C1+x1 %.2f  C2 %.2f  D+x2 %.2f us; span %.2f us\n", stage, rep ? " (again: L2-hot)" : "", n,
-                   ph[0] / n / 100.0, ph[1] / n / 100.0, ph[2] / n / 100.0, ph[3] / n / 100.0, ph[4] / n / 100.0, ph[5] / n / 100.0, (double)(t1 - t0) / 100.0);
+    if (n) fprintf(stderr, "[cluster-timing] %s%s members %d: stage %.2f  A %.2f  B %.2f  C1+x1 %.2f  C2 %.2f  D+x2 %.2f us; span %.2f us; shader clock %.0f MHz\n", stage, rep ? " (again: L2-hot)" : "", n,
+                   ph[0] / n / 100.0, ph[1] / n / 100.0, ph[2] / n / 100.0, ph[3] / n / 100.0, ph[4] / n / 100.0, ph[5] / n / 100.0, (double)(t1 - t0) / 100.0, clk / n);
   }
 #endif
   return MKWS_OK;
