@@ -161,6 +161,8 @@ def test_streaming_session_graph_replay_equals_eager_predict(batch):
     models = [tl.TransferLearnedModel(emb, Head(max_batch=batch, seed=s), blob, "synthetic") for s in range(5)]
     sess = bsa.StreamingSession(models, ms, batch=batch)
     assert sess.graph is not None
+    if batch == 1 and emb.get_option("fuse_cluster"):
+        assert emb.get_option("fuse_cluster_chain") == 1        # round 6: a live window's blocks 4b .. 7a replay as ONE cluster-chain launch
     eager = bsa.StreamingSession(models, ms, batch=batch, use_graph=False)
     clips = synth.clips_float32(3 * batch)
     for k in (0, 1, 2, 1):
